@@ -1,0 +1,175 @@
+"""Generate the data-only golden fixtures under tests/golden/ from the
+reference's own action code.  Run ONLY in the build container:
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+TEST INFRASTRUCTURE.  Needs /root/reference (never present on the GPU box).
+What comes from where:
+  * A, me, fe            -- reference `Annealer.A / me_gaussian / fe_gaussian`
+                            (va_ode.py:130-234) run unmodified under the py3
+                            loader in oracle/_refload.py.
+  * grad A               -- complex-step derivative THROUGH the reference's A
+                            (ADOL-C is not installed; see _refload docstring).
+  * ladders (g4_*)       -- the reference's own anneal()/anneal_step()/
+                            min_lbfgs_scipy() control flow (va_ode.py:459-789,
+                            _autodiffmin.py:72-95) + SciPy 1.15.3 L-BFGS-B,
+                            with adolc.function -> reference A and
+                            adolc.gradient -> oracle adjoint (checked against
+                            the complex-step goldens to <=1e-12).
+Inputs are seeded and stored in the fixture next to the outputs.
+"""
+import contextlib
+import io
+import os
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import _refload  # noqa: E402
+import va_oracle  # noqa: E402
+from varanneal_amd import twin  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+SHIPPED = os.path.join(_refload.REF_ROOT, "examples", "Lorenz96_D20",
+                       "l96_D20_dt0p025_N161_sm0p5_sec1_mem1.npy")
+EX_LIDX = [0, 2, 4, 6, 8, 10, 14, 16]      # Lorenz96_anneal.py:22
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def ref_annealer(va, Y, t, D=20):
+    a = va.Annealer()
+    a.set_model(twin.l96, D)
+    a.set_data(Y, t=t)
+    return a
+
+
+def single_eval_cases(va):
+    """g1/g2/g3: (XP0, Y, hyper-params) -> (A, me, fe, grad)."""
+    data = np.load(SHIPPED)
+    t161, Yfull = data[:, 0], data[:, 1:]
+    out = {}
+
+    def run(name, Y, t, Lidx, N_model, disc, RM, RF0, rf_scale, init_to_data, dt_model=None,
+            seed=12345, D=20, grad=True):
+        rng = np.random.RandomState(seed)
+        X0 = (20 * rng.rand(N_model * D) - 10).reshape(N_model, D)
+        P0 = np.array([4 * rng.rand() + 6])
+        a = ref_annealer(va, Y, t, D)
+        with quiet():
+            a.anneal_init(X0, P0.copy(), 1.5, np.arange(2), RM, RF0, Lidx, [0],
+                          dt_model=dt_model, init_to_data=init_to_data, disc=disc)
+        a.RF = a.RF0 * rf_scale
+        XP = a.minpaths[0].copy()
+        A = float(a.A(XP)); me = float(a.me_gaussian(XP[:N_model * D])); fe = float(a.fe_gaussian(XP))
+        rec = dict(XP=XP, Y=np.asarray(Y), Lidx=np.array(Lidx, dtype=np.int32), D=D,
+                   N_model=N_model, dt_model=float(a.dt_model), merr_nskip=int(a.merr_nskip),
+                   disc=disc, RM=np.asarray(RM, dtype=np.float64),
+                   RF0=np.asarray(RF0, dtype=np.float64), rf_scale=float(rf_scale),
+                   A=A, me=me, fe=fe)
+        if grad:
+            rec["grad"] = _refload.complex_step_grad(a.A, XP)
+        out[name] = rec
+        print("%-28s A=%.16e me=%.6e fe=%.6e" % (name, A, me, fe))
+
+    Y8 = Yfull[:, EX_LIDX]
+    # g1: values on the shipped data, three RF levels, all four discretisations
+    for disc in ("trapezoid", "SimpsonHermite", "euler", "forwardmap"):
+        for rfs in (1.0, 0.37 / 4e-6, 1e3 / 4e-6):
+            for itd in (True, False):
+                run("g1_%s_rf%.0e_itd%d" % (disc, 4e-6 * rfs, itd), Y8, t161, EX_LIDX, 161, disc,
+                    4.0, 4e-6, rfs, itd, grad=(rfs != 1e3 / 4e-6))
+    # g3: vector RM (L,), vector RF0 (D,), dt_model = dt_data/2
+    rng = np.random.RandomState(7)
+    RMv = list(4.0 * (0.5 + rng.rand(len(EX_LIDX))))
+    RFv = list(4e-6 * (0.5 + rng.rand(20)))
+    for disc in ("trapezoid", "SimpsonHermite", "euler"):
+        run("g3_vecRMRF_%s" % disc, Y8, t161, EX_LIDX, 161, disc, RMv, RFv, 1.5 ** 20, False)
+        run("g3_nskip2_%s" % disc, Y8, t161, EX_LIDX, 321, disc, 4.0, 4e-6, 1.5 ** 15, False,
+            dt_model=0.0125)
+    run("g3_nskip2_vec_trapezoid", Y8, t161, EX_LIDX, 321, "trapezoid", RMv, RFv, 1.5 ** 10, True,
+        dt_model=0.0125)
+    # g2: BASELINE C2 shape (D=20, N=1000, L=7) on twin data, full gradient
+    t, Y, _, Lidx = twin.make_twin(20, 1000)
+    run("g2_c2_trapezoid", Y, t, Lidx, 1000, "trapezoid", 4.0, 4e-6, 1.5 ** 12, False, seed=1000)
+    t, Y, _, Lidx = twin.make_twin(20, 1001)
+    run("g2_c2_SimpsonHermite", Y, t, Lidx, 1001, "SimpsonHermite", 4.0, 4e-6, 1.5 ** 12, False,
+        seed=1000)
+    return out
+
+
+def ladder_case(va, name, Y, t, Lidx, N, disc, nbeta, seed_index, D=20):
+    """g4: the reference's own ladder loop + SciPy."""
+    import adolc  # the inert stub registered by _refload
+    X0, P0 = twin.initial_guess(N, D, seed_index)
+    a = ref_annealer(va, Y, t, D)
+    opts = {'gtol': 1.0e-8, 'ftol': 1.0e-8, 'maxfun': 1000000, 'maxiter': 1000000}
+    nev = [0]
+
+    def fn(_id, XP):
+        nev[0] += 1
+        return a.A(XP)
+
+    def gr(_id, XP):
+        pb = va_oracle.Problem(D, N, Y, Lidx, a.dt_model, a.RM, a.RF0, a.P, [0], disc=disc)
+        return pb.action_grad(XP, a.RF / a.RF0)[3]
+
+    adolc.function, adolc.gradient = fn, gr
+    beta = np.arange(nbeta)
+    buf = io.StringIO()
+    X0in = X0.copy()
+    with contextlib.redirect_stdout(buf):
+        a.anneal(X0, P0.copy(), 1.5, beta, 4.0, 4e-6, Lidx, [0], dt_model=float(t[1] - t[0]),
+                 init_to_data=True, disc=disc, method='L-BFGS-B', opt_args=opts, adolcID=0)
+    nit = [int(l.split("=")[1]) for l in buf.getvalue().splitlines() if l.startswith("Iterations")]
+    flags = [int(l.split("=")[1]) for l in buf.getvalue().splitlines() if l.startswith("Exit flag")]
+    ND = N * D
+    rec = dict(Y=np.asarray(Y), t=np.asarray(t), Lidx=np.array(Lidx, dtype=np.int32), D=D, N=N,
+               disc=disc, X0=X0in, P0=P0, alpha=1.5, beta=beta, RM=4.0, RF0=4e-6,
+               gtol=1e-8, ftol=1e-8, seed_index=seed_index,
+               A_array=a.A_array.copy(), me_array=a.me_array.copy(), fe_array=a.fe_array.copy(),
+               params=a.minpaths[:, ND:].copy(), final_path=a.minpaths[-1, :ND].copy(),
+               path_mid=a.minpaths[nbeta // 2, :ND].copy(),
+               nit=np.array(nit), exitflag=np.array(flags), nfev_total=nev[0])
+    print("%-24s evals=%d  A_final=%.10e  k: %.4f -> %.6f  nit=%s" %
+          (name, nev[0], a.A_array[-1], P0[0], a.minpaths[-1, ND], nit))
+    return rec
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    va = _refload.load_reference("va_ode")
+    shutil.copyfile(SHIPPED, os.path.join(GOLD, os.path.basename(SHIPPED)))   # data file (MIT)
+    cases = single_eval_cases(va)
+    flat = {}
+    for cname, rec in cases.items():
+        for k, v in rec.items():
+            flat["%s/%s" % (cname, k)] = v
+    np.savez_compressed(os.path.join(GOLD, "single_eval.npz"), **flat)
+
+    lad = {}
+    t, Y, _, Lidx = twin.make_twin(20, 200)
+    lad["g4_c1_trapezoid_N200"] = ladder_case(va, "g4_c1_trapezoid_N200", Y, t, Lidx, 200,
+                                              "trapezoid", 30, 0)
+    data = np.load(SHIPPED)
+    lad["g4_shipped_SH_N161"] = ladder_case(va, "g4_shipped_SH_N161", data[:, 1:][:, EX_LIDX],
+                                            data[:, 0], EX_LIDX, 161, "SimpsonHermite", 30, 1)
+    flat = {}
+    for cname, rec in lad.items():
+        for k, v in rec.items():
+            flat["%s/%s" % (cname, k)] = v
+    np.savez_compressed(os.path.join(GOLD, "ladders.npz"), **flat)
+    for f in sorted(os.listdir(GOLD)):
+        print(f, os.path.getsize(os.path.join(GOLD, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,72 @@
+/* oracle/va_oracle.h -- CPU restatement of the variational-annealing hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; varanneal_amd/ never does.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function
+ * here against the .npz fixtures in tests/golden, which oracle/gen_golden.py produced by
+ * running the reference's own action code (varanneal/va_ode.py:130-234,
+ * 341-454 under the py3 loader oracle/_refload.py) -- values directly,
+ * gradients by complex-step through the reference's A (ADOL-C, the
+ * un-vendored third-party AD engine the reference calls at
+ * _autodiffmin.py:57-58, is not installed anywhere in this image).
+ */
+#ifndef VA_ORACLE_H
+#define VA_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VAO_DISC_EULER = 0, VAO_DISC_TRAPEZOID = 1, VAO_DISC_SIMPSON_HERMITE = 2,
+       VAO_DISC_FORWARDMAP = 3 };
+enum { VAO_RHS_LORENZ96 = 0, VAO_RHS_NAKL = 1 /* reserved */ };
+
+typedef struct {
+    int32_t D, N_model, N_data, merr_nskip, L;
+    const int32_t *Lidx;      /* [L] observed state indices              */
+    const double  *Y;         /* [N_data*L] observations                 */
+    double         dt_model;
+    const double  *rm_array;  /* NULL -> scalar rm; else [N_data*L] diag */
+    double         rm;
+    const double  *rf0_array; /* NULL -> scalar; else [(N_model-1)*D]    */
+    double         rf0;       /* RF = rf0 * rf_scale (rf_scale=alpha^beta) */
+    int32_t NP, NPest;
+    const int32_t *Pidx;      /* [NPest]                                 */
+    const double  *P;         /* [NP] full parameter vector (fixed part) */
+    int32_t disc, rhs;
+} vao_problem;
+
+/* One (A, me, fe, grad A) evaluation.  XP = [X (N*D row-major) | p_est].
+ * grad may be NULL (value only).  Returns 0, or <0 on bad arguments. */
+int vao_action_grad(const vao_problem *pb, const double *XP, double rf_scale,
+                    double *A, double *me, double *fe, double *grad);
+
+typedef struct {
+    int32_t m;          /* maxcor (SciPy default 10)  */
+    double  ftol, gtol; /* SciPy names: factr*epsmch, pgtol */
+    int32_t maxiter;
+    int64_t maxfun;
+    int32_t maxls;      /* SciPy default 20 */
+} vao_lbfgs_opts;
+
+/* Unbounded L-BFGS following the published L-BFGS-B 3.0 algorithm on its
+ * unconstrained path (what scipy.optimize.minimize(method='L-BFGS-B',
+ * bounds=None) executes; reference call site _autodiffmin.py:85-86).
+ * status: 0 converged, 1 maxiter/maxfun, 2 abnormal (SciPy warnflag).   */
+int vao_minimize_lbfgs(const vao_problem *pb, double *XP_inout, double rf_scale,
+                       const vao_lbfgs_opts *o, double *Amin, int32_t *status,
+                       int32_t *nit, int64_t *nfev);
+
+/* Full ladder for one seed (va_ode.py:459-490, 707-789).  out_minpaths is
+ * [nbeta*(N*D+NP)], out_ame is [nbeta*3] = (A, me, fe) per beta step.   */
+int vao_anneal(const vao_problem *pb, const double *XP0, double alpha,
+               const uint16_t *beta, int32_t nbeta, const vao_lbfgs_opts *o,
+               double *out_minpaths, double *out_ame, int32_t *out_status,
+               int32_t *out_nit, int64_t *out_nfev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

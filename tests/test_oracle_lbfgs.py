@@ -1,0 +1,65 @@
+"""CPU: the oracle's L-BFGS (published L-BFGS-B 3.0 unconstrained path +
+MINPACK-2 dcsrch) pinned behaviourally against scipy.optimize.minimize --
+the reference's actual minimiser (_autodiffmin.py:85-86) -- and the oracle's
+ladder against the golden ladders the reference's anneal() produced.
+
+Trajectory-level parity is chaotic: short runs must agree
+step for step; long runs must land in the same basin within loose tolerance."""
+import numpy as np
+import scipy.optimize as opt
+
+import va_oracle
+
+OPTS = {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000000, 'maxiter': 1000000}
+
+
+def _c1(golden_ladders, name="g4_c1_trapezoid_N200"):
+    c = golden_ladders[name]
+    N, D = int(c["N"]), int(c["D"])
+    X0 = c["X0"].copy()
+    X0[:, c["Lidx"]] = c["Y"]
+    XP0 = np.append(X0.flatten(), c["P0"])
+    pb = va_oracle.Problem(D, N, c["Y"], c["Lidx"], float(c["t"][1] - c["t"][0]), 4.0, 4e-6,
+                           c["P0"], [0], disc=str(c["disc"]))
+    return c, pb, XP0
+
+
+def test_short_runs_match_scipy_step_for_step(golden_ladders):
+    c, pb, XP0 = _c1(golden_ladders)
+    for rf in (1.0, 1.5 ** 3, 1.5 ** 7):
+        res = opt.minimize(lambda z: (lambda r: (r[0], r[3]))(pb.action_grad(z, rf)), XP0,
+                           method="L-BFGS-B", jac=True, options=OPTS)
+        x, A, st, nit, nfev = pb.minimize_lbfgs(XP0, rf, OPTS)
+        assert (nit, nfev, st) == (res.nit, res.nfev, res.status)
+        assert abs(A - res.fun) <= 1e-6 * abs(res.fun)
+        assert np.abs(x - res.x).max() <= 1e-5
+
+
+def test_maxiter_and_status_codes(golden_ladders):
+    c, pb, XP0 = _c1(golden_ladders)
+    o = dict(OPTS, maxiter=5)
+    res = opt.minimize(lambda z: (lambda r: (r[0], r[3]))(pb.action_grad(z, 1.5 ** 15)), XP0,
+                       method="L-BFGS-B", jac=True, options=o)
+    x, A, st, nit, nfev = pb.minimize_lbfgs(XP0, 1.5 ** 15, o)
+    assert st == res.status == 1 and nit == res.nit == 5 and nfev == res.nfev
+    assert abs(A - res.fun) <= 1e-9 * abs(res.fun)
+    # already-converged start: gtol satisfied at x0 -> 0 iterations, status 0
+    o = dict(OPTS, gtol=1e3)
+    x, A, st, nit, nfev = pb.minimize_lbfgs(XP0, 1.0, o)
+    assert (st, nit, nfev) == (0, 0, 1)
+
+
+def test_ladder_matches_reference_ladder(golden_ladders):
+    for name in ("g4_c1_trapezoid_N200", "g4_shipped_SH_N161"):
+        c, pb, XP0 = _c1(golden_ladders, name)
+        r = pb.anneal(XP0, float(c["alpha"]), c["beta"], OPTS)
+        ref_A, ref_k = c["A_array"], c["params"][:, 0]
+        # early ladder (few iterations per step): tight
+        assert np.all(np.abs(r["A"][:12] - ref_A[:12]) <= 1e-6 * ref_A[:12]), name
+        # end of ladder: same basin, loose (SURVEY.md 8(c) tolerances)
+        assert abs(r["A"][-1] - ref_A[-1]) <= 1e-3 * ref_A[-1], name
+        assert abs(r["minpaths"][-1, -1] - ref_k[-1]) <= 2e-3 * abs(ref_k[-1]), name
+        # iteration counts identical while the run is still short
+        assert list(r["nit"][:7]) == list(c["nit"][:7]), name
+        # A = me + fe at every stored step (va_ode.py:773-775)
+        assert np.allclose(r["A"], r["me"] + r["fe"], rtol=1e-12)

@@ -1,0 +1,67 @@
+"""Twin-experiment data for Lorenz-96 (the reference ships only one N=161 file,
+examples/Lorenz96_D20/l96_D20_dt0p025_N161_sm0p5_sec1_mem1.npy, and no
+generator).  Used by bench.py, the tests and examples to build the BASELINE
+configs (D=20 N=200/1000, D=200 N=5000) with identical bytes on every box.
+
+Model (examples/Lorenz96_D20/Lorenz96_anneal.py:15-16):
+    dx_i/dt = x_{i-1} (x_{i+1} - x_{i-2}) - x_i + k,  cyclic in i.
+"""
+import numpy as np
+
+K_TRUE = 8.17       # examples/jupyter-tutorial/Lorenz96/data file names ("k8p17")
+DT = 0.025          # dt of the shipped data file
+SIGMA = 0.5         # "sm0p5"
+GEN_SEED = 20260101
+README_LIDX_D20 = [0, 2, 4, 8, 10, 14, 16]      # README.md:105 (L=7)
+
+
+def l96(t, x, k):
+    """The reference example's RHS, verbatim semantics (rows = time points)."""
+    return np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - x + k
+
+
+def _f1(x, k):
+    return np.roll(x, 1) * (np.roll(x, -1) - np.roll(x, 2)) - x + k
+
+
+def integrate_l96(D, N, dt=DT, k=K_TRUE, seed=GEN_SEED, spinup=2000):
+    """RK4 trajectory (N, D) sampled every dt after a transient."""
+    rng = np.random.RandomState(seed)
+    x = k * np.ones(D) + 0.01 * rng.randn(D)
+    out = np.empty((N, D))
+    for n in range(-spinup, N):
+        if n >= 0:
+            out[n] = x
+        k1 = _f1(x, k); k2 = _f1(x + 0.5 * dt * k1, k)
+        k3 = _f1(x + 0.5 * dt * k2, k); k4 = _f1(x + dt * k3, k)
+        x = x + dt * (k1 + 2 * k2 + 2 * k3 + k4) / 6.0
+    return out
+
+
+def default_lidx(D):
+    """L=7 of D=20 (README.md:105); for other D every index with i%5 in {0,2}
+    (L=80 of D=200)."""
+    if D == 20:
+        return list(README_LIDX_D20)
+    return [i for i in range(D) if i % 5 in (0, 2)]
+
+
+def make_twin(D, N, Lidx=None, dt=DT, k=K_TRUE, sigma=SIGMA, seed=GEN_SEED):
+    """Returns (t (N,), Y (N, L) noisy observations, truth (N, D), Lidx)."""
+    Lidx = default_lidx(D) if Lidx is None else list(Lidx)
+    truth = integrate_l96(D, N, dt, k, seed)
+    rng = np.random.RandomState(seed + 1)
+    Y = truth[:, Lidx] + sigma * rng.randn(N, len(Lidx))
+    t = dt * np.arange(N)
+    return t, Y, truth, Lidx
+
+
+def initial_guess(N, D, seed_index, Y=None, Lidx=None, nskip=1):
+    """X0 ~ U(-10,10), P0 ~ U(6,10) (Lorenz96_anneal.py:51,68) from
+    RandomState(1000+seed_index); optionally init_to_data (va_ode.py:677-678)."""
+    rng = np.random.RandomState(1000 + int(seed_index))
+    X0 = (20.0 * rng.rand(N * D) - 10.0).reshape(N, D)
+    P0 = np.array([4.0 * rng.rand() + 6.0])
+    if Y is not None:
+        X0[::nskip, Lidx] = Y
+    return X0, P0
