@@ -54,8 +54,9 @@ def test_ladder_matches_reference_ladder(golden_ladders):
         c, pb, XP0 = _c1(golden_ladders, name)
         r = pb.anneal(XP0, float(c["alpha"]), c["beta"], OPTS)
         ref_A, ref_k = c["A_array"], c["params"][:, 0]
-        # early ladder (few iterations per step): tight
-        assert np.all(np.abs(r["A"][:12] - ref_A[:12]) <= 1e-6 * ref_A[:12]), name
+        # early ladder (few iterations per step): within the optimiser's own
+        # stopping threshold (ftol is an ABSOLUTE 1e-8 while A << 1)
+        assert np.all(np.abs(r["A"][:12] - ref_A[:12]) <= 1e-8), name
         # end of ladder: same basin, loose (SURVEY.md 8(c) tolerances)
         assert abs(r["A"][-1] - ref_A[-1]) <= 1e-3 * ref_A[-1], name
         assert abs(r["minpaths"][-1, -1] - ref_k[-1]) <= 2e-3 * abs(ref_k[-1]), name
