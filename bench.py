@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""bench.py -- (A, grad A) evaluations per second of the variational-annealing action
+on MI355X, against the HBM roofline, with the CPU oracle timed beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c4|c2] [--no-cpu]
+
+A "step" is ONE batched evaluation (one k_eval launch): the action A(X,p) and its
+full gradient for all B resident seeds.  Paths are resident in HBM before the
+timed region.  N>1: one process per GPU (torch.distributed over RCCL), B seeds per
+GPU (weak scaling), no data-path collective; one all_gather of the per-seed actions
+closes the timed region.
+
+Workloads (BASELINE.json configs):
+  c3 (default)  Lorenz-96 D=20,  N=1000, L=7,  B=64 seeds per GPU, trapezoid
+  c4            Lorenz-96 D=200, N=5000, L=80, B=64 seeds per GPU, trapezoid
+  c2            Lorenz-96 D=20,  N=1000, L=7,  B=1  (parity config; launch-bound)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "c3": dict(D=20, N=1000, B=64, name="lorenz96_D20_N1000_L7_B64_trapezoid"),
+    "c4": dict(D=200, N=5000, B=64, name="lorenz96_D200_N5000_L80_B64_trapezoid"),
+    "c2": dict(D=20, N=1000, B=1, name="lorenz96_D20_N1000_L7_B1_trapezoid"),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+RF_SCALE = 1.5 ** 15           # mid-ladder RF (value does not change the work)
+
+
+def bytes_alg(B, N, D, NPest, N_data, L):
+    """read X once, write grad once, p/grad-p, (A,me,fe); Y once per batch."""
+    return 8 * (B * (2 * N * D + 2 * NPest + 3) + N_data * L)
+
+
+def make_inputs(D, N, B, rank):
+    from varanneal_amd import twin
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    XP = np.empty((B, N * D + 1)); P = np.empty((B, 1))
+    for b in range(B):
+        X0, P0 = twin.initial_guess(N, D, rank * B + b, Y, Lidx)      # global seed index
+        XP[b, :-1] = X0.ravel(); XP[b, -1] = P0[0]; P[b] = P0
+    return Y, Lidx, XP, P
+
+
+def cpu_baseline(D, N, Y, Lidx, XP, P, budget_s=10.0):
+    """The oracle's C restatement (oracle/va_oracle.c: vao_action_grad), ONE host core,
+    same inputs, bounded sample.  Test infrastructure used only as the reported baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import va_oracle
+    from varanneal_amd import twin
+    pbs = [va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[b], [0], disc="trapezoid")
+           for b in range(min(len(P), 8))]
+    pbs[0].action_grad(XP[0], RF_SCALE)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        for b, pb in enumerate(pbs):
+            pb.action_grad(XP[b], RF_SCALE)
+        n += len(pbs)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": "%d (A,gradA) evaluations of the same D=%d N=%d paths in %.1f s on 1 of %d host cores"
+                      % (n, D, N, dt, os.cpu_count() or 0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--tile-rows", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    from varanneal_amd import _capi, twin
+    w = WORKLOADS[args.workload]
+    D, N, B = w["D"], w["N"], w["B"]
+    Y, Lidx, XP, P = make_inputs(D, N, B, rank)
+    pb = _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid",
+                       device=local_rank, tile_rows=args.tile_rows)
+    info = pb.info()
+    A, me, fe, g = pb.action_grad(XP, RF_SCALE)          # paths now resident in HBM
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    pb.eval_timed(RF_SCALE, max(args.warmup, 1))
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = pb.eval_timed(RF_SCALE, args.steps)      # HIP events on the launch stream
+    if dist is not None:                                 # the single RCCL gather of per-seed actions
+        mine = torch.from_numpy(A).cuda()
+        allA = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allA, mine)
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall, kernel_ms = float(tmax[0]), float(tmax[1])
+
+    if rank == 0:
+        balg = bytes_alg(B, N, D, 1, N, len(Lidx))
+        kern_s = kernel_ms * 1e-3 / args.steps
+        achieved = balg / kern_s / 1e9
+        out = {
+            "metric": "action+grad evals/sec, Lorenz-96 D=%d N=%d" % (D, N),
+            "value": world * B * args.steps / wall, "unit": "evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic (Lorenz-96 twin experiment, k=8.17, sigma=0.5, seeded)",
+            "config": {"workload": w["name"], "seeds_per_gpu": B, "D": D, "N": N, "L": len(Lidx),
+                       "disc": "trapezoid", "tile_rows": info["tile_rows"], "ntiles": info["ntiles"],
+                       "parallelism": "seeds sharded, %d per GPU" % B},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_eval<RhsL96,trapezoid>", "kernel_us": kern_s * 1e6,
+                         "bytes_alg_per_launch": balg},
+            "cpu_baseline": None,
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(D, N, Y, Lidx, XP, P)
+        print(json.dumps(out), flush=True)
+    pb.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,148 @@
+/* include/varanneal_amd.h -- C-ABI of the MI355X-native variational-annealing
+ * hot path (libvaranneal_amd.so, HIP for gfx950).
+ *
+ * The reference (paulrozdeba/varanneal) has no FFI: its seam is the ADmin
+ * mixin that va_ode.Annealer inherits (varanneal/va_ode.py:41,43).  Each entry
+ * point below names the reference interface it stands in for; the ctypes
+ * binding a maintainer would add is shown in INTEGRATION.md and implemented in
+ * varanneal_amd/_capi.py.
+ *
+ * Conventions
+ *   - every function returns VA_OK (0) or a negative VA_E* code; never exits,
+ *     never throws (reference: print + sys.exit(1), va_ode.py:622-623,637-638).
+ *     va_last_error() returns a thread-local message for the last failure.
+ *   - caller owns every pointer it passes; host inputs need only stay valid
+ *     for the duration of the call.
+ *   - a handle is bound to one device and one HIP stream and is NOT re-entrant;
+ *     distinct handles may be used from distinct threads.
+ *   - all arithmetic is float64.
+ *   - path vectors use the reference's packing (va_ode.py:688-693):
+ *         XP[b] = [ X[b] flattened (N_model*D, time-major) | p_est (NPest) ]
+ *     `ld` is the stride in doubles between consecutive seeds (>= n_var).
+ *     `mem` says where XP/grad/outputs live: host (copied in/out) or device
+ *     (used in place, no PCIe traffic).
+ */
+#ifndef VARANNEAL_AMD_H
+#define VARANNEAL_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VA_ABI_VERSION 1
+
+enum { VA_OK = 0, VA_EINVAL = -1, VA_ENOMEM = -2, VA_EHIP = -3, VA_EUNSUPPORTED = -4,
+       VA_ESTATE = -5 };
+
+/* discretisations: va_ode.py:341-356 (euler), 358-380 (trapezoid),
+ * 404-437 (SimpsonHermite, needs odd N_model), 439-454 (forwardmap) */
+enum { VA_DISC_EULER = 0, VA_DISC_TRAPEZOID = 1, VA_DISC_SIMPSON_HERMITE = 2,
+       VA_DISC_FORWARDMAP = 3 };
+
+/* built-in right-hand sides (the user `f(t,x,p)` of set_model, va_ode.py:56-67).
+ * LORENZ96: examples/Lorenz96_D20/Lorenz96_anneal.py:15-16, NP = 1 (forcing k). */
+enum { VA_RHS_LORENZ96 = 0 };
+
+enum { VA_MEM_HOST = 0, VA_MEM_DEVICE = 1 };
+
+typedef struct va_problem_s *va_handle;
+
+/* Everything anneal_init() freezes (va_ode.py:531-705). */
+typedef struct va_problem_desc {
+    int32_t struct_size;      /* = sizeof(va_problem_desc)                          */
+    int32_t device;           /* HIP device ordinal                                  */
+    int32_t batch;            /* B: independent initial paths ("seeds") resident     */
+    int32_t D;                /* state dimension (set_model)                         */
+    int32_t N_model;          /* time points of the path                             */
+    int32_t N_data;           /* observation times                                   */
+    int32_t merr_nskip;       /* int(dt_data/dt_model), va_ode.py:556                */
+    int32_t L;                /* observed components                                 */
+    const int32_t *Lidx;      /* [L]                                                 */
+    const double *Y;          /* [N_data*L] observations, shared by all seeds        */
+    double dt_model;
+    int32_t rm_kind;          /* 0: scalar rm;  1: rm_array [N_data*L] (va_ode.py:147-148) */
+    double rm;
+    const double *rm_array;
+    int32_t rf_kind;          /* 0: scalar rf0; 1: rf0_array [(N_model-1)*D] (va_ode.py:203-209) */
+    double rf0;
+    const double *rf0_array;
+    int32_t NP;               /* parameters of the RHS                               */
+    int32_t NPest;            /* how many are estimated                              */
+    const int32_t *Pidx;      /* [NPest] indices into the parameter vector           */
+    const double *P;          /* [B*NP] full parameter vector of every seed          */
+    int32_t disc;             /* VA_DISC_*                                           */
+    int32_t rhs;              /* VA_RHS_*                                            */
+    int32_t lbfgs_m;          /* history pairs kept on device (SciPy maxcor, 10)     */
+    int32_t max_beta;         /* longest ladder va_anneal will be asked for (>=1)    */
+    int32_t keep_paths;       /* 1: keep every beta step's path on device (minpaths) */
+    int32_t tile_rows;        /* 0 = auto; time rows per workgroup                   */
+    void *stream;             /* hipStream_t to run on; NULL = library-owned stream  */
+} va_problem_desc;
+
+/* SciPy option names (reference passes opt_args through, _autodiffmin.py:85-86) */
+typedef struct va_lbfgs_opts {
+    int32_t maxcor;           /* <= desc.lbfgs_m                                     */
+    double ftol;              /* (f_k - f_{k+1})/max(|f_k|,|f_{k+1}|,1) <= ftol      */
+    double gtol;              /* max|g_i| <= gtol                                    */
+    int32_t maxiter;
+    int64_t maxfun;
+    int32_t maxls;
+} va_lbfgs_opts;
+
+int32_t va_abi_version(void);
+const char *va_last_error(void);
+int va_device_count(int32_t *count);
+
+int va_problem_create(const va_problem_desc *desc, va_handle *out);
+void va_problem_destroy(va_handle h);
+
+/* n_var = N_model*D + NPest; ld_internal = device stride the library uses. */
+int va_problem_info(va_handle h, int64_t *n_var, int64_t *ld_internal, int32_t *tile_rows,
+                    int32_t *ntiles);
+
+/* S1 evaluator -- replaces ADmin.A_gradA_taped (_autodiffmin.py:57-58), batched:
+ * (A, me, fe, grad A) for all B seeds at RF = RF0*rf_scale.  me/fe follow
+ * me_gaussian/fe_gaussian (va_ode.py:138-234).  A/me/fe: [B]; grad: [B*ldg] or NULL.
+ * Outputs live where `mem` says. */
+int va_action_grad(va_handle h, const double *XP, int64_t ld, int32_t mem, double rf_scale,
+                   double *A, double *me, double *fe, double *grad, int64_t ldg);
+
+/* S2 minimiser -- replaces ADmin.min_lbfgs_scipy (_autodiffmin.py:72-95) for
+ * bounds=None: device-resident batched L-BFGS with L-BFGS-B's stopping rules.
+ * status[b]: 0 converged, 1 maxiter/maxfun reached, 2 abnormal (SciPy warnflag).
+ * XP_inout (mem) receives the minimisers; Amin/status/nit/nfev are HOST arrays [B]. */
+int va_minimize_lbfgs(va_handle h, double *XP_inout, int64_t ld, int32_t mem, double rf_scale,
+                      const va_lbfgs_opts *opts, double *Amin, double *me, double *fe,
+                      int32_t *status, int32_t *nit, int64_t *nfev);
+
+/* S3 ladder -- replaces the beta loop of Annealer.anneal + anneal_step
+ * (va_ode.py:474-490, 707-789) for all B seeds, each seed climbing the ladder
+ * at its own pace, without returning to the host between steps.
+ *   rf_scale[nbeta]  = alpha**beta_k (computed by the caller, va_ode.py:650,782)
+ *   XP_inout         start paths in, final-step minimisers out
+ *   ame  [B*nbeta*3] HOST: (A, me, fe) per seed per step (va_ode.py:773-775)
+ *   pest [B*nbeta*NPest] HOST: estimated parameters per step (may be NULL)
+ *   status/nit/nfev [B*nbeta] HOST (may be NULL)
+ *   minpaths [B*nbeta*(N_model*D+NP)] HOST or NULL; needs desc.keep_paths=1 */
+int va_anneal(va_handle h, double *XP_inout, int64_t ld, int32_t mem, const double *rf_scale,
+              int32_t nbeta, const va_lbfgs_opts *opts, double *ame, double *pest,
+              int32_t *status, int32_t *nit, int64_t *nfev, double *minpaths);
+
+/* Copy the path stored for (seed, beta step) by the last va_anneal (keep_paths=1):
+ * out[N_model*D + NP] HOST. */
+int va_get_minpath(va_handle h, int32_t seed, int32_t beta_idx, double *out);
+
+/* Measurement hook for bench.py: launches the (A, grad A) kernel `iters` times on
+ * the resident paths (those of the last va_action_grad / va_anneal call),
+ * bracketed by HIP events on the handle's stream; returns elapsed ms. */
+int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms);
+
+/* Cumulative counters since create: batched eval launches, seed-evaluations,
+ * L-BFGS cycles. */
+int va_get_counters(va_handle h, int64_t *eval_launches, int64_t *seed_evals, int64_t *cycles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VARANNEAL_AMD_H */

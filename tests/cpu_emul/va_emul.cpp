@@ -1,0 +1,241 @@
+// tests/cpu_emul/va_emul.cpp -- TEST INFRASTRUCTURE.
+// Serial driver for the __host__ __device__ logic in varanneal_amd/csrc/va_core.h:
+// the same tile phases / line-search / coefficient-space two-loop code the HIP
+// kernels execute, run phase by phase with an emulated thread loop.  Lets the CPU
+// test-suite cover halo indexing, edge tiles and the per-seed state machine without
+// a GPU.  Never linked into libvaranneal_amd.so and never used as a fallback.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/varanneal_amd.h"
+#include "../../varanneal_amd/csrc/va_core.h"
+
+using namespace va;
+
+namespace {
+
+struct Emul {
+    Dims dm;
+    ProblemPtrs pp;
+    std::vector<int> lmap, pidx;
+    std::vector<double> Y, rm, rf0, P;
+    int rhs;
+};
+
+int setup(const va_problem_desc *d, int T, Emul &E)
+{
+    Dims &m = E.dm;
+    m.D = d->D; m.N = d->N_model; m.ND = m.D * m.N; m.L = d->L; m.N_data = d->N_data;
+    m.nskip = d->merr_nskip; m.NP = d->NP; m.NPest = d->NPest; m.B = d->batch;
+    m.m = d->lbfgs_m > 0 ? d->lbfgs_m : 10; m.disc = d->disc;
+    m.ld = ((m.ND + m.NPest + 15) / 16) * 16;
+    if (m.disc == DISC_SH && (T & 1)) ++T;
+    m.T = T; m.ntiles = (m.N + T - 1) / T;
+    m.chunk = 1000; m.nchunks = (m.ld + m.chunk - 1) / m.chunk;
+    m.dt = d->dt_model; m.cme = 1.0 / ((double)m.L * m.N_data); m.cfe = 1.0 / ((double)m.D * (m.N - 1));
+    m.rm = d->rm; m.rf0 = d->rf0;
+    E.lmap.assign(m.D, -1);
+    for (int l = 0; l < m.L; ++l) E.lmap[d->Lidx[l]] = l;
+    E.Y.assign(d->Y, d->Y + (size_t)m.N_data * m.L);
+    if (d->rm_kind) E.rm.assign(d->rm_array, d->rm_array + (size_t)m.N_data * m.L);
+    if (d->rf_kind) E.rf0.assign(d->rf0_array, d->rf0_array + (size_t)(m.N - 1) * m.D);
+    E.pidx.assign(d->Pidx, d->Pidx + m.NPest);
+    E.P.assign(d->P, d->P + (size_t)m.B * m.NP);
+    E.pp.lmap = E.lmap.data(); E.pp.Y = E.Y.data();
+    E.pp.rm_arr = d->rm_kind ? E.rm.data() : nullptr;
+    E.pp.rf0_arr = d->rf_kind ? E.rf0.data() : nullptr;
+    E.pp.Pidx = E.pidx.data(); E.pp.Pfull = E.P.data();
+    E.rhs = d->rhs;
+    if (m.disc == DISC_SH && (m.N % 2) == 0) return VA_EINVAL;
+    return VA_OK;
+}
+
+// K1 for one seed: all tiles, emulated NT threads per tile; returns summed partials.
+template <class RHS, int DISC>
+void eval_seed(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
+               double rf_scale, double *gt, double *ev)
+{
+    const Dims &dm = E.dm;
+    const int NT = 48;                         // deliberately not a divisor of anything
+    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
+    const int R = dm.T + HL + HR;
+    std::vector<double> xs(R * dm.D), fs(R * dm.D), qs(R * dm.D);
+    for (int k = 0; k < EP_N; ++k) ev[k] = 0.0;
+    for (int tile = 0; tile < dm.ntiles; ++tile) {
+        TileCtx c;
+        c.n0 = tile * dm.T; c.R = R; c.use_d = use_d; c.stp = stp; c.c = 2.0 * rf_scale * dm.cfe;
+        c.xs = xs.data(); c.fs = fs.data(); c.qs = qs.data();
+        c.xg = x; c.dg = d; c.gtg = gt;
+        tile_params<RHS>(dm, E.pp, b, c);
+        std::vector<ThreadAcc> acc(NT);
+        for (auto &a : acc) a.clear();
+        for (int t = 0; t < NT; ++t) tile_load<DISC>(dm, c, t, NT);
+        for (int t = 0; t < NT; ++t) tile_f<RHS, DISC>(dm, c, t, NT);
+        for (int t = 0; t < NT; ++t) tile_q<DISC>(dm, E.pp, c, acc[t], t, NT);
+        for (int t = 0; t < NT; ++t) tile_s<DISC>(dm, c, t, NT);
+        for (int t = 0; t < NT; ++t) tile_g<RHS, DISC>(dm, E.pp, c, acc[t], t, NT);
+        for (int t = 0; t < NT; ++t)
+            for (int k = 0; k < EP_N; ++k) {
+                if (k == EP_GMAX) ev[k] = fmax(ev[k], acc[t].v[k]);
+                else ev[k] += acc[t].v[k];
+            }
+    }
+}
+
+template <int DISC>
+void eval_seed_rhs(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
+                   double rf_scale, double *gt, double *ev)
+{
+    eval_seed<RhsL96, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+}
+
+void eval_dispatch(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
+                   double rf_scale, double *gt, double *ev)
+{
+    switch (E.dm.disc) {
+    case DISC_EULER: eval_seed_rhs<DISC_EULER>(E, b, x, d, use_d, stp, rf_scale, gt, ev); break;
+    case DISC_TRAPEZOID: eval_seed_rhs<DISC_TRAPEZOID>(E, b, x, d, use_d, stp, rf_scale, gt, ev); break;
+    case DISC_SH: eval_seed_rhs<DISC_SH>(E, b, x, d, use_d, stp, rf_scale, gt, ev); break;
+    default: eval_seed_rhs<DISC_FWDMAP>(E, b, x, d, use_d, stp, rf_scale, gt, ev); break;
+    }
+}
+
+// parameter tail of the gradient and its contributions to the line-search sums
+void finish_tail(const Emul &E, const double *d, int use_d, double *gt, double *ev)
+{
+    const Dims &dm = E.dm;
+    for (int k = 0; k < dm.NPest; ++k) {
+        double g = ev[EP_GP + E.pidx[k]];
+        gt[dm.ND + k] = g;
+        if (use_d) ev[EP_GTD] += g * d[dm.ND + k];
+        ev[EP_GN2] += g * g;
+        ev[EP_GMAX] = fmax(ev[EP_GMAX], fabs(g));
+    }
+}
+
+}  // namespace
+
+extern "C" int emul_action_grad(const va_problem_desc *desc, int T, const double *XP, double rf_scale,
+                                double *A, double *me, double *fe, double *grad)
+{
+    Emul E;
+    int rc = setup(desc, T, E);
+    if (rc) return rc;
+    const Dims &dm = E.dm;
+    const int nv = dm.ND + dm.NPest;
+    std::vector<double> gt(dm.ld);
+    for (int b = 0; b < dm.B; ++b) {
+        double ev[EP_N];
+        eval_dispatch(E, b, XP + (size_t)b * nv, nullptr, 0, 0.0, rf_scale, gt.data(), ev);
+        finish_tail(E, nullptr, 0, gt.data(), ev);
+        me[b] = ev[EP_ME] * dm.cme; fe[b] = ev[EP_FE] * dm.cfe * rf_scale; A[b] = me[b] + fe[b];
+        if (grad) memcpy(grad + (size_t)b * nv, gt.data(), sizeof(double) * nv);
+    }
+    return VA_OK;
+}
+
+extern "C" int emul_anneal(const va_problem_desc *desc, int T, double *XP, const double *rf_scale,
+                           int nbeta, const va_lbfgs_opts *o_, double *ame, double *pest,
+                           int *status, int *nit, long long *nfev, double *minpaths,
+                           long long *cycles_out)
+{
+    Emul E;
+    int rc = setup(desc, T, E);
+    if (rc) return rc;
+    const Dims &dm = E.dm;
+    const int nv = dm.ND + dm.NPest, ld = dm.ld, M = dm.m, wide = dm.ND + dm.NP;
+    Opts o; o.m = o_->maxcor < M ? o_->maxcor : M; o.maxiter = o_->maxiter; o.maxls = o_->maxls;
+    o.maxfun = o_->maxfun; o.ftol = o_->ftol; o.gtol = o_->gtol;
+    const int B = dm.B;
+    std::vector<double> x((size_t)B * ld, 0.0), g((size_t)B * ld, 0.0), gt((size_t)B * ld, 0.0),
+        d((size_t)B * ld, 0.0), S((size_t)B * M * ld, 0.0), Yh((size_t)B * M * ld, 0.0);
+    std::vector<SeedState> st(B);
+    std::vector<double> dirp((size_t)B * DP_N, 0.0);
+    int n_active = B;
+    long long cycles = 0;
+    for (int b = 0; b < B; ++b) {
+        memcpy(&x[(size_t)b * ld], XP + (size_t)b * nv, sizeof(double) * nv);
+        memset(&st[b], 0, sizeof(SeedState));
+        st[b].phase = PH_START; st[b].beta_idx = 0; st[b].rf_scale = rf_scale[0]; st[b].theta = 1.0;
+    }
+    while (n_active > 0) {
+        ++cycles;
+        for (int b = 0; b < B; ++b) {
+            SeedState &s = st[b];
+            if (s.phase != PH_START && s.phase != PH_LS) continue;
+            double *xb = &x[(size_t)b * ld], *gb = &g[(size_t)b * ld], *gtb = &gt[(size_t)b * ld],
+                   *db = &d[(size_t)b * ld];
+            // K1
+            double ev[EP_N];
+            const int use_d = s.phase == PH_LS;
+            eval_dispatch(E, b, xb, db, use_d, s.stp, s.rf_scale, gtb, ev);
+            // K2
+            finish_tail(E, db, use_d, gtb, ev);
+            SeedResults r;
+            r.ame = ame + (size_t)b * nbeta * 3;
+            r.pest = pest ? pest + (size_t)b * nbeta * dm.NPest : nullptr;
+            r.status = status + (size_t)b * nbeta; r.nit = nit + (size_t)b * nbeta;
+            r.nfev = nfev + (size_t)b * nbeta;
+            int dec = 0;
+            ls_step(s, ev, &dirp[(size_t)b * DP_N], o, rf_scale, nbeta, r, &dec, dm.cme, dm.cfe);
+            n_active -= dec;
+            // K3
+            double up[UP_N];
+            for (int k = 0; k < UP_N; ++k) up[k] = 0.0;
+            if (s.upd || s.dir) {
+                const bool hist = s.upd & UPD_HIST;
+                double *Sn = hist ? &S[((size_t)b * M + s.slot) * ld] : nullptr;
+                double *Yn = hist ? &Yh[((size_t)b * M + s.slot) * ld] : nullptr;
+                for (int i = 0; i < ld; ++i) {
+                    const double dv = db[i], gv = gb[i], gtv = gtb[i];
+                    double xn = xb[i];
+                    if (s.upd & UPD_X) { xn = trial(xn, s.stp_upd, dv); xb[i] = xn; }
+                    double sv = 0.0, yv = 0.0;
+                    if (hist) { sv = s.stp_upd * dv; yv = gtv - gv; Sn[i] = sv; Yn[i] = yv; }
+                    if (s.upd & UPD_G) gb[i] = gtv;
+                    if (s.dir) {
+                        up[UP_YGT] += yv * gtv; up[UP_SGT] += sv * gtv; up[UP_YY] += yv * yv;
+                        up[UP_SY] += sv * yv; up[UP_GTGT] += gtv * gtv;
+                        for (int j = 0; j < s.nold; ++j) {
+                            const double sj = S[((size_t)b * M + s.order[j]) * ld + i],
+                                         yj = Yh[((size_t)b * M + s.order[j]) * ld + i];
+                            up[UP_OLD + 4 * j + 0] += sj * gtv; up[UP_OLD + 4 * j + 1] += yj * gtv;
+                            up[UP_OLD + 4 * j + 2] += sj * yv; up[UP_OLD + 4 * j + 3] += yj * yv;
+                        }
+                    }
+                }
+                if (s.upd & UPD_STORE) {
+                    const int k = s.store_idx;
+                    if (minpaths) {
+                        double *mp = minpaths + ((size_t)b * nbeta + k) * wide;
+                        memcpy(mp, xb, sizeof(double) * dm.ND);
+                        for (int j = 0; j < dm.NP; ++j) mp[dm.ND + j] = E.P[(size_t)b * dm.NP + j];
+                        for (int j = 0; j < dm.NPest; ++j) mp[dm.ND + E.pidx[j]] = xb[dm.ND + j];
+                    }
+                    if (r.pest) for (int j = 0; j < dm.NPest; ++j) r.pest[k * dm.NPest + j] = xb[dm.ND + j];
+                }
+            }
+            if (s.dir) {
+                // K4
+                direction_coeffs(s, up, o);
+                // K5
+                double gd = 0.0, dd = 0.0;
+                for (int i = 0; i < ld; ++i) {
+                    double v = s.cg * gb[i];
+                    for (int j = 0; j < s.col; ++j) {
+                        const int sj = s.order[j];
+                        v += s.cY[sj] * Yh[((size_t)b * M + sj) * ld + i];
+                        v += s.cS[sj] * S[((size_t)b * M + sj) * ld + i];
+                    }
+                    db[i] = v; gd += gb[i] * v; dd += v * v;
+                }
+                dirp[(size_t)b * DP_N + DP_GD] = gd; dirp[(size_t)b * DP_N + DP_DD] = dd;
+            }
+        }
+    }
+    for (int b = 0; b < B; ++b) memcpy(XP + (size_t)b * nv, &x[(size_t)b * ld], sizeof(double) * nv);
+    if (cycles_out) *cycles_out = cycles;
+    return VA_OK;
+}

@@ -1,0 +1,80 @@
+"""CPU: the C-ABI library loads and exports every symbol include/varanneal_amd.h
+declares; argument validation that needs no GPU; the ctypes structs match the header."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "varanneal_amd.h")
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from varanneal_amd import _build, _capi
+    _build.build(verbose=False)
+    return _capi
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(va_[a-z_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(capi):
+    names = declared_functions()
+    assert len(names) >= 12
+    lib = capi.lib()
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(capi.EXPORTS) == names
+    assert lib.va_abi_version() == 1
+
+
+def test_struct_layout_matches_header(capi, tmp_path):
+    prog = tmp_path / "sz.c"
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "varanneal_amd.h"\n'
+                    'int main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(va_problem_desc), sizeof(va_lbfgs_opts),'
+                    ' offsetof(va_problem_desc, rf0_array), offsetof(va_problem_desc, stream),'
+                    ' offsetof(va_lbfgs_opts, maxfun)); return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(prog)])
+    out = subprocess.check_output([str(exe)]).split()
+    assert int(out[0]) == C.sizeof(capi.ProblemDesc)
+    assert int(out[1]) == C.sizeof(capi.LbfgsOpts)
+    assert int(out[2]) == capi.ProblemDesc.rf0_array.offset
+    assert int(out[3]) == capi.ProblemDesc.stream.offset
+    assert int(out[4]) == capi.LbfgsOpts.maxfun.offset
+
+
+def test_validation_without_gpu(capi):
+    lib = capi.lib()
+    h = C.c_void_p()
+    d = capi.ProblemDesc()
+    d.struct_size = 3
+    assert lib.va_problem_create(C.byref(d), C.byref(h)) == -1          # VA_EINVAL
+    assert b"struct_size" in lib.va_last_error()
+    assert lib.va_problem_create(None, C.byref(h)) == -1
+    assert lib.va_problem_info(None, None, None, None, None) == -1
+    assert lib.va_device_count(None) == -1
+    lib.va_problem_destroy(None)                                         # no-op
+
+
+def test_default_options_are_scipys(capi):
+    o = capi.make_opts(None)
+    assert (o.maxcor, o.maxiter, o.maxfun, o.maxls) == (10, 15000, 15000, 20)
+    assert o.gtol == 1e-5 and abs(o.ftol - 2.2204460492503131e-09) < 1e-24
+    o = capi.make_opts({'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000000, 'maxiter': 1000000})
+    assert (o.gtol, o.ftol, o.maxfun, o.maxiter) == (1e-8, 1e-8, 1000000, 1000000)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "varanneal_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "va_oracle" not in txt and "cpu_emul" not in txt.replace("tests/cpu_emul", ""), f

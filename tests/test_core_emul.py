@@ -1,0 +1,81 @@
+"""CPU: the __host__ __device__ core of the HIP path (varanneal_amd/csrc/va_core.h --
+tile phases, halo/edge indexing, More'-Thuente step, coefficient-space two-loop,
+per-seed ladder state machine) driven serially by tests/cpu_emul and checked against
+the golden vectors and the oracle.  The emulator is test infrastructure only."""
+import numpy as np
+import pytest
+
+import va_oracle
+from _util import rm_rf_for
+from cpu_emul import emul
+from varanneal_amd import _capi
+
+OPTS = {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000000, 'maxiter': 1000000}
+
+
+def _desc(c, batch=1):
+    N, D = int(c["N_model"]), int(c["D"])
+    RM, RF0 = rm_rf_for(c)
+    return _capi.make_desc(batch, D, N, c["Y"], c["Lidx"], c["dt_model"], RM, RF0,
+                           np.tile(c["XP"][N * D:], (batch, 1)), [0], disc=str(c["disc"]),
+                           merr_nskip=int(c["merr_nskip"]))
+
+
+def test_tile_phases_match_golden_for_every_tiling(golden_single):
+    for name, c in golden_single.items():
+        desc, keep = _desc(c)
+        for T in (2, 7, 50, 400):        # tiny tiles, ragged last tile, single tile
+            A, me, fe, g = emul.action_grad(desc, T, c["XP"][None, :], c["rf_scale"])
+            assert abs(A[0] - c["A"]) <= 1e-12 * abs(c["A"]), (name, T)
+            if "grad" in c:
+                assert np.abs(g[0] - c["grad"]).max() <= 1e-11 * np.abs(c["grad"]).max(), (name, T)
+
+
+def _c1(golden_ladders, name):
+    c = golden_ladders[name]
+    N, D = int(c["N"]), int(c["D"])
+    X0 = c["X0"].copy(); X0[:, c["Lidx"]] = c["Y"]
+    XP0 = np.append(X0.flatten(), c["P0"])
+    desc, keep = _capi.make_desc(1, D, N, c["Y"], c["Lidx"], 0.025, 4.0, 4e-6, c["P0"][None, :], [0],
+                                 disc=str(c["disc"]))
+    opb = va_oracle.Problem(D, N, c["Y"], c["Lidx"], 0.025, 4.0, 4e-6, c["P0"], [0], disc=str(c["disc"]))
+    return c, N, D, XP0, desc, keep, opb
+
+
+@pytest.mark.parametrize("name", ["g4_c1_trapezoid_N200", "g4_shipped_SH_N161"])
+def test_state_machine_matches_oracle_step_for_step(golden_ladders, name):
+    c, N, D, XP0, desc, keep, opb = _c1(golden_ladders, name)
+    for rf, k in ((1.0, 3), (1.5 ** 7, 6), (1.5 ** 7, 10 ** 6), (1.5 ** 14, 20)):
+        o = dict(OPTS, maxiter=k)
+        r = emul.anneal(desc, 50, XP0[None, :], [rf], o)
+        x, A, st, nit, nfev = opb.minimize_lbfgs(XP0, rf, o)
+        assert (r["nit"][0, 0], r["nfev"][0, 0], r["status"][0, 0]) == (nit, nfev, st), (rf, k)
+        assert abs(r["A"][0, 0] - A) <= 1e-6 * abs(A)
+        assert np.abs(r["x"][0] - x).max() <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["g4_c1_trapezoid_N200", "g4_shipped_SH_N161"])
+def test_ladder_lands_in_reference_basin(golden_ladders, name):
+    c, N, D, XP0, desc, keep, opb = _c1(golden_ladders, name)
+    rf = 1.5 ** c["beta"].astype(np.uint16)
+    r = emul.anneal(desc, 50, XP0[None, :], rf, OPTS)
+    assert np.all(np.abs(r["A"][0, :12] - c["A_array"][:12]) <= 1e-8)
+    assert list(r["nit"][0, :7]) == list(c["nit"][:7])
+    assert abs(r["A"][0, -1] - c["A_array"][-1]) <= 1e-3 * c["A_array"][-1]
+    assert abs(r["pest"][0, -1, 0] - c["params"][-1, 0]) <= 2e-3 * abs(c["params"][-1, 0])
+    assert np.array_equal(r["minpaths"][0, -1, :N * D], r["x"][0, :N * D])
+    assert np.array_equal(r["minpaths"][0, :, N * D], r["pest"][0, :, 0])
+
+
+def test_small_history_and_limits(golden_ladders):
+    c, N, D, XP0, desc, keep, opb = _c1(golden_ladders, "g4_c1_trapezoid_N200")
+    # maxcor=3: the circular history wraps many times; still tracks the oracle
+    o = dict(OPTS, maxcor=3, maxiter=40)
+    r = emul.anneal(desc, 50, XP0[None, :], [1.5 ** 12], o)
+    x, A, st, nit, nfev = opb.minimize_lbfgs(XP0, 1.5 ** 12, o)
+    assert (r["nit"][0, 0], r["nfev"][0, 0], r["status"][0, 0]) == (nit, nfev, st)
+    assert abs(r["A"][0, 0] - A) <= 1e-6 * abs(A)
+    # gtol satisfied at the start: zero iterations, one evaluation
+    r = emul.anneal(desc, 50, XP0[None, :], [1.0], dict(OPTS, gtol=1e3))
+    assert (r["nit"][0, 0], r["nfev"][0, 0], r["status"][0, 0]) == (0, 1, 0)
+    assert np.array_equal(r["x"][0], XP0)

@@ -1,0 +1,189 @@
+"""GPU parity tests: the HIP path (through the C-ABI, varanneal_amd._capi) against
+the golden vectors generated from the reference and against the CPU oracle.
+
+Tolerances (float64; SURVEY.md 8(c), north_star "stated floating-point tolerance"):
+  single evaluation   |A-A_ref|/|A_ref| <= 1e-12 ; ||g-g_ref||_inf/||g_ref||_inf <= 1e-10
+  short minimisation  identical (nit, nfev, status) to the oracle, A within 1e-6 rel, x within 1e-6
+  end of ladder       A_min within 1e-3 relative, k within 2e-3 relative (same basin)
+"""
+import numpy as np
+import pytest
+
+from _util import load_npz_cases, oracle_problem, rm_rf_for
+
+pytestmark = pytest.mark.gpu
+
+RTOL_A = 1e-12
+RTOL_G = 1e-10
+OPTS = {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000000, 'maxiter': 1000000}
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from varanneal_amd import _capi
+    _capi.lib()          # fails loudly if the HIP library is missing
+    return _capi
+
+
+def gpu_problem(capi, c, batch=1, **kw):
+    N, D = int(c["N_model"]), int(c["D"])
+    RM, RF0 = rm_rf_for(c)
+    P = np.tile(c["XP"][N * D:], (batch, 1))
+    return capi.Problem(batch, D, N, c["Y"], c["Lidx"], float(c["dt_model"]), RM, RF0, P, [0],
+                        disc=str(c["disc"]), merr_nskip=int(c["merr_nskip"]), **kw)
+
+
+def test_all_golden_single_evals(capi, golden_single):
+    worstA = worstG = 0.0
+    for name, c in golden_single.items():
+        for tile_rows in (0, 6):
+            with gpu_problem(capi, c, tile_rows=tile_rows) as pb:
+                A, me, fe, g = pb.action_grad(c["XP"][None, :], c["rf_scale"])
+            eA = abs(A[0] - c["A"]) / abs(c["A"])
+            assert eA <= RTOL_A, (name, tile_rows, eA)
+            assert abs(me[0] - c["me"]) <= RTOL_A * max(abs(c["me"]), abs(c["A"])), name
+            assert abs(fe[0] - c["fe"]) <= RTOL_A * abs(c["fe"]), name
+            worstA = max(worstA, eA)
+            if "grad" in c:
+                eG = np.abs(g[0] - c["grad"]).max() / np.abs(c["grad"]).max()
+                assert eG <= RTOL_G, (name, tile_rows, eG)
+                worstG = max(worstG, eG)
+    print("worst rel err A %.2e grad %.2e" % (worstA, worstG))
+
+
+def test_batched_eval_matches_oracle_per_seed(capi, golden_single):
+    c = golden_single["g2_c2_trapezoid"]
+    N, D = int(c["N_model"]), int(c["D"])
+    B = 5
+    rng = np.random.RandomState(11)
+    XP = np.tile(c["XP"], (B, 1)) + rng.randn(B, c["XP"].size)
+    P = 6.0 + 4.0 * rng.rand(B, 1)            # per-seed parameter vectors
+    XP[:, -1] = P[:, 0]
+    pb = capi.Problem(B, D, N, c["Y"], c["Lidx"], float(c["dt_model"]), 4.0, 4e-6, P, [0],
+                      disc="trapezoid")
+    A, me, fe, g = pb.action_grad(XP, 33.0)
+    opb = oracle_problem(c)
+    for b in range(B):
+        Ao, meo, feo, go = opb.action_grad(XP[b], 33.0)
+        assert abs(A[b] - Ao) <= RTOL_A * abs(Ao)
+        assert abs(fe[b] - feo) <= RTOL_A * abs(feo)
+        assert np.abs(g[b] - go).max() <= RTOL_G * np.abs(go).max()
+    # determinism: no atomics anywhere on the path -> bitwise repeatable
+    A2, _, _, g2 = pb.action_grad(XP, 33.0)
+    assert np.array_equal(A, A2) and np.array_equal(g, g2)
+    pb.close()
+
+
+def test_fixed_parameter_not_estimated(capi, golden_single):
+    # NPest = 0: XP holds the path only, k comes from P (va_ode.py:165-167)
+    c = golden_single["g1_trapezoid_rf4e-01_itd0"]
+    N, D = int(c["N_model"]), int(c["D"])
+    k = c["XP"][-1]
+    pb = capi.Problem(1, D, N, c["Y"], c["Lidx"], float(c["dt_model"]), 4.0, 4e-6, [[k]], [],
+                      disc="trapezoid")
+    A, me, fe, g = pb.action_grad(c["XP"][None, :N * D], c["rf_scale"])
+    assert abs(A[0] - c["A"]) <= RTOL_A * abs(c["A"])
+    assert np.abs(g[0] - c["grad"][:N * D]).max() <= RTOL_G * np.abs(c["grad"]).max()
+    pb.close()
+
+
+def test_error_paths(capi, golden_single):
+    c = golden_single["g1_SimpsonHermite_rf4e-06_itd1"]
+    with pytest.raises(capi.VaError) as e:      # even N with Simpson-Hermite (reference: broadcast error)
+        capi.Problem(1, 20, 160, c["Y"][:160], c["Lidx"], 0.025, 4.0, 4e-6, [[8.0]], [0],
+                     disc="SimpsonHermite")
+    assert e.value.code == -1 and "odd" in str(e.value)
+    with pytest.raises(capi.VaError):           # Lidx out of range
+        capi.Problem(1, 20, 161, c["Y"], [0, 2, 4, 6, 8, 10, 14, 20], 0.025, 4.0, 4e-6, [[8.0]], [0])
+    with gpu_problem(capi, c) as pb:
+        with pytest.raises(ValueError):
+            pb.action_grad(np.zeros((2, 5)))
+        with pytest.raises(capi.VaError):       # ladder longer than max_beta
+            pb.anneal(c["XP"][None, :], np.ones(3), OPTS)
+
+
+def _c1(golden_ladders, name):
+    c = golden_ladders[name]
+    N, D = int(c["N"]), int(c["D"])
+    X0 = c["X0"].copy()
+    X0[:, c["Lidx"]] = c["Y"]
+    XP0 = np.append(X0.flatten(), c["P0"])
+    return c, N, D, XP0
+
+
+def test_minimize_matches_oracle_step_for_step(capi, golden_ladders):
+    import va_oracle
+    c, N, D, XP0 = _c1(golden_ladders, "g4_c1_trapezoid_N200")
+    opb = va_oracle.Problem(D, N, c["Y"], c["Lidx"], 0.025, 4.0, 4e-6, c["P0"], [0], disc="trapezoid")
+    pb = capi.Problem(2, D, N, c["Y"], c["Lidx"], 0.025, 4.0, 4e-6, np.tile(c["P0"], (2, 1)), [0],
+                      disc="trapezoid")
+    for rf, extra in ((1.0, {}), (1.5 ** 7, {}), (1.5 ** 15, {"maxiter": 25})):
+        o = dict(OPTS, **extra)
+        x, A, st, nit, nfev = opb.minimize_lbfgs(XP0, rf, o)
+        r = pb.minimize_lbfgs(np.tile(XP0, (2, 1)), rf, o)
+        for b in range(2):
+            assert (r["nit"][b], r["nfev"][b], r["status"][b]) == (nit, nfev, st), (rf, b)
+            assert abs(r["A"][b] - A) <= 1e-6 * abs(A)
+            assert np.abs(r["x"][b] - x).max() <= 1e-6
+        assert np.array_equal(r["x"][0], r["x"][1])      # identical seeds stay identical
+    pb.close()
+
+
+@pytest.mark.parametrize("name", ["g4_c1_trapezoid_N200", "g4_shipped_SH_N161"])
+def test_ladder_matches_reference_ladder(capi, golden_ladders, name):
+    c, N, D, XP0 = _c1(golden_ladders, name)
+    nb = len(c["beta"])
+    rf = float(c["alpha"]) ** c["beta"].astype(np.uint16)
+    pb = capi.Problem(1, D, N, c["Y"], c["Lidx"], float(c["t"][1] - c["t"][0]), 4.0, 4e-6,
+                      c["P0"][None, :], [0], disc=str(c["disc"]), max_beta=nb, keep_paths=1)
+    r = pb.anneal(XP0[None, :], rf, OPTS, want_paths=True)
+    ref_A, ref_k = c["A_array"], c["params"][:, 0]
+    assert np.all(np.abs(r["A"][0, :12] - ref_A[:12]) <= 1e-8)          # optimiser's own ftol
+    assert list(r["nit"][0, :7]) == list(c["nit"][:7])
+    assert abs(r["A"][0, -1] - ref_A[-1]) <= 1e-3 * ref_A[-1]
+    assert abs(r["pest"][0, -1, 0] - ref_k[-1]) <= 2e-3 * abs(ref_k[-1])
+    assert np.allclose(r["A"][0], r["me"][0] + r["fe"][0], rtol=1e-12)
+    assert np.all(r["status"][0] == 0)
+    # stored paths: final step equals XP out; parameters column = estimated k
+    assert np.array_equal(r["minpaths"][0, -1, :N * D], r["x"][0, :N * D])
+    assert np.array_equal(r["minpaths"][0, :, N * D], r["pest"][0, :, 0])
+    # the stored minimiser really has the stored action (re-evaluate through S1)
+    for k in (0, nb // 2, nb - 1):
+        A, me, fe, _ = pb.action_grad(np.append(r["minpaths"][0, k, :N * D], r["pest"][0, k, 0])[None, :],
+                                      rf[k], want_grad=False)
+        assert abs(A[0] - r["A"][0, k]) <= 1e-12 * abs(A[0])
+    pb.close()
+
+
+def test_c3_shape_properties(capi):
+    """BASELINE config 3 shape (D=20, N=1000, L=7, 64 seeds): size-independent properties."""
+    from varanneal_amd import twin
+    D, N, B = 20, 1000, 64
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    XP = np.empty((B, N * D + 1)); P = np.empty((B, 1))
+    for b in range(B):
+        X0, P0 = twin.initial_guess(N, D, b)
+        XP[b, :-1] = X0.ravel(); XP[b, -1] = P0[0]; P[b] = P0
+    pb = capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid")
+    A1, me1, fe1, g1 = pb.action_grad(XP, 1.0)
+    A2, me2, fe2, g2 = pb.action_grad(XP, 1000.0)
+    # A is affine in RF: me independent of it, fe and (g - g_me) proportional
+    assert np.array_equal(me1, me2)
+    assert np.allclose(fe2, 1000.0 * fe1, rtol=1e-13)
+    A3, _, _, g3 = pb.action_grad(XP, 500.5)
+    assert np.allclose(g3, 0.5 * (g1 + g2), rtol=1e-11, atol=1e-13 * np.abs(g2).max())
+    # directional derivative by central differences on a few seeds
+    rng = np.random.RandomState(5)
+    v = rng.randn(*XP.shape)
+    h = 1e-6
+    Ap, _, _, _ = pb.action_grad(XP + h * v, 1000.0, want_grad=False)
+    Am, _, _, _ = pb.action_grad(XP - h * v, 1000.0, want_grad=False)
+    fd = (Ap - Am) / (2 * h)
+    an = np.sum(g2 * v, axis=1)
+    assert np.allclose(fd, an, rtol=1e-7)
+    # seeds are independent: permuting the batch permutes the outputs bit for bit
+    perm = rng.permutation(B)
+    pb2 = capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[perm], [0], disc="trapezoid")
+    Ap_, _, _, gp_ = pb2.action_grad(XP[perm], 1000.0)
+    assert np.array_equal(Ap_, A2[perm]) and np.array_equal(gp_, g2[perm])
+    pb.close(); pb2.close()

@@ -1,0 +1,38 @@
+"""Build libvaranneal_amd.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m varanneal_amd._build [--force]
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libvaranneal_amd.so")
+SOURCES = ["va_capi.hip", "va_kernels.hip"]
+HEADERS = ["va_core.h", "va_device.h", os.path.join("..", "..", "include", "varanneal_amd.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function"]
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return OUT
+    cmd = [HIPCC] + FLAGS + ["-o", OUT] + [os.path.join(CSRC, f) for f in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

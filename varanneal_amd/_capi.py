@@ -1,0 +1,253 @@
+"""ctypes binding of include/varanneal_amd.h (libvaranneal_amd.so).
+
+This is the thin shim north_star asks for: host code stays Python, the HIP
+kernels are reached through a plain C-ABI.  There is NO CPU fallback: if the
+shared library is missing or fails to load, importing callers get a loud
+`VaLibraryError`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvaranneal_amd.so")
+
+VA_OK = 0
+ERRNAMES = {-1: "VA_EINVAL", -2: "VA_ENOMEM", -3: "VA_EHIP", -4: "VA_EUNSUPPORTED", -5: "VA_ESTATE"}
+DISC = {"euler": 0, "trapezoid": 1, "SimpsonHermite": 2, "forwardmap": 3}
+RHS = {"lorenz96": 0}
+MEM_HOST, MEM_DEVICE = 0, 1
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+c_lp = C.POINTER(C.c_int64)
+
+
+class VaLibraryError(RuntimeError):
+    pass
+
+
+class VaError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "%s (%d): %s" % (ERRNAMES.get(code, "VA_E?"), code, msg))
+        self.code = code
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32),
+                ("D", C.c_int32), ("N_model", C.c_int32), ("N_data", C.c_int32),
+                ("merr_nskip", C.c_int32), ("L", C.c_int32),
+                ("Lidx", c_ip), ("Y", c_dp), ("dt_model", C.c_double),
+                ("rm_kind", C.c_int32), ("rm", C.c_double), ("rm_array", c_dp),
+                ("rf_kind", C.c_int32), ("rf0", C.c_double), ("rf0_array", c_dp),
+                ("NP", C.c_int32), ("NPest", C.c_int32), ("Pidx", c_ip), ("P", c_dp),
+                ("disc", C.c_int32), ("rhs", C.c_int32), ("lbfgs_m", C.c_int32),
+                ("max_beta", C.c_int32), ("keep_paths", C.c_int32), ("tile_rows", C.c_int32),
+                ("stream", C.c_void_p)]
+
+
+class LbfgsOpts(C.Structure):
+    _fields_ = [("maxcor", C.c_int32), ("ftol", C.c_double), ("gtol", C.c_double),
+                ("maxiter", C.c_int32), ("maxfun", C.c_int64), ("maxls", C.c_int32)]
+
+
+def make_opts(opt_args=None):
+    """SciPy L-BFGS-B option names and defaults (scipy/optimize/_lbfgsb_py.py)."""
+    o = dict(opt_args or {})
+    return LbfgsOpts(int(o.get("maxcor", 10)), float(o.get("ftol", 2.2204460492503131e-09)),
+                     float(o.get("gtol", 1e-5)), int(min(int(o.get("maxiter", 15000)), 2 ** 31 - 1)),
+                     int(o.get("maxfun", 15000)), int(o.get("maxls", 20)))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def make_desc(batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, disc="trapezoid",
+              rhs="lorenz96", merr_nskip=1, lbfgs_m=10, max_beta=1, keep_paths=0, tile_rows=0,
+              device=0, stream=None):
+    """Build a ProblemDesc plus the list of arrays that must outlive it."""
+    Y = _f64(Y)
+    N_data, L = Y.shape
+    Lidx = np.ascontiguousarray(Lidx, dtype=np.int32)
+    Pidx = np.ascontiguousarray(Pidx, dtype=np.int32)
+    P = _f64(P)
+    if P.ndim == 1:
+        P = np.ascontiguousarray(np.broadcast_to(P, (batch, P.shape[0])))
+    keep = [Y, Lidx, Pidx, P]
+    d = ProblemDesc()
+    d.struct_size = C.sizeof(ProblemDesc)
+    d.device, d.batch, d.D, d.N_model, d.N_data = device, batch, D, N_model, N_data
+    d.merr_nskip, d.L = merr_nskip, L
+    d.Lidx = Lidx.ctypes.data_as(c_ip)
+    d.Y = Y.ctypes.data_as(c_dp)
+    d.dt_model = float(dt_model)
+    if isinstance(RM, np.ndarray):
+        rm = _f64(RM)
+        if rm.shape != (N_data, L):
+            raise ValueError("RM array must have shape (N_data, L)")
+        keep.append(rm)
+        d.rm_kind, d.rm, d.rm_array = 1, 0.0, rm.ctypes.data_as(c_dp)
+    else:
+        d.rm_kind, d.rm, d.rm_array = 0, float(RM), None
+    if isinstance(RF0, np.ndarray):
+        rf = _f64(RF0)
+        if rf.shape != (N_model - 1, D):
+            raise ValueError("RF0 array must have shape (N_model-1, D)")
+        keep.append(rf)
+        d.rf_kind, d.rf0, d.rf0_array = 1, 0.0, rf.ctypes.data_as(c_dp)
+    else:
+        d.rf_kind, d.rf0, d.rf0_array = 0, float(RF0), None
+    d.NP, d.NPest = P.shape[1], len(Pidx)
+    d.Pidx = Pidx.ctypes.data_as(c_ip)
+    d.P = P.ctypes.data_as(c_dp)
+    d.disc = DISC[disc] if isinstance(disc, str) else int(disc)
+    d.rhs = RHS[rhs] if isinstance(rhs, str) else int(rhs)
+    d.lbfgs_m, d.max_beta, d.keep_paths, d.tile_rows = lbfgs_m, max_beta, keep_paths, tile_rows
+    d.stream = stream
+    return d, keep
+
+
+_lib = None
+
+
+def lib():
+    """Load libvaranneal_amd.so (built by varanneal_amd._build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VaLibraryError("%s not found: build it with `python -m varanneal_amd._build` "
+                             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise VaLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+    h = C.c_void_p
+    L.va_abi_version.restype = C.c_int32
+    L.va_last_error.restype = C.c_char_p
+    L.va_device_count.argtypes = [c_ip]
+    L.va_problem_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(h)]
+    L.va_problem_destroy.argtypes = [h]
+    L.va_problem_destroy.restype = None
+    L.va_problem_info.argtypes = [h, c_lp, c_lp, c_ip, c_ip]
+    L.va_action_grad.argtypes = [h, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.va_minimize_lbfgs.argtypes = [h, C.c_void_p, C.c_int64, C.c_int32, C.c_double,
+                                    C.POINTER(LbfgsOpts), c_dp, c_dp, c_dp, c_ip, c_ip, c_lp]
+    L.va_anneal.argtypes = [h, C.c_void_p, C.c_int64, C.c_int32, c_dp, C.c_int32,
+                            C.POINTER(LbfgsOpts), c_dp, c_dp, c_ip, c_ip, c_lp, c_dp]
+    L.va_get_minpath.argtypes = [h, C.c_int32, C.c_int32, c_dp]
+    L.va_eval_timed.argtypes = [h, C.c_double, C.c_int32, C.POINTER(C.c_float)]
+    L.va_get_counters.argtypes = [h, c_lp, c_lp, c_lp]
+    for fn in ("va_device_count", "va_problem_create", "va_problem_info", "va_action_grad",
+               "va_minimize_lbfgs", "va_anneal", "va_get_minpath", "va_eval_timed",
+               "va_get_counters"):
+        getattr(L, fn).restype = C.c_int
+    _lib = L
+    return L
+
+
+EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_problem_create",
+           "va_problem_destroy", "va_problem_info", "va_action_grad", "va_minimize_lbfgs",
+           "va_anneal", "va_get_minpath", "va_eval_timed", "va_get_counters"]
+
+
+def check(rc):
+    if rc != VA_OK:
+        raise VaError(rc, lib().va_last_error().decode("utf-8", "replace"))
+
+
+class Problem(object):
+    """RAII wrapper of a va_handle; arrays are NumPy (host) or raw device pointers."""
+
+    def __init__(self, batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, **kw):
+        self._L = lib()
+        self.desc, self._keep = make_desc(batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, **kw)
+        self.B, self.D, self.N = batch, D, N_model
+        self.NP, self.NPest = self.desc.NP, self.desc.NPest
+        self.n_var = N_model * D + self.NPest
+        self.max_beta = self.desc.max_beta
+        self._h = C.c_void_p()
+        check(self._L.va_problem_create(C.byref(self.desc), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.va_problem_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def info(self):
+        nv, ld = C.c_int64(), C.c_int64()
+        T, nt = C.c_int32(), C.c_int32()
+        check(self._L.va_problem_info(self._h, C.byref(nv), C.byref(ld), C.byref(T), C.byref(nt)))
+        return dict(n_var=nv.value, ld=ld.value, tile_rows=T.value, ntiles=nt.value)
+
+    def _xp(self, XP):
+        XP = _f64(XP)
+        if XP.shape != (self.B, self.n_var):
+            raise ValueError("XP must have shape (B, N*D+NPest) = (%d, %d), got %s" %
+                             (self.B, self.n_var, XP.shape))
+        return XP
+
+    def action_grad(self, XP, rf_scale=1.0, want_grad=True):
+        XP = self._xp(XP)
+        A = np.empty(self.B); me = np.empty(self.B); fe = np.empty(self.B)
+        g = np.empty((self.B, self.n_var)) if want_grad else None
+        check(self._L.va_action_grad(self._h, XP.ctypes.data, self.n_var, MEM_HOST, float(rf_scale),
+                                     A.ctypes.data, me.ctypes.data, fe.ctypes.data,
+                                     g.ctypes.data if want_grad else None, self.n_var))
+        return A, me, fe, g
+
+    def action_grad_device(self, xp_ptr, ld, rf_scale, A_ptr, me_ptr, fe_ptr, g_ptr, ldg):
+        check(self._L.va_action_grad(self._h, xp_ptr, ld, MEM_DEVICE, float(rf_scale), A_ptr, me_ptr,
+                                     fe_ptr, g_ptr, ldg))
+
+    def minimize_lbfgs(self, XP, rf_scale, opt_args=None):
+        XP = self._xp(XP).copy()
+        o = make_opts(opt_args)
+        A = np.empty(self.B); me = np.empty(self.B); fe = np.empty(self.B)
+        st = np.empty(self.B, np.int32); nit = np.empty(self.B, np.int32); nfev = np.empty(self.B, np.int64)
+        check(self._L.va_minimize_lbfgs(self._h, XP.ctypes.data, self.n_var, MEM_HOST, float(rf_scale),
+                                        C.byref(o), A.ctypes.data_as(c_dp), me.ctypes.data_as(c_dp),
+                                        fe.ctypes.data_as(c_dp), st.ctypes.data_as(c_ip),
+                                        nit.ctypes.data_as(c_ip), nfev.ctypes.data_as(c_lp)))
+        return dict(x=XP, A=A, me=me, fe=fe, status=st, nit=nit, nfev=nfev)
+
+    def anneal(self, XP, rf_scale, opt_args=None, want_paths=False, xp_device=None, ld=None):
+        rf = _f64(rf_scale)
+        nb = rf.shape[0]
+        o = make_opts(opt_args)
+        B = self.B
+        ame = np.empty((B, nb, 3)); pest = np.empty((B, nb, self.NPest))
+        st = np.empty((B, nb), np.int32); nit = np.empty((B, nb), np.int32); nfev = np.empty((B, nb), np.int64)
+        mp = np.empty((B, nb, self.N * self.D + self.NP)) if want_paths else None
+        if xp_device is None:
+            XP = self._xp(XP).copy()
+            ptr, stride, mem = XP.ctypes.data, self.n_var, MEM_HOST
+        else:
+            ptr, stride, mem = xp_device, ld, MEM_DEVICE
+        check(self._L.va_anneal(self._h, ptr, stride, mem, rf.ctypes.data_as(c_dp), nb, C.byref(o),
+                                ame.ctypes.data_as(c_dp), pest.ctypes.data_as(c_dp),
+                                st.ctypes.data_as(c_ip), nit.ctypes.data_as(c_ip),
+                                nfev.ctypes.data_as(c_lp), mp.ctypes.data_as(c_dp) if want_paths else None))
+        return dict(x=XP if xp_device is None else None, A=ame[:, :, 0], me=ame[:, :, 1],
+                    fe=ame[:, :, 2], pest=pest, status=st, nit=nit, nfev=nfev, minpaths=mp)
+
+    def eval_timed(self, rf_scale, iters):
+        ms = C.c_float()
+        check(self._L.va_eval_timed(self._h, float(rf_scale), int(iters), C.byref(ms)))
+        return ms.value
+
+    def counters(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(self._L.va_get_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(eval_launches=a.value, seed_evals=b.value, cycles=c.value)

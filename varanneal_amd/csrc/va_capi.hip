@@ -1,0 +1,446 @@
+// va_capi.hip -- host side of libvaranneal_amd.so: the C-ABI of include/varanneal_amd.h.
+//
+// Owns the device image of one annealing problem (B seeds resident in HBM), moves
+// paths in/out, and drives the kernel cycle
+//     k_eval -> k_ls -> k_update -> k_coeffs -> k_direction
+// until every seed has climbed its whole RF ladder.  No per-iteration host sync:
+// the host only polls a device counter of unfinished seeds every few cycles.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/varanneal_amd.h"
+#include "va_device.h"
+
+using namespace va;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? VA_ENOMEM : VA_EHIP, "%s: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                 \
+    } while (0)
+
+}  // namespace
+
+struct va_problem_s {
+    Dev dv;
+    int device = 0, rhs = 0, keep_paths = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::vector<void *> allocs;
+    int *h_nactive = nullptr;          // pinned: [0] live seeds; bytes 8..15: evaluation counter
+    double *d_rf = nullptr;            // ladder on device [max_beta]
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int64_t n_eval_launch = 0, n_seed_evals = 0, n_seed_evals_direct = 0, n_cycles = 0;
+    int last_nbeta = 0;
+
+    template <class T> int alloc(T **p, size_t n, bool zero = true)
+    {
+        void *q = nullptr;
+        size_t bytes = sizeof(T) * (n ? n : 1);
+        HIPCHK(hipMalloc(&q, bytes));
+        allocs.push_back(q);
+        if (zero) HIPCHK(hipMemsetAsync(q, 0, bytes, stream));
+        *p = (T *)q;
+        return VA_OK;
+    }
+};
+
+namespace {
+
+int pick_tile_rows(const va_problem_desc *d)
+{
+    const int D = d->D, N = d->N_model, HLR = (d->disc == VA_DISC_SIMPSON_HERMITE) ? 3 : 2;
+    // LDS: 3 staged arrays of (T+halo) rows; keep a workgroup under ~48 KiB so several fit a CU
+    int tmax = (int)((48 * 1024) / (3 * sizeof(double) * D)) - HLR;
+    if (tmax < 2) tmax = 2;
+    int tmin = (EVAL_THREADS + D - 1) / D;               // >= one element per lane
+    if (tmin > tmax) tmin = tmax;
+    int T;
+    if (d->tile_rows > 0) T = d->tile_rows;
+    else {
+        // enough workgroups to cover 256 CUs a few times over
+        int want = (1024 + d->batch - 1) / d->batch;     // tiles per seed
+        T = N / (want > 0 ? want : 1);
+        if (T < tmin) T = tmin;
+        if (T > tmax) T = tmax;
+    }
+    if (T > N) T = N;
+    if (d->disc == VA_DISC_SIMPSON_HERMITE && (T & 1)) ++T;
+    if (T < 2) T = 2;
+    return T;
+}
+
+int copy_in(va_handle h, const double *XP, int64_t ld, int32_t mem)
+{
+    const Dims &dm = h->dv.dm;
+    const size_t w = sizeof(double) * (dm.ND + dm.NPest);
+    HIPCHK(hipMemcpy2DAsync(h->dv.x, sizeof(double) * dm.ld, XP, sizeof(double) * ld, w, dm.B,
+                            mem == VA_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                            h->stream));
+    return VA_OK;
+}
+
+int copy_out(va_handle h, const double *src, double *dst, int64_t ld, int32_t mem)
+{
+    const Dims &dm = h->dv.dm;
+    const size_t w = sizeof(double) * (dm.ND + dm.NPest);
+    HIPCHK(hipMemcpy2DAsync(dst, sizeof(double) * ld, src, sizeof(double) * dm.ld, w, dm.B,
+                            mem == VA_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                            h->stream));
+    return VA_OK;
+}
+
+int check_xp(va_handle h, const void *XP, int64_t ld, int32_t mem)
+{
+    if (!h) return fail(VA_EINVAL, "null handle");
+    if (!XP) return fail(VA_EINVAL, "XP is NULL");
+    if (ld < h->dv.dm.ND + h->dv.dm.NPest) return fail(VA_EINVAL, "ld (%lld) < n_var (%d)", (long long)ld, h->dv.dm.ND + h->dv.dm.NPest);
+    if (mem != VA_MEM_HOST && mem != VA_MEM_DEVICE) return fail(VA_EINVAL, "bad mem kind %d", mem);
+    return VA_OK;
+}
+
+int set_opts(va_handle h, const va_lbfgs_opts *o)
+{
+    if (!o) return fail(VA_EINVAL, "opts is NULL");
+    if (o->maxls <= 0) return fail(VA_EINVAL, "maxls must be positive");
+    if (o->maxcor <= 0) return fail(VA_EINVAL, "maxcor must be positive");
+    Opts &d = h->dv.o;
+    d.m = o->maxcor < h->dv.dm.m ? o->maxcor : h->dv.dm.m;
+    d.maxiter = o->maxiter; d.maxls = o->maxls; d.maxfun = o->maxfun;
+    d.ftol = o->ftol; d.gtol = o->gtol;
+    return VA_OK;
+}
+
+// the kernel cycle until no seed is left (or the evaluation budget bound is hit)
+int run_ladder(va_handle h, const double *rf_scale, int nbeta)
+{
+    Dev &dv = h->dv;
+    if (nbeta < 1 || nbeta > dv.max_beta) return fail(VA_EINVAL, "nbeta=%d outside [1, max_beta=%d]", nbeta, dv.max_beta);
+    HIPCHK(hipMemcpyAsync(h->d_rf, rf_scale, sizeof(double) * nbeta, hipMemcpyHostToDevice, h->stream));
+    dv.nbeta = nbeta; h->last_nbeta = nbeta;
+    *h->h_nactive = dv.dm.B;
+    HIPCHK(hipMemcpyAsync(dv.n_active, h->h_nactive, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(dv.dpp, 0, sizeof(double) * dv.dm.B * dv.dm.nchunks * DP_N, h->stream));
+    launch_init_states(dv, PH_START, -1.0, h->stream);
+    // every cycle costs each live seed at least one evaluation
+    const double per_step = (double)dv.o.maxfun + dv.o.maxls + 4.0;
+    const double bound = per_step * nbeta;
+    long long max_cycles = bound > 4e18 ? (long long)4e18 : (long long)bound;
+    long long cyc = 0;
+    int poll = 4;
+    for (;;) {
+        for (int k = 0; k < poll; ++k) {
+            launch_eval(dv, h->rhs, h->stream);
+            launch_ls(dv, h->stream);
+            launch_update(dv, h->stream);
+            launch_coeffs(dv, h->stream);
+            launch_direction(dv, h->stream);
+        }
+        cyc += poll;
+        HIPCHK(hipMemcpyAsync(h->h_nactive, dv.n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_nactive + 2, dv.n_evals, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (*h->h_nactive <= 0) break;
+        if (cyc > max_cycles) return fail(VA_ESTATE, "ladder did not finish within %lld cycles", max_cycles);
+        if (poll < 64) poll *= 2;
+    }
+    h->n_cycles += cyc; h->n_eval_launch += cyc;
+    h->n_seed_evals = h->n_seed_evals_direct + (int64_t)*(unsigned long long *)(h->h_nactive + 2);
+    HIPCHK(hipGetLastError());
+    return VA_OK;
+}
+
+template <class T>
+int fetch_table(va_handle h, const T *dev, T *host, int nbeta, int per)
+{
+    if (!host) return VA_OK;
+    const Dev &dv = h->dv;
+    HIPCHK(hipMemcpy2DAsync(host, sizeof(T) * nbeta * per, dev, sizeof(T) * dv.max_beta * per,
+                            sizeof(T) * nbeta * per, dv.dm.B, hipMemcpyDeviceToHost, h->stream));
+    return VA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t va_abi_version(void) { return VA_ABI_VERSION; }
+const char *va_last_error(void) { return g_err.c_str(); }
+
+int va_device_count(int32_t *count)
+{
+    if (!count) return fail(VA_EINVAL, "count is NULL");
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    *count = n;
+    return VA_OK;
+}
+
+int va_problem_create(const va_problem_desc *d, va_handle *out)
+{
+    if (!d || !out) return fail(VA_EINVAL, "null argument");
+    *out = nullptr;
+    if (d->struct_size != (int32_t)sizeof(va_problem_desc)) return fail(VA_EINVAL, "struct_size %d != %zu", d->struct_size, sizeof(va_problem_desc));
+    if (d->batch < 1 || d->D < 1 || d->N_model < 2 || d->N_data < 1 || d->L < 0 || d->merr_nskip < 1)
+        return fail(VA_EINVAL, "bad sizes (batch=%d D=%d N_model=%d N_data=%d L=%d nskip=%d)", d->batch, d->D, d->N_model, d->N_data, d->L, d->merr_nskip);
+    if ((int64_t)(d->N_data - 1) * d->merr_nskip + 1 > d->N_model)
+        return fail(VA_EINVAL, "observations reach past the path: (N_data-1)*nskip+1 > N_model");
+    if (d->disc < VA_DISC_EULER || d->disc > VA_DISC_FORWARDMAP) return fail(VA_EINVAL, "unknown disc %d", d->disc);
+    if (d->disc == VA_DISC_SIMPSON_HERMITE && (d->N_model % 2) == 0)
+        return fail(VA_EINVAL, "SimpsonHermite needs an odd number of time points (N_model=%d)", d->N_model);
+    if (d->rhs != VA_RHS_LORENZ96) return fail(VA_EUNSUPPORTED, "unknown built-in rhs %d", d->rhs);
+    if (d->rhs == VA_RHS_LORENZ96 && (d->NP != RhsL96::NP || d->D < 4))
+        return fail(VA_EINVAL, "Lorenz-96 needs NP=1 and D>=4 (NP=%d D=%d)", d->NP, d->D);
+    if (d->NPest < 0 || d->NPest > d->NP || d->NP > RHS_MAX_NP) return fail(VA_EINVAL, "bad NP/NPest (%d/%d)", d->NP, d->NPest);
+    if (!d->Y || (d->L > 0 && !d->Lidx) || !d->P || (d->NPest > 0 && !d->Pidx)) return fail(VA_EINVAL, "null array in desc");
+    if ((d->rm_kind && !d->rm_array) || (d->rf_kind && !d->rf0_array)) return fail(VA_EINVAL, "rm/rf array kind without array");
+    for (int l = 0; l < d->L; ++l)
+        if (d->Lidx[l] < 0 || d->Lidx[l] >= d->D) return fail(VA_EINVAL, "Lidx[%d]=%d outside [0,D)", l, d->Lidx[l]);
+    for (int k = 0; k < d->NPest; ++k)
+        if (d->Pidx[k] < 0 || d->Pidx[k] >= d->NP) return fail(VA_EINVAL, "Pidx[%d]=%d outside [0,NP)", k, d->Pidx[k]);
+    const int m = d->lbfgs_m > 0 ? d->lbfgs_m : 10;
+    if (m > MAX_M) return fail(VA_EINVAL, "lbfgs_m=%d > %d", m, MAX_M);
+    const int max_beta = d->max_beta > 0 ? d->max_beta : 1;
+
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (d->device < 0 || d->device >= ndev) return fail(VA_EINVAL, "device %d of %d", d->device, ndev);
+    HIPCHK(hipSetDevice(d->device));
+
+    va_handle h = new va_problem_s();
+    h->device = d->device; h->rhs = d->rhs; h->keep_paths = d->keep_paths;
+    if (d->stream) h->stream = (hipStream_t)d->stream;
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete h; return fail(VA_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        h->own_stream = true;
+    }
+    Dev &dv = h->dv;
+    memset(&dv, 0, sizeof dv);
+    Dims &dm = dv.dm;
+    dm.D = d->D; dm.N = d->N_model; dm.ND = dm.D * dm.N; dm.L = d->L; dm.N_data = d->N_data;
+    dm.nskip = d->merr_nskip; dm.NP = d->NP; dm.NPest = d->NPest; dm.B = d->batch; dm.m = m;
+    dm.disc = d->disc;
+    dm.ld = ((dm.ND + dm.NPest + 15) / 16) * 16;
+    dm.T = pick_tile_rows(d);
+    dm.ntiles = (dm.N + dm.T - 1) / dm.T;
+    dm.chunk = VEC_CHUNK; dm.nchunks = (dm.ld + VEC_CHUNK - 1) / VEC_CHUNK;
+    dm.dt = d->dt_model;
+    dm.cme = d->L > 0 ? 1.0 / ((double)dm.L * dm.N_data) : 0.0;
+    dm.cfe = 1.0 / ((double)dm.D * (dm.N - 1));
+    dm.rm = d->rm; dm.rf0 = d->rf0;
+    dv.ups = UP_OLD + 4 * m; dv.max_beta = max_beta; dv.nbeta = 1;
+    dv.o.m = m; dv.o.maxiter = 15000; dv.o.maxls = 20; dv.o.maxfun = 15000; dv.o.ftol = 2.2204460492503131e-09; dv.o.gtol = 1e-5;
+
+    if (eval_lds_bytes(dm) > 64 * 1024) {
+        va_problem_destroy(h);
+        return fail(VA_EUNSUPPORTED, "tile of %d rows x D=%d needs %zu B of LDS (> 64 KiB); lower tile_rows", dm.T, dm.D, eval_lds_bytes(dm));
+    }
+
+    int rc = VA_OK;
+    const size_t B = dm.B, ld = dm.ld;
+    int *lmap_d = nullptr, *pidx_d = nullptr;
+    double *Y_d = nullptr, *rm_d = nullptr, *rf_d = nullptr, *P_d = nullptr;
+#define TRY(x) do { rc = (x); if (rc) { va_problem_destroy(h); return rc; } } while (0)
+    TRY(h->alloc(&lmap_d, dm.D));
+    TRY(h->alloc(&Y_d, (size_t)dm.N_data * dm.L));
+    TRY(h->alloc(&pidx_d, dm.NPest));
+    TRY(h->alloc(&P_d, B * dm.NP));
+    if (d->rm_kind) TRY(h->alloc(&rm_d, (size_t)dm.N_data * dm.L));
+    if (d->rf_kind) TRY(h->alloc(&rf_d, (size_t)(dm.N - 1) * dm.D));
+    TRY(h->alloc(&dv.x, B * ld)); TRY(h->alloc(&dv.g, B * ld));
+    TRY(h->alloc(&dv.gt, B * ld)); TRY(h->alloc(&dv.d, B * ld));
+    TRY(h->alloc(&dv.S, B * m * ld)); TRY(h->alloc(&dv.Y, B * m * ld));
+    TRY(h->alloc(&dv.st, B));
+    TRY(h->alloc(&dv.evp, B * dm.ntiles * EP_N));
+    TRY(h->alloc(&dv.upp, B * dm.nchunks * dv.ups));
+    TRY(h->alloc(&dv.dpp, B * dm.nchunks * DP_N));
+    TRY(h->alloc(&h->d_rf, (size_t)max_beta));
+    TRY(h->alloc(&dv.ame, B * max_beta * 3));
+    TRY(h->alloc(&dv.pest, B * max_beta * (dm.NPest ? dm.NPest : 1)));
+    TRY(h->alloc(&dv.status, B * max_beta)); TRY(h->alloc(&dv.nit, B * max_beta));
+    TRY(h->alloc(&dv.nfev, B * max_beta));
+    if (d->keep_paths) TRY(h->alloc(&dv.minpaths, B * max_beta * (size_t)(dm.ND + dm.NP), false));
+    TRY(h->alloc(&dv.n_active, 1));
+    TRY(h->alloc(&dv.n_evals, 1));
+    TRY(h->alloc(&dv.outA, B)); TRY(h->alloc(&dv.outme, B)); TRY(h->alloc(&dv.outfe, B));
+    dv.rf_ladder = h->d_rf;
+
+    std::vector<int> lmap(dm.D, -1);
+    for (int l = 0; l < dm.L; ++l) lmap[d->Lidx[l]] = l;
+#define H2D(dst, src, n, T) do { hipError_t e_ = hipMemcpyAsync(dst, src, sizeof(T) * (n), hipMemcpyHostToDevice, h->stream); \
+        if (e_ != hipSuccess) { va_problem_destroy(h); return fail(VA_EHIP, "H2D %s: %s", #dst, hipGetErrorString(e_)); } } while (0)
+    H2D(lmap_d, lmap.data(), dm.D, int);
+    H2D(Y_d, d->Y, (size_t)dm.N_data * dm.L, double);
+    if (dm.NPest) H2D(pidx_d, d->Pidx, dm.NPest, int);
+    H2D(P_d, d->P, B * dm.NP, double);
+    if (d->rm_kind) H2D(rm_d, d->rm_array, (size_t)dm.N_data * dm.L, double);
+    if (d->rf_kind) H2D(rf_d, d->rf0_array, (size_t)(dm.N - 1) * dm.D, double);
+    dv.pp.lmap = lmap_d; dv.pp.Y = Y_d; dv.pp.rm_arr = rm_d; dv.pp.rf0_arr = rf_d;
+    dv.pp.Pidx = pidx_d; dv.pp.Pfull = P_d;
+
+    hipError_t e = hipHostMalloc((void **)&h->h_nactive, 4 * sizeof(int), hipHostMallocDefault);
+    if (e != hipSuccess) { va_problem_destroy(h); return fail(VA_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e)); }
+    e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e != hipSuccess) { va_problem_destroy(h); return fail(VA_EHIP, "hipEventCreate: %s", hipGetErrorString(e)); }
+    e = hipStreamSynchronize(h->stream);     // lmap (stack vector) must be consumed before we return
+    if (e != hipSuccess) { va_problem_destroy(h); return fail(VA_EHIP, "create sync: %s", hipGetErrorString(e)); }
+    launch_init_states(dv, PH_IDLE, 1.0, h->stream);
+#undef TRY
+#undef H2D
+    *out = h;
+    return VA_OK;
+}
+
+void va_problem_destroy(va_handle h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) (void)hipFree(p);
+    if (h->h_nactive) (void)hipHostFree(h->h_nactive);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int va_problem_info(va_handle h, int64_t *n_var, int64_t *ld_internal, int32_t *tile_rows, int32_t *ntiles)
+{
+    if (!h) return fail(VA_EINVAL, "null handle");
+    if (n_var) *n_var = h->dv.dm.ND + h->dv.dm.NPest;
+    if (ld_internal) *ld_internal = h->dv.dm.ld;
+    if (tile_rows) *tile_rows = h->dv.dm.T;
+    if (ntiles) *ntiles = h->dv.dm.ntiles;
+    return VA_OK;
+}
+
+int va_action_grad(va_handle h, const double *XP, int64_t ld, int32_t mem, double rf_scale,
+                   double *A, double *me, double *fe, double *grad, int64_t ldg)
+{
+    int rc = check_xp(h, XP, ld, mem);
+    if (rc) return rc;
+    if (!A || !me || !fe) return fail(VA_EINVAL, "A/me/fe must not be NULL");
+    if (grad && ldg < h->dv.dm.ND + h->dv.dm.NPest) return fail(VA_EINVAL, "ldg < n_var");
+    HIPCHK(hipSetDevice(h->device));
+    Dev &dv = h->dv;
+    if ((rc = copy_in(h, XP, ld, mem))) return rc;
+    launch_init_states(dv, PH_START, rf_scale, h->stream);
+    launch_eval(dv, h->rhs, h->stream);
+    launch_finalize_eval(dv, h->stream);
+    const hipMemcpyKind k = mem == VA_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    HIPCHK(hipMemcpyAsync(A, dv.outA, sizeof(double) * dv.dm.B, k, h->stream));
+    HIPCHK(hipMemcpyAsync(me, dv.outme, sizeof(double) * dv.dm.B, k, h->stream));
+    HIPCHK(hipMemcpyAsync(fe, dv.outfe, sizeof(double) * dv.dm.B, k, h->stream));
+    if (grad && (rc = copy_out(h, dv.gt, grad, ldg, mem))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    h->n_eval_launch += 1; h->n_seed_evals += dv.dm.B; h->n_seed_evals_direct += dv.dm.B;
+    return VA_OK;
+}
+
+int va_anneal(va_handle h, double *XP, int64_t ld, int32_t mem, const double *rf_scale, int32_t nbeta,
+              const va_lbfgs_opts *opts, double *ame, double *pest, int32_t *status, int32_t *nit,
+              int64_t *nfev, double *minpaths)
+{
+    int rc = check_xp(h, XP, ld, mem);
+    if (rc) return rc;
+    if (!rf_scale) return fail(VA_EINVAL, "rf_scale is NULL");
+    if (minpaths && !h->dv.minpaths) return fail(VA_ESTATE, "minpaths requested but the problem was created with keep_paths=0");
+    if ((rc = set_opts(h, opts))) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    Dev &dv = h->dv;
+    if ((rc = copy_in(h, XP, ld, mem))) return rc;
+    if ((rc = run_ladder(h, rf_scale, nbeta))) return rc;
+    if ((rc = copy_out(h, dv.x, XP, ld, mem))) return rc;
+    if ((rc = fetch_table(h, dv.ame, ame, nbeta, 3))) return rc;
+    if (dv.dm.NPest && (rc = fetch_table(h, dv.pest, pest, nbeta, dv.dm.NPest))) return rc;
+    if ((rc = fetch_table(h, dv.status, status, nbeta, 1))) return rc;
+    if ((rc = fetch_table(h, dv.nit, nit, nbeta, 1))) return rc;
+    if ((rc = fetch_table(h, (const int64_t *)dv.nfev, nfev, nbeta, 1))) return rc;
+    if ((rc = fetch_table(h, dv.minpaths, minpaths, nbeta, dv.dm.ND + dv.dm.NP))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return VA_OK;
+}
+
+int va_minimize_lbfgs(va_handle h, double *XP, int64_t ld, int32_t mem, double rf_scale,
+                      const va_lbfgs_opts *opts, double *Amin, double *me, double *fe,
+                      int32_t *status, int32_t *nit, int64_t *nfev)
+{
+    if (!h) return fail(VA_EINVAL, "null handle");
+    const int B = h->dv.dm.B;
+    std::vector<double> ame((size_t)B * 3);
+    int rc = va_anneal(h, XP, ld, mem, &rf_scale, 1, opts, ame.data(), nullptr, status, nit, nfev, nullptr);
+    if (rc) return rc;
+    for (int b = 0; b < B; ++b) {
+        if (Amin) Amin[b] = ame[3 * b];
+        if (me) me[b] = ame[3 * b + 1];
+        if (fe) fe[b] = ame[3 * b + 2];
+    }
+    return VA_OK;
+}
+
+int va_get_minpath(va_handle h, int32_t seed, int32_t beta_idx, double *out)
+{
+    if (!h || !out) return fail(VA_EINVAL, "null argument");
+    const Dev &dv = h->dv;
+    if (!dv.minpaths) return fail(VA_ESTATE, "problem was created with keep_paths=0");
+    if (seed < 0 || seed >= dv.dm.B || beta_idx < 0 || beta_idx >= h->last_nbeta)
+        return fail(VA_EINVAL, "seed/beta index out of range");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t wide = dv.dm.ND + dv.dm.NP;
+    HIPCHK(hipMemcpyAsync(out, dv.minpaths + ((size_t)seed * dv.max_beta + beta_idx) * wide,
+                          sizeof(double) * wide, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return VA_OK;
+}
+
+int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms)
+{
+    if (!h || !elapsed_ms || iters < 1) return fail(VA_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    Dev &dv = h->dv;
+    launch_init_states(dv, PH_START, rf_scale, h->stream);
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < iters; ++i) launch_eval(dv, h->rhs, h->stream);
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+    HIPCHK(hipGetLastError());
+    h->n_eval_launch += iters; h->n_seed_evals += (int64_t)iters * dv.dm.B;
+    h->n_seed_evals_direct += (int64_t)iters * dv.dm.B;
+    return VA_OK;
+}
+
+int va_get_counters(va_handle h, int64_t *eval_launches, int64_t *seed_evals, int64_t *cycles)
+{
+    if (!h) return fail(VA_EINVAL, "null handle");
+    if (eval_launches) *eval_launches = h->n_eval_launch;
+    if (seed_evals) *seed_evals = h->n_seed_evals;
+    if (cycles) *cycles = h->n_cycles;
+    return VA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,585 @@
+// va_core.h -- per-tile action/adjoint arithmetic and the per-seed L-BFGS state
+// machine, written once as __host__ __device__ code.
+//
+// The HIP kernels in va_kernels.hip give these functions their parallel
+// decomposition (workgroup = one tile of time rows of one seed, LDS staging,
+// wave64 reductions).  tests/cpu_emul/ compiles the same header with g++ and
+// drives the phases serially, so the index/halo/state-machine logic is covered
+// by the CPU test-suite; that emulator is test infrastructure and is not linked
+// into the product library.
+//
+// Reference arithmetic this restates for the device (paths in /root/reference):
+//   me_gaussian  varanneal/va_ode.py:138-158     fe_gaussian  :160-234
+//   disc_euler :341-356  disc_trapezoid :358-380  disc_SimpsonHermite :404-437
+//   disc_forwardmap :439-454   l96  examples/Lorenz96_D20/Lorenz96_anneal.py:15-16
+//   min_lbfgs_scipy varanneal/_autodiffmin.py:72-95 -> L-BFGS-B 3.0 (unbounded path)
+//   anneal_step  varanneal/va_ode.py:707-789
+//
+// Gradient: no tape.  With q = (2 RF/(D(N-1))) * w * residual, the adjoint of the
+// discretisation stencil at time row m is
+//     dA/dx_m = direct_m(q) + J_m^T s_m(q)   (+ measurement term)
+//     dA/dp   = sum_m (df_m/dp)^T s_m(q)
+// where direct_m and s_m are fixed linear combinations of q at rows m-2..m+1
+// (see disc_direct_s below); J_m^T s is hand-coded per RHS.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define VA_HD __host__ __device__ inline
+#else
+#define VA_HD inline
+#endif
+
+namespace va {
+
+enum { DISC_EULER = 0, DISC_TRAPEZOID = 1, DISC_SH = 2, DISC_FWDMAP = 3 };
+enum { PH_IDLE = 0, PH_START = 1, PH_LS = 2, PH_FINISHED = 3 };
+enum { UPD_X = 1, UPD_G = 2, UPD_HIST = 4, UPD_STORE = 8 };
+enum { LS_START = 0, LS_FG = 1, LS_CONV = 2, LS_WARN = 3, LS_ERROR = 4 };
+
+constexpr int MAX_M = 32;        // history pairs
+constexpr int RHS_MAX_NP = 8;    // parameters a built-in RHS may have
+// eval partial columns
+enum { EP_ME = 0, EP_FE = 1, EP_GTD = 2, EP_GN2 = 3, EP_GMAX = 4, EP_GP = 5 };
+constexpr int EP_N = EP_GP + RHS_MAX_NP;
+// update partial columns: 5 fixed + 4 per old history slot
+enum { UP_YGT = 0, UP_SGT = 1, UP_YY = 2, UP_SY = 3, UP_GTGT = 4, UP_OLD = 5 };
+constexpr int UP_N = UP_OLD + 4 * MAX_M;
+enum { DP_GD = 0, DP_DD = 1, DP_N = 2 };
+
+struct Dims {
+    int D, N, ND, ld, L, N_data, nskip, NP, NPest, T, ntiles, B, m, disc, nchunks, chunk;
+    double dt, cme, cfe, rm, rf0;
+};
+
+// Read-only problem arrays (device pointers on the GPU, heap in the emulator).
+struct ProblemPtrs {
+    const int *lmap;       // [D] -> l or -1
+    const double *Y;       // [N_data*L]
+    const double *rm_arr;  // NULL or [N_data*L]
+    const double *rf0_arr; // NULL or [(N-1)*D]
+    const int *Pidx;       // [NPest]
+    const double *Pfull;   // [B*NP]
+};
+
+struct LsState {
+    int brackt, stage;
+    double ginit, gtest, gx, gy, finit, fx, fy, stx, sty, stmin, stmax, width, width1;
+};
+
+struct Opts {
+    int m, maxiter, maxls;
+    long long maxfun;
+    double ftol, gtol;
+};
+
+struct SeedState {
+    int phase, beta_idx, iter, col, head, ifun, iback, ls_task;
+    int upd, slot, dir, store_idx, nold, pad0;
+    int order[MAX_M];       // history slots, oldest -> newest (after the pending update)
+    long long nfev;
+    double f, fold, me, fe, theta, stp, gd, gdold, rf_scale, gn2, dr;
+    double stp_upd;         // accepted step the update kernel applies (stp is the NEXT trial step)
+    LsState ls;
+    double cg, cY[MAX_M], cS[MAX_M];
+    double a[MAX_M], b[MAX_M];
+    double SY[MAX_M * MAX_M], YY[MAX_M * MAX_M];
+};
+
+// ---------------------------------------------------------------- RHS: Lorenz-96
+// f_i = x_{i-1}(x_{i+1} - x_{i-2}) - x_i + k   (cyclic)
+struct RhsL96 {
+    static constexpr int NP = 1;
+    static VA_HD double f(const double *x, int i, int D, const double *p)
+    {
+        int im1 = i == 0 ? D - 1 : i - 1;
+        int im2 = im1 == 0 ? D - 1 : im1 - 1;
+        int ip1 = i == D - 1 ? 0 : i + 1;
+        return x[im1] * (x[ip1] - x[im2]) - x[i] + p[0];
+    }
+    // (J^T s)_j = s_{j+1}(x_{j+2} - x_{j-1}) + s_{j-1} x_{j-2} - s_{j+2} x_{j+1} - s_j
+    static VA_HD double vjp(const double *x, const double *s, int j, int D, const double *)
+    {
+        int jm1 = j == 0 ? D - 1 : j - 1;
+        int jm2 = jm1 == 0 ? D - 1 : jm1 - 1;
+        int jp1 = j == D - 1 ? 0 : j + 1;
+        int jp2 = jp1 == D - 1 ? 0 : jp1 + 1;
+        return s[jp1] * (x[jp2] - x[jm1]) + s[jm1] * x[jm2] - s[jp2] * x[jp1] - s[j];
+    }
+    // acc[k] += s_i * df_i/dp_k
+    static VA_HD void pgrad(const double *, const double *s, int i, int, const double *, double *acc)
+    {
+        acc[0] += s[i];
+    }
+};
+
+// ---------------------------------------------------------------- tile context
+template <int DISC> struct Halo {
+    static constexpr int HL = (DISC == DISC_SH) ? 2 : 1;   // rows needed before the tile
+    static constexpr int HR = 1;                           // rows needed after it
+};
+
+struct TileCtx {
+    int n0, R, use_d;            // first owned row, rows staged, trial point x + stp*d ?
+    double stp, c;               // c = 2 * rf0_scale * cfe   (rf0 weight applied per element)
+    double *xs, *fs, *qs;        // staged rows [R*D] (LDS); fs is re-used for s
+    const double *xg, *dg;       // this seed's x (and d) in global memory
+    double *gtg;                 // this seed's gradient output
+    double p[RHS_MAX_NP];
+};
+
+struct ThreadAcc {
+    double v[EP_N];
+    VA_HD void clear() { for (int k = 0; k < EP_N; ++k) v[k] = 0.0; }
+};
+
+// trial point; the SAME expression is used by the update kernel so that the
+// accepted iterate is bit-identical to the point that was evaluated.
+VA_HD double trial(double x, double stp, double d) { return fma(stp, d, x); }
+
+template <class RHS>
+VA_HD void tile_params(const Dims &dm, const ProblemPtrs &pp, int b, TileCtx &c)
+{
+#pragma unroll
+    for (int k = 0; k < RHS::NP; ++k) c.p[k] = pp.Pfull[(size_t)b * dm.NP + k];
+    for (int k = 0; k < dm.NPest; ++k) {
+        double v = c.xg[dm.ND + k];
+        if (c.use_d) v = trial(v, c.stp, c.dg[dm.ND + k]);
+        const int dst = pp.Pidx[k];
+        // select chain instead of c.p[dst]: a runtime-indexed array would live in scratch
+#pragma unroll
+        for (int j = 0; j < RHS::NP; ++j) c.p[j] = (dst == j) ? v : c.p[j];
+    }
+}
+
+// phase 1: stage rows [n0-HL, n0-HL+R) of x (or x + stp*d); rows outside [0,N) read as 0.
+template <int DISC>
+VA_HD void tile_load(const Dims &dm, TileCtx &c, int tid, int nt)
+{
+    const long base = (long)(c.n0 - Halo<DISC>::HL) * dm.D;
+    const int tot = c.R * dm.D;
+    for (int e = tid; e < tot; e += nt) {
+        long gi = base + e;
+        double v = 0.0;
+        if (gi >= 0 && gi < dm.ND) {
+            v = c.xg[gi];
+            if (c.use_d) v = trial(v, c.stp, c.dg[gi]);
+        }
+        c.xs[e] = v;
+    }
+}
+
+// phase 2: f at every staged row that exists.
+template <class RHS, int DISC>
+VA_HD void tile_f(const Dims &dm, TileCtx &c, int tid, int nt)
+{
+    const int D = dm.D, tot = c.R * D;
+    int lr = tid / D, i = tid - lr * D;
+    const int dlr = nt / D, di = nt - dlr * D;
+    for (int e = tid; e < tot; e += nt) {
+        int row = c.n0 - Halo<DISC>::HL + lr;
+        c.fs[e] = (row >= 0 && row < dm.N) ? RHS::f(c.xs + lr * D, i, D, c.p) : 0.0;
+        lr += dlr; i += di;
+        if (i >= D) { i -= D; ++lr; }
+    }
+}
+
+// phase 3: weighted residual adjoints q for rows [n0-HL, n0+T); model-error sum over owned rows.
+template <int DISC>
+VA_HD void tile_q(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &acc, int tid, int nt)
+{
+    constexpr int HL = Halo<DISC>::HL;
+    const int D = dm.D, N = dm.N, tot = (dm.T + HL) * D;
+    const double dt = dm.dt;
+    int lr = tid / D, i = tid - lr * D;
+    const int dlr = nt / D, di = nt - dlr * D;
+    for (int e = tid; e < tot; e += nt) {
+        const int row = c.n0 - HL + lr;
+        double q = 0.0;
+        if (row >= 0) {
+            const double *x0 = c.xs + lr * D, *f0 = c.fs + lr * D;
+            double r = 0.0; bool have = false;
+            if (DISC == DISC_SH) {
+                if ((row & 1) == 0) {
+                    if (row + 2 <= N - 1) {          // d1 of the interval starting at `row`
+                        r = x0[2 * D + i] - x0[i]
+                            - (f0[i] + 4.0 * f0[D + i] + f0[2 * D + i]) * (2.0 * dt) / 6.0;
+                        have = true;
+                    }
+                } else if (row + 1 <= N - 1) {       // d2 of the interval starting at row-1
+                    r = x0[i] - ((x0[i - D] + x0[i + D]) / 2.0
+                                 + (f0[i - D] - f0[i + D]) * (2.0 * dt) / 8.0);
+                    have = true;
+                }
+            } else if (row <= N - 2) {
+                if (DISC == DISC_TRAPEZOID) r = x0[D + i] - x0[i] - dt * (f0[i] + f0[D + i]) / 2.0;
+                else if (DISC == DISC_EULER) r = x0[D + i] - x0[i] - dt * f0[i];
+                else r = x0[D + i] - f0[i];
+                have = true;
+            }
+            if (have) {
+                double w = pp.rf0_arr ? pp.rf0_arr[(size_t)row * D + i] : dm.rf0;
+                q = c.c * w * r;
+                if (lr >= HL && row < N) acc.v[EP_FE] += w * r * r;
+            }
+        }
+        c.qs[e] = q;
+        lr += dlr; i += di;
+        if (i >= D) { i -= D; ++lr; }
+    }
+}
+
+// direct_m and s_m from q (qm points at q[row m][i]; rows m-2..m+1 are addressable,
+// out-of-range rows hold 0 by construction of tile_q).
+template <int DISC>
+VA_HD void disc_direct_s(const double *qm, int D, int m, double dt, double &direct, double &s)
+{
+    if (DISC == DISC_TRAPEZOID) {
+        direct = qm[-D] - qm[0];
+        s = -0.5 * dt * (qm[-D] + qm[0]);
+    } else if (DISC == DISC_EULER) {
+        direct = qm[-D] - qm[0];
+        s = -dt * qm[0];
+    } else if (DISC == DISC_FWDMAP) {
+        direct = qm[-D];
+        s = -qm[0];
+    } else {                                          // Simpson-Hermite
+        if ((m & 1) == 0) {
+            // q1_m = q[m], q2_m = q[m+1], q1_{m-2} = q[m-2], q2_{m-2} = q[m-1]
+            direct = -qm[0] - 0.5 * qm[D] + qm[-2 * D] - 0.5 * qm[-D];
+            s = -(dt / 3.0) * (qm[0] + qm[-2 * D]) - (dt / 4.0) * (qm[D] - qm[-D]);
+        } else {
+            direct = qm[0];
+            s = -(4.0 * dt / 3.0) * qm[-D];
+        }
+    }
+}
+
+// phase 4: s rows for the owned rows (written over fs).
+template <int DISC>
+VA_HD void tile_s(const Dims &dm, TileCtx &c, int tid, int nt)
+{
+    constexpr int HL = Halo<DISC>::HL;
+    const int D = dm.D, tot = dm.T * D;
+    int lt = tid / D, i = tid - lt * D;
+    const int dlr = nt / D, di = nt - dlr * D;
+    for (int e = tid; e < tot; e += nt) {
+        const int lr = lt + HL, m = c.n0 + lt;
+        double direct, s = 0.0;
+        if (m < dm.N) disc_direct_s<DISC>(c.qs + lr * D + i, D, m, dm.dt, direct, s);
+        c.fs[lr * D + i] = s;
+        lt += dlr; i += di;
+        if (i >= D) { i -= D; ++lt; }
+    }
+}
+
+// phase 5: gradient rows of the tile + measurement term + parameter-gradient and
+// line-search partial sums.
+template <class RHS, int DISC>
+VA_HD void tile_g(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &acc, int tid, int nt)
+{
+    constexpr int HL = Halo<DISC>::HL;
+    const int D = dm.D, tot = dm.T * D;
+    int lt = tid / D, j = tid - lt * D;
+    const int dlr = nt / D, dj = nt - dlr * D;
+    for (int e = tid; e < tot; e += nt) {
+        const int lr = lt + HL, m = c.n0 + lt;
+        if (m < dm.N) {
+            double direct, sdummy;
+            disc_direct_s<DISC>(c.qs + lr * D + j, D, m, dm.dt, direct, sdummy);
+            const double *xr = c.xs + lr * D, *sr = c.fs + lr * D;
+            double g = direct + RHS::vjp(xr, sr, j, D, c.p);
+            RHS::pgrad(xr, sr, j, D, c.p, acc.v + EP_GP);
+            const int l = pp.lmap[j];
+            if (l >= 0 && (m % dm.nskip) == 0) {
+                const int nd = m / dm.nskip;
+                const double diff = xr[j] - pp.Y[(size_t)nd * dm.L + l];
+                const double w = pp.rm_arr ? pp.rm_arr[(size_t)nd * dm.L + l] : dm.rm;
+                acc.v[EP_ME] += w * diff * diff;
+                g += 2.0 * dm.cme * w * diff;
+            }
+            const long gi = (long)m * D + j;
+            c.gtg[gi] = g;
+            if (c.use_d) acc.v[EP_GTD] += g * c.dg[gi];
+            acc.v[EP_GN2] += g * g;
+            acc.v[EP_GMAX] = fmax(acc.v[EP_GMAX], fabs(g));
+        }
+        lt += dlr; j += dj;
+        if (j >= D) { j -= D; ++lt; }
+    }
+}
+
+// ---------------------------------------------------------------- dcsrch / dcstep
+// MINPACK-2 line search (More' & Thuente 1994) as used by L-BFGS-B's lnsrlb.
+VA_HD void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy,
+                  double &stp, double fp, double dp, int &brackt, double stpmin, double stpmax)
+{
+    const double sgnd = dp * (dx / fabs(dx));
+    double theta, s, gamma, p, q, r, stpc, stpq, stpf;
+    if (fp > fx) {
+        theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+        s = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
+        gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+        if (stp < stx) gamma = -gamma;
+        p = (gamma - dx) + theta; q = ((gamma - dx) + gamma) + dp; r = p / q;
+        stpc = stx + r * (stp - stx);
+        stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
+        stpf = (fabs(stpc - stx) < fabs(stpq - stx)) ? stpc : stpc + (stpq - stpc) / 2.0;
+        brackt = 1;
+    } else if (sgnd < 0.0) {
+        theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+        s = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
+        gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+        if (stp > stx) gamma = -gamma;
+        p = (gamma - dp) + theta; q = ((gamma - dp) + gamma) + dx; r = p / q;
+        stpc = stp + r * (stx - stp);
+        stpq = stp + (dp / (dp - dx)) * (stx - stp);
+        stpf = (fabs(stpc - stp) > fabs(stpq - stp)) ? stpc : stpq;
+        brackt = 1;
+    } else if (fabs(dp) < fabs(dx)) {
+        theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+        s = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
+        gamma = s * sqrt(fmax(0.0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
+        if (stp > stx) gamma = -gamma;
+        p = (gamma - dp) + theta; q = (gamma + (dx - dp)) + gamma; r = p / q;
+        if (r < 0.0 && gamma != 0.0) stpc = stp + r * (stx - stp);
+        else if (stp > stx) stpc = stpmax;
+        else stpc = stpmin;
+        stpq = stp + (dp / (dp - dx)) * (stx - stp);
+        if (brackt) {
+            stpf = (fabs(stpc - stp) < fabs(stpq - stp)) ? stpc : stpq;
+            if (stp > stx) stpf = fmin(stp + 0.66 * (sty - stp), stpf);
+            else stpf = fmax(stp + 0.66 * (sty - stp), stpf);
+        } else {
+            stpf = (fabs(stpc - stp) > fabs(stpq - stp)) ? stpc : stpq;
+            stpf = fmin(stpmax, stpf); stpf = fmax(stpmin, stpf);
+        }
+    } else {
+        if (brackt) {
+            theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
+            s = fmax(fabs(theta), fmax(fabs(dy), fabs(dp)));
+            gamma = s * sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
+            if (stp > sty) gamma = -gamma;
+            p = (gamma - dp) + theta; q = ((gamma - dp) + gamma) + dy; r = p / q;
+            stpf = stp + r * (sty - stp);
+        } else if (stp > stx) stpf = stpmax;
+        else stpf = stpmin;
+    }
+    if (fp > fx) { sty = stp; fy = fp; dy = dp; }
+    else {
+        if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
+        stx = stp; fx = fp; dx = dp;
+    }
+    stp = stpf;
+}
+
+VA_HD int dcsrch(double f, double g, double &stp, double ftol, double gtol, double xtol,
+                 double stpmin, double stpmax, int task, LsState &st)
+{
+    const double xtrapl = 1.1, xtrapu = 4.0;
+    if (task == LS_START) {
+        if (stp < stpmin || stp > stpmax || g >= 0.0) return LS_ERROR;
+        st.brackt = 0; st.stage = 1; st.finit = f; st.ginit = g; st.gtest = ftol * g;
+        st.width = stpmax - stpmin; st.width1 = st.width / 0.5;
+        st.stx = 0.0; st.fx = f; st.gx = g; st.sty = 0.0; st.fy = f; st.gy = g;
+        st.stmin = 0.0; st.stmax = stp + xtrapu * stp;
+        return LS_FG;
+    }
+    const double ftest = st.finit + stp * st.gtest;
+    if (st.stage == 1 && f <= ftest && g >= 0.0) st.stage = 2;
+    int out = LS_FG;
+    if (st.brackt && (stp <= st.stmin || stp >= st.stmax)) out = LS_WARN;
+    if (st.brackt && st.stmax - st.stmin <= xtol * st.stmax) out = LS_WARN;
+    if (stp == stpmax && f <= ftest && g <= st.gtest) out = LS_WARN;
+    if (stp == stpmin && (f > ftest || g >= st.gtest)) out = LS_WARN;
+    if (f <= ftest && fabs(g) <= gtol * (-st.ginit)) out = LS_CONV;
+    if (out != LS_FG) return out;
+    if (st.stage == 1 && f <= st.fx && f > ftest) {
+        double fm = f - stp * st.gtest, fxm = st.fx - st.stx * st.gtest,
+               fym = st.fy - st.sty * st.gtest, gm = g - st.gtest, gxm = st.gx - st.gtest,
+               gym = st.gy - st.gtest;
+        dcstep(st.stx, fxm, gxm, st.sty, fym, gym, stp, fm, gm, st.brackt, st.stmin, st.stmax);
+        st.fx = fxm + st.stx * st.gtest; st.fy = fym + st.sty * st.gtest;
+        st.gx = gxm + st.gtest; st.gy = gym + st.gtest;
+    } else {
+        dcstep(st.stx, st.fx, st.gx, st.sty, st.fy, st.gy, stp, f, g, st.brackt, st.stmin, st.stmax);
+    }
+    if (st.brackt) {
+        if (fabs(st.sty - st.stx) >= 0.66 * st.width1) stp = st.stx + 0.5 * (st.sty - st.stx);
+        st.width1 = st.width; st.width = fabs(st.sty - st.stx);
+        st.stmin = fmin(st.stx, st.sty); st.stmax = fmax(st.stx, st.sty);
+    } else {
+        st.stmin = stp + xtrapl * (stp - st.stx);
+        st.stmax = stp + xtrapu * (stp - st.stx);
+    }
+    stp = fmax(stp, stpmin); stp = fmin(stp, stpmax);
+    if ((st.brackt && (stp <= st.stmin || stp >= st.stmax)) ||
+        (st.brackt && st.stmax - st.stmin <= xtol * st.stmax))
+        stp = st.stx;
+    return LS_FG;
+}
+
+// ---------------------------------------------------------------- per-seed results
+struct SeedResults {
+    double *ame;          // [nbeta*3]
+    double *pest;         // [nbeta*NPest] or NULL
+    int *status, *nit;    // [nbeta]
+    long long *nfev;      // [nbeta]
+};
+
+// close the current beta step (va_ode.py:773-782): record, then move to the next RF
+// or finish.  `accepted`: the trial point becomes the stored minimiser.
+VA_HD void finish_step(SeedState &s, int status, bool accepted, const double *rf_ladder, int nbeta,
+                       const SeedResults &r, int *n_active_dec)
+{
+    const int k = s.beta_idx;
+    r.ame[3 * k] = s.f; r.ame[3 * k + 1] = s.me; r.ame[3 * k + 2] = s.fe;
+    r.status[k] = status; r.nit[k] = s.iter; r.nfev[k] = s.nfev;
+    s.upd = (accepted ? UPD_X : 0) | UPD_STORE;
+    s.store_idx = k; s.dir = 0; s.nold = 0;
+    if (k + 1 < nbeta) {
+        s.beta_idx = k + 1; s.rf_scale = rf_ladder[k + 1]; s.phase = PH_START;
+    } else {
+        s.phase = PH_FINISHED; *n_active_dec = 1;
+    }
+}
+
+VA_HD void begin_linesearch(SeedState &s)
+{
+    const double big = 1e10;
+    s.ifun = 0; s.iback = 0; s.ls_task = LS_START;
+    s.stp = (s.iter == 0) ? fmin(1.0 / sqrt(s.gn2), big) : 1.0;   // lnsrlb; d = -g at iter 0
+    s.dir = 1;
+}
+
+VA_HD void reset_memory(SeedState &s) { s.col = 0; s.head = 0; s.theta = 1.0; s.nold = 0; }
+
+// K2: consume one evaluation.  ev[] = eval partial sums INCLUDING the parameter tail
+// contributions; dirp[] = (g.d, d.d) of the direction in use.
+VA_HD void ls_step(SeedState &s, const double *ev, const double *dirp, const Opts &o,
+                   const double *rf_ladder, int nbeta, const SeedResults &r, int *n_active_dec,
+                   double cme, double cfe)
+{
+    const double epsmch = 2.220446049250313e-16, big = 1e10;
+    s.upd = 0; s.dir = 0; s.nold = 0; s.store_idx = -1;
+    const double me = ev[EP_ME] * cme, fe = ev[EP_FE] * cfe * s.rf_scale;
+    const double ft = me + fe;
+    if (s.phase == PH_START) {
+        // first evaluation of a minimisation (setulb FG_START)
+        s.f = ft; s.me = me; s.fe = fe; s.gn2 = ev[EP_GN2];
+        s.iter = 0; s.nfev = 1; reset_memory(s);
+        if (ev[EP_GMAX] <= o.gtol) { finish_step(s, 0, false, rf_ladder, nbeta, r, n_active_dec); return; }
+        s.upd = UPD_G; s.phase = PH_LS;
+        begin_linesearch(s);
+        return;
+    }
+    if (s.phase != PH_LS) return;
+    bool fail = false;
+    if (s.ifun == 0) {
+        // lnsrlb entry: directional derivative at the start point
+        s.gdold = dirp[DP_GD]; s.fold = s.f;
+        if (s.gdold >= 0.0) fail = true;
+        else {
+            s.ls_task = dcsrch(s.f, s.gdold, s.stp, 1e-3, 0.9, 0.1, 0.0, big, LS_START, s.ls);
+            if (s.ls_task == LS_ERROR) fail = true;
+            else { s.ifun = 1; s.iback = 0; s.nfev += 1; }    // the evaluation we are consuming
+        }
+    }
+    double stp_eval = s.stp;
+    if (!fail) {
+        s.gd = ev[EP_GTD];
+        s.ls_task = dcsrch(ft, s.gd, s.stp, 1e-3, 0.9, 0.1, 0.0, big, LS_FG, s.ls);
+        if (s.ls_task == LS_FG) {
+            s.ifun += 1; s.iback = s.ifun - 1;
+            if (s.iback >= o.maxls) fail = true;
+            else { s.nfev += 1; return; }                     // next trial at the new s.stp
+        }
+    }
+    if (fail) {
+        // restore the previous iterate (x, g, f untouched during the search)
+        if (s.col == 0) { finish_step(s, 2, false, rf_ladder, nbeta, r, n_active_dec); return; }
+        reset_memory(s);                                      // RESTART_FROM_LNSRCH
+        s.ifun = 0; s.iback = 0; s.ls_task = LS_START; s.stp = 1.0; s.dir = 1;
+        return;
+    }
+    // NEW_X: the point evaluated at stp_eval is accepted (dcsrch leaves stp unchanged on CONV/WARN)
+    s.stp = stp_eval; s.stp_upd = stp_eval;
+    const double fold = s.f;
+    s.f = ft; s.me = me; s.fe = fe; s.gn2 = ev[EP_GN2];
+    s.iter += 1;
+    if (s.iter >= o.maxiter) { finish_step(s, 1, true, rf_ladder, nbeta, r, n_active_dec); return; }
+    if (s.nfev > o.maxfun) { finish_step(s, 1, true, rf_ladder, nbeta, r, n_active_dec); return; }
+    if (ev[EP_GMAX] <= o.gtol) { finish_step(s, 0, true, rf_ladder, nbeta, r, n_active_dec); return; }
+    {
+        const double dd = fmax(fmax(fabs(fold), fabs(ft)), 1.0);
+        if (fold - ft <= o.ftol * dd) { finish_step(s, 0, true, rf_ladder, nbeta, r, n_active_dec); return; }
+    }
+    // BFGS pair (matupd) unless L-BFGS-B's curvature rule skips it
+    const double dr = (s.gd - s.gdold) * s.stp, ddum = -s.gdold * s.stp;
+    s.upd = UPD_X | UPD_G;
+    s.nold = s.col;
+    if (dr > epsmch * ddum) {
+        int slot;
+        if (s.col < o.m) { slot = (s.head + s.col) % o.m; s.nold = s.col; s.col += 1; }
+        else {
+            // the oldest pair is evicted: order[] shifts left
+            slot = s.head; s.head = (s.head + 1) % o.m;
+            for (int j = 0; j + 1 < s.col; ++j) s.order[j] = s.order[j + 1];
+            s.nold = s.col - 1;
+        }
+        s.order[s.col - 1] = slot;
+        s.slot = slot; s.dr = dr; s.upd |= UPD_HIST;
+    }
+    begin_linesearch(s);
+}
+
+// K4: Gram update + two-loop recursion carried out in coefficient space.
+// up[] = update-kernel dot products (UP_* layout, old slots in s.order[0..nold)).
+// Produces d = cg*g + sum_j cY[slot]*Y[slot] + cS[slot]*S[slot].
+VA_HD void direction_coeffs(SeedState &s, const double *up, const Opts &o)
+{
+    (void)o;
+    const int M = MAX_M;
+    const bool hist = (s.upd & UPD_HIST) != 0;
+    const int nold = s.nold, col = s.col;
+    if (hist) {
+        const int sn = s.slot;
+        for (int j = 0; j < nold; ++j) {
+            const int sj = s.order[j];
+            s.SY[sj * M + sn] = up[UP_OLD + 4 * j + 2];          // S_j . y
+            s.YY[sj * M + sn] = s.YY[sn * M + sj] = up[UP_OLD + 4 * j + 3];
+        }
+        s.SY[sn * M + sn] = s.dr;                                // s.y as the line search saw it
+        s.YY[sn * M + sn] = up[UP_YY];
+        s.theta = up[UP_YY] / s.dr;
+    }
+    for (int j = 0; j < nold; ++j) {
+        s.a[j] = up[UP_OLD + 4 * j + 0];                         // S_j . g
+        s.b[j] = up[UP_OLD + 4 * j + 1];                         // Y_j . g
+    }
+    if (hist) { s.a[col - 1] = up[UP_SGT]; s.b[col - 1] = up[UP_YGT]; }
+    const double gamma = 1.0 / s.theta;
+    double c[MAX_M], e[MAX_M], al[MAX_M];
+    for (int j = 0; j < col; ++j) { c[j] = 0.0; e[j] = 0.0; }
+    for (int i = col - 1; i >= 0; --i) {                         // newest -> oldest
+        const int si = s.order[i];
+        double sq = s.a[i];
+        for (int j = i + 1; j < col; ++j) sq += c[j] * s.SY[si * M + s.order[j]];
+        al[i] = sq / s.SY[si * M + si];
+        c[i] = -al[i];
+    }
+    for (int i = 0; i < col; ++i) {                              // oldest -> newest
+        const int si = s.order[i];
+        double yr = s.b[i];
+        for (int j = 0; j < col; ++j) yr += c[j] * s.YY[si * M + s.order[j]];
+        yr *= gamma;
+        for (int j = 0; j < i; ++j) yr += e[j] * s.SY[s.order[j] * M + si];
+        e[i] = al[i] - yr / s.SY[si * M + si];
+    }
+    s.cg = -gamma;
+    for (int j = 0; j < MAX_M; ++j) { s.cY[j] = 0.0; s.cS[j] = 0.0; }
+    for (int j = 0; j < col; ++j) { s.cY[s.order[j]] = -gamma * c[j]; s.cS[s.order[j]] = -e[j]; }
+}
+
+}  // namespace va

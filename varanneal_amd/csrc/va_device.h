@@ -1,0 +1,51 @@
+// va_device.h -- device-side problem image shared by va_kernels.hip and va_capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "va_core.h"
+
+namespace va {
+
+constexpr int EVAL_THREADS = 256;    // 4 waves per workgroup
+constexpr int VEC_THREADS = 256;
+constexpr int VEC_CHUNK = 1024;      // elements of a seed's vector per workgroup (2 x double2 per lane)
+
+// Everything a kernel needs, passed by value as the kernel argument.
+struct Dev {
+    Dims dm;
+    ProblemPtrs pp;
+    Opts o;
+    // per-seed vectors, stride dm.ld (multiple of 16 doubles -> 128-byte aligned rows)
+    double *x, *g, *gt, *d;
+    double *S, *Y;                 // [B][m][ld]
+    SeedState *st;                 // [B]
+    double *evp;                   // [B][ntiles][EP_N]       eval partials
+    double *upp;                   // [B][nchunks][ups]       update-kernel dot partials
+    double *dpp;                   // [B][nchunks][DP_N]      direction partials
+    int ups;                       // = UP_OLD + 4*m
+    // ladder + results (device copies; host reads them back once at the end)
+    const double *rf_ladder;       // [nbeta]
+    int nbeta, max_beta;
+    double *ame;                   // [B][max_beta][3]
+    double *pest;                  // [B][max_beta][NPest]
+    int *status, *nit;             // [B][max_beta]
+    long long *nfev;               // [B][max_beta]
+    double *minpaths;              // NULL or [B][max_beta][ND+NP]
+    int *n_active;
+    unsigned long long *n_evals;   // seed-evaluations consumed by k_ls since create
+    // S1 outputs
+    double *outA, *outme, *outfe;  // [B]
+};
+
+// launch wrappers (va_kernels.hip); all asynchronous on `s`
+void launch_eval(const Dev &dv, int rhs, hipStream_t s);
+void launch_ls(const Dev &dv, hipStream_t s);
+void launch_update(const Dev &dv, hipStream_t s);
+void launch_coeffs(const Dev &dv, hipStream_t s);
+void launch_direction(const Dev &dv, hipStream_t s);
+void launch_init_states(const Dev &dv, int phase, double rf_scale_or_neg, hipStream_t s);
+void launch_finalize_eval(const Dev &dv, hipStream_t s);
+size_t eval_lds_bytes(const Dims &dm);
+int eval_grid(const Dims &dm);
+
+}  // namespace va

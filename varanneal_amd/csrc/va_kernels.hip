@@ -1,0 +1,436 @@
+// va_kernels.hip -- gfx950 kernels of the variational-annealing hot path.
+//
+//   k_eval       (A, me, fe, grad A) of every live seed at x (or x + stp*d):
+//                one workgroup = one tile of T time rows of one seed; rows (+halo)
+//                staged in LDS; forward residuals and the hand-coded adjoint of the
+//                discretisation stencil in the same kernel; wave64 shuffle + LDS
+//                reductions to one partial row per tile (deterministic: no atomics).
+//   k_ls         one wave per seed: reduce partials, More'-Thuente line-search step,
+//                L-BFGS-B stopping rules, beta-ladder bookkeeping (va_core.h: ls_step).
+//   k_update     x += stp*d, history pair (s, y) into its slot, g <- g_t, and all the
+//                inner products the direction needs in ONE sweep over S and Y.
+//   k_coeffs     one wave per seed: Gram update + two-loop recursion in coefficient space.
+//   k_direction  d = cg*g + sum_j cY_j*Y_j + cS_j*S_j, and g.d / d.d partials.
+//
+// Reference arithmetic: see va_core.h header.  All fp64.  HBM-bound streaming
+// kernels: nothing here is GEMM-shaped, so no MFMA.
+#include "va_device.h"
+
+namespace va {
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one):
+// give each XCD a contiguous range of work items so that neighbouring tiles of a
+// seed (which share halo rows) meet in the same L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwork)
+{
+    const int per = (nwork + 7) >> 3;
+    return (bid & 7) * per + (bid >> 3);
+}
+
+// ------------------------------------------------------------------ K1: eval
+template <class RHS, int DISC>
+__global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
+{
+    extern __shared__ double smem[];
+    const Dims &dm = dv.dm;
+    const int nwork = dm.B * dm.ntiles;
+    const int w = xcd_swizzle(blockIdx.x, nwork);
+    if (w >= nwork) return;
+    const int b = w / dm.ntiles, tile = w - b * dm.ntiles;
+    const SeedState &st = dv.st[b];
+    const int phase = st.phase;
+    if (phase != PH_START && phase != PH_LS) return;
+
+    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
+    constexpr int K = EP_GP + RHS::NP;            // partial columns in use
+    const int R = dm.T + HL + HR, RD = R * dm.D;
+    TileCtx c;
+    c.n0 = tile * dm.T; c.R = R; c.use_d = (phase == PH_LS);
+    c.stp = st.stp; c.c = 2.0 * st.rf_scale * dm.cfe;
+    c.xs = smem; c.fs = smem + RD; c.qs = smem + 2 * RD;
+    double *red = smem + 3 * RD;
+    c.xg = dv.x + (size_t)b * dm.ld; c.dg = dv.d + (size_t)b * dm.ld;
+    c.gtg = dv.gt + (size_t)b * dm.ld;
+    tile_params<RHS>(dm, dv.pp, b, c);
+
+    const int tid = threadIdx.x, nt = blockDim.x;
+    ThreadAcc acc;
+    acc.clear();
+    tile_load<DISC>(dm, c, tid, nt);
+    __syncthreads();
+    tile_f<RHS, DISC>(dm, c, tid, nt);
+    __syncthreads();
+    tile_q<DISC>(dm, dv.pp, c, acc, tid, nt);
+    __syncthreads();
+    tile_s<DISC>(dm, c, tid, nt);
+    __syncthreads();
+    tile_g<RHS, DISC>(dm, dv.pp, c, acc, tid, nt);
+
+    // wave64 shuffle reduction, then across the workgroup's waves through LDS
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double v = (k == EP_GMAX) ? wave_max(acc.v[k]) : wave_sum(acc.v[k]);
+        if (lane == 0) red[wave * K + k] = v;
+    }
+    __syncthreads();
+    if (tid < K) {
+        double v = red[tid];
+        for (int ww = 1; ww < nw; ++ww)
+            v = (tid == EP_GMAX) ? fmax(v, red[ww * K + tid]) : v + red[ww * K + tid];
+        dv.evp[((size_t)b * dm.ntiles + tile) * EP_N + tid] = v;
+    }
+}
+
+size_t eval_lds_bytes(const Dims &dm)
+{
+    const int HL = dm.disc == DISC_SH ? 2 : 1;
+    const int R = dm.T + HL + 1;
+    return sizeof(double) * ((size_t)3 * R * dm.D + (EVAL_THREADS / 64) * EP_N);
+}
+int eval_grid(const Dims &dm) { return ((dm.B * dm.ntiles + 7) / 8) * 8; }
+
+template <class RHS>
+static void launch_eval_rhs(const Dev &dv, hipStream_t s)
+{
+    const dim3 grid(eval_grid(dv.dm)), block(EVAL_THREADS);
+    const size_t lds = eval_lds_bytes(dv.dm);
+    switch (dv.dm.disc) {
+    case DISC_EULER: hipLaunchKernelGGL((k_eval<RHS, DISC_EULER>), grid, block, lds, s, dv); break;
+    case DISC_TRAPEZOID: hipLaunchKernelGGL((k_eval<RHS, DISC_TRAPEZOID>), grid, block, lds, s, dv); break;
+    case DISC_SH: hipLaunchKernelGGL((k_eval<RHS, DISC_SH>), grid, block, lds, s, dv); break;
+    default: hipLaunchKernelGGL((k_eval<RHS, DISC_FWDMAP>), grid, block, lds, s, dv); break;
+    }
+}
+
+void launch_eval(const Dev &dv, int rhs, hipStream_t s)
+{
+    (void)rhs;                 // VA_RHS_LORENZ96 is the only built-in RHS so far
+    launch_eval_rhs<RhsL96>(dv, s);
+}
+
+// reduce the tile partials of seed b: lane k owns column k.  Fixed order -> deterministic.
+__device__ __forceinline__ double reduce_eval_col(const Dev &dv, int b, int k)
+{
+    const double *p = dv.evp + (size_t)b * dv.dm.ntiles * EP_N + k;
+    double v = 0.0;
+    if (k == EP_GMAX) { for (int t = 0; t < dv.dm.ntiles; ++t) v = fmax(v, p[(size_t)t * EP_N]); }
+    else { for (int t = 0; t < dv.dm.ntiles; ++t) v += p[(size_t)t * EP_N]; }
+    return v;
+}
+
+// parameter tail of grad A (sum over tiles of the per-tile parameter partials) and its
+// share of the line-search sums.
+__device__ __forceinline__ void eval_tail(const Dev &dv, int b, int use_d, double *ev)
+{
+    const Dims &dm = dv.dm;
+    double *gt = dv.gt + (size_t)b * dm.ld;
+    const double *d = dv.d + (size_t)b * dm.ld;
+    for (int k = 0; k < dm.NPest; ++k) {
+        const double g = ev[EP_GP + dv.pp.Pidx[k]];
+        gt[dm.ND + k] = g;
+        if (use_d) ev[EP_GTD] += g * d[dm.ND + k];
+        ev[EP_GN2] += g * g;
+        ev[EP_GMAX] = fmax(ev[EP_GMAX], fabs(g));
+    }
+}
+
+// ------------------------------------------------------------------ K2: line search / ladder
+__global__ __launch_bounds__(64) void k_ls(const Dev dv)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    SeedState &s = dv.st[b];
+    const int phase = s.phase;
+    if (phase != PH_START && phase != PH_LS) {
+        if (lane == 0) { s.upd = 0; s.dir = 0; }
+        return;
+    }
+    const Dims &dm = dv.dm;
+    double col = (lane < EP_N) ? reduce_eval_col(dv, b, lane) : 0.0;
+    // direction partials (g.d, d.d) left by k_direction
+    double dcol = 0.0;
+    if (lane < DP_N) {
+        const double *p = dv.dpp + (size_t)b * dm.nchunks * DP_N + lane;
+        for (int t = 0; t < dm.nchunks; ++t) dcol += p[(size_t)t * DP_N];
+    }
+    double ev[EP_N], dirp[DP_N];
+#pragma unroll
+    for (int k = 0; k < EP_N; ++k) ev[k] = __shfl(col, k, 64);
+#pragma unroll
+    for (int k = 0; k < DP_N; ++k) dirp[k] = __shfl(dcol, k, 64);
+    if (lane != 0) return;
+    atomicAdd(dv.n_evals, 1ULL);
+    eval_tail(dv, b, phase == PH_LS, ev);
+    SeedResults r;
+    r.ame = dv.ame + (size_t)b * dv.max_beta * 3;
+    r.pest = nullptr;
+    r.status = dv.status + (size_t)b * dv.max_beta;
+    r.nit = dv.nit + (size_t)b * dv.max_beta;
+    r.nfev = dv.nfev + (size_t)b * dv.max_beta;
+    int dec = 0;
+    ls_step(s, ev, dirp, dv.o, dv.rf_ladder, dv.nbeta, r, &dec, dm.cme, dm.cfe);
+    if (dec) atomicSub(dv.n_active, 1);
+}
+void launch_ls(const Dev &dv, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_ls, dim3(dv.dm.B), dim3(64), 0, s, dv);
+}
+
+// S1 epilogue: A, me, fe and the parameter tail for a plain evaluation.
+__global__ __launch_bounds__(64) void k_finalize_eval(const Dev dv)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double col = (lane < EP_N) ? reduce_eval_col(dv, b, lane) : 0.0;
+    double ev[EP_N];
+#pragma unroll
+    for (int k = 0; k < EP_N; ++k) ev[k] = __shfl(col, k, 64);
+    if (lane != 0) return;
+    eval_tail(dv, b, 0, ev);
+    const double me = ev[EP_ME] * dv.dm.cme, fe = ev[EP_FE] * dv.dm.cfe * dv.st[b].rf_scale;
+    dv.outA[b] = me + fe; dv.outme[b] = me; dv.outfe[b] = fe;
+}
+void launch_finalize_eval(const Dev &dv, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_finalize_eval, dim3(dv.dm.B), dim3(64), 0, s, dv);
+}
+
+// reset every seed: phase, ladder position, RF.  rf < 0 -> take rf_ladder[0].
+__global__ void k_init_states(const Dev dv, int phase, double rf)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= dv.dm.B) return;
+    SeedState &s = dv.st[b];
+    s.phase = phase; s.beta_idx = 0; s.iter = 0; s.col = 0; s.head = 0; s.ifun = 0; s.iback = 0;
+    s.ls_task = LS_START; s.upd = 0; s.slot = 0; s.dir = 0; s.store_idx = -1; s.nold = 0;
+    s.nfev = 0; s.f = 0.0; s.fold = 0.0; s.me = 0.0; s.fe = 0.0; s.theta = 1.0; s.stp = 0.0;
+    s.stp_upd = 0.0; s.gd = 0.0; s.gdold = 0.0; s.gn2 = 0.0; s.dr = 0.0; s.cg = -1.0;
+    s.rf_scale = rf < 0.0 ? dv.rf_ladder[0] : rf;
+}
+void launch_init_states(const Dev &dv, int phase, double rf, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_init_states, dim3((dv.dm.B + 63) / 64), dim3(64), 0, s, dv, phase, rf);
+}
+
+// ------------------------------------------------------------------ K3: update + inner products
+__global__ __launch_bounds__(VEC_THREADS) void k_update(const Dev dv)
+{
+    __shared__ double red[(VEC_THREADS / 64) * UP_N];
+    const Dims &dm = dv.dm;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const SeedState &s = dv.st[b];
+    const int upd = s.upd, dir = s.dir;
+    if (!upd && !dir) return;
+    const int nold = dir ? s.nold : 0;
+    const bool hist = (upd & UPD_HIST) != 0;
+    const double stp = s.stp_upd;
+    const size_t vo = (size_t)b * dm.ld;
+    double *x = dv.x + vo, *g = dv.g + vo;
+    const double *gt = dv.gt + vo, *d = dv.d + vo;
+    double *Sn = dv.S + ((size_t)b * dm.m + s.slot) * dm.ld;
+    double *Yn = dv.Y + ((size_t)b * dm.m + s.slot) * dm.ld;
+    double *mp = nullptr;
+    if ((upd & UPD_STORE) && dv.minpaths)
+        mp = dv.minpaths + ((size_t)b * dv.max_beta + s.store_idx) * (dm.ND + dm.NP);
+
+    constexpr int E = VEC_CHUNK / VEC_THREADS / 2;      // double2 per lane
+    const int tid = threadIdx.x;
+    double2 gtv[E], yv[E];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
+    int idx[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = chunk * VEC_CHUNK + (e * VEC_THREADS + tid) * 2;
+        idx[e] = i;
+        gtv[e] = make_double2(0.0, 0.0); yv[e] = make_double2(0.0, 0.0);
+        if (i >= dm.ld) continue;
+        const double2 dv2 = *reinterpret_cast<const double2 *>(d + i);
+        const double2 gv = *reinterpret_cast<const double2 *>(g + i);
+        const double2 tv = *reinterpret_cast<const double2 *>(gt + i);
+        double2 xv = *reinterpret_cast<const double2 *>(x + i);
+        gtv[e] = tv;
+        if (upd & UPD_X) {
+            xv.x = trial(xv.x, stp, dv2.x); xv.y = trial(xv.y, stp, dv2.y);
+            *reinterpret_cast<double2 *>(x + i) = xv;
+        }
+        if (upd & UPD_STORE) {
+            // the lane that owns an element stores it (va_ode.py:776): path entries as they
+            // are, estimated parameters scattered to their Pidx slot of the full vector.
+            const double vals[2] = {xv.x, xv.y};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ii = i + u;
+                if (ii < dm.ND) { if (mp) mp[ii] = vals[u]; }
+                else if (ii < dm.ND + dm.NPest) {
+                    const int k = ii - dm.ND;
+                    dv.pest[((size_t)b * dv.max_beta + s.store_idx) * dm.NPest + k] = vals[u];
+                    if (mp) mp[dm.ND + dv.pp.Pidx[k]] = vals[u];
+                }
+            }
+        }
+        double2 sv = make_double2(0.0, 0.0);
+        if (hist) {
+            sv = make_double2(stp * dv2.x, stp * dv2.y);
+            yv[e] = make_double2(tv.x - gv.x, tv.y - gv.y);
+            *reinterpret_cast<double2 *>(Sn + i) = sv;
+            *reinterpret_cast<double2 *>(Yn + i) = yv[e];
+        }
+        if (upd & UPD_G) *reinterpret_cast<double2 *>(g + i) = tv;
+        a0 += yv[e].x * tv.x + yv[e].y * tv.y;          // y.gt
+        a1 += sv.x * tv.x + sv.y * tv.y;                // s.gt
+        a2 += yv[e].x * yv[e].x + yv[e].y * yv[e].y;    // y.y
+        a3 += sv.x * yv[e].x + sv.y * yv[e].y;          // s.y
+        a4 += tv.x * tv.x + tv.y * tv.y;                // gt.gt
+    }
+    if (mp && chunk == 0 && tid == 0) {
+        // fixed (non-estimated) parameters of the stored step come from P
+        for (int j = 0; j < dm.NP; ++j) {
+            bool est = false;
+            for (int k = 0; k < dm.NPest; ++k) est = est || (dv.pp.Pidx[k] == j);
+            if (!est) mp[dm.ND + j] = dv.pp.Pfull[(size_t)b * dm.NP + j];
+        }
+    }
+    if (!dir) return;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int K = UP_OLD + 4 * nold;
+    {
+        double v;
+        v = wave_sum(a0); if (lane == 0) red[wave * UP_N + UP_YGT] = v;
+        v = wave_sum(a1); if (lane == 0) red[wave * UP_N + UP_SGT] = v;
+        v = wave_sum(a2); if (lane == 0) red[wave * UP_N + UP_YY] = v;
+        v = wave_sum(a3); if (lane == 0) red[wave * UP_N + UP_SY] = v;
+        v = wave_sum(a4); if (lane == 0) red[wave * UP_N + UP_GTGT] = v;
+    }
+    for (int j = 0; j < nold; ++j) {
+        const int sj = s.order[j];
+        const double *Sj = dv.S + ((size_t)b * dm.m + sj) * dm.ld;
+        const double *Yj = dv.Y + ((size_t)b * dm.m + sj) * dm.ld;
+        double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (idx[e] >= dm.ld) continue;
+            const double2 sv = *reinterpret_cast<const double2 *>(Sj + idx[e]);
+            const double2 yj = *reinterpret_cast<const double2 *>(Yj + idx[e]);
+            b0 += sv.x * gtv[e].x + sv.y * gtv[e].y;    // S_j . gt
+            b1 += yj.x * gtv[e].x + yj.y * gtv[e].y;    // Y_j . gt
+            b2 += sv.x * yv[e].x + sv.y * yv[e].y;      // S_j . y
+            b3 += yj.x * yv[e].x + yj.y * yv[e].y;      // Y_j . y
+        }
+        double v;
+        v = wave_sum(b0); if (lane == 0) red[wave * UP_N + UP_OLD + 4 * j + 0] = v;
+        v = wave_sum(b1); if (lane == 0) red[wave * UP_N + UP_OLD + 4 * j + 1] = v;
+        v = wave_sum(b2); if (lane == 0) red[wave * UP_N + UP_OLD + 4 * j + 2] = v;
+        v = wave_sum(b3); if (lane == 0) red[wave * UP_N + UP_OLD + 4 * j + 3] = v;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += VEC_THREADS) {
+        double v = red[k];
+#pragma unroll
+        for (int ww = 1; ww < VEC_THREADS / 64; ++ww) v += red[ww * UP_N + k];
+        dv.upp[((size_t)b * dm.nchunks + chunk) * dv.ups + k] = v;
+    }
+}
+void launch_update(const Dev &dv, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_update, dim3(dv.dm.nchunks, dv.dm.B), dim3(VEC_THREADS), 0, s, dv);
+}
+
+// ------------------------------------------------------------------ K4: direction coefficients
+__global__ __launch_bounds__(64) void k_coeffs(const Dev dv)
+{
+    __shared__ double up[UP_N];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    SeedState &s = dv.st[b];
+    if (!s.dir) return;
+    const Dims &dm = dv.dm;
+    const int K = UP_OLD + 4 * s.nold;
+    for (int k = lane; k < K; k += 64) {
+        const double *p = dv.upp + (size_t)b * dm.nchunks * dv.ups + k;
+        double v = 0.0;
+        for (int t = 0; t < dm.nchunks; ++t) v += p[(size_t)t * dv.ups];
+        up[k] = v;
+    }
+    __syncthreads();
+    if (lane == 0) direction_coeffs(s, up, dv.o);
+}
+void launch_coeffs(const Dev &dv, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_coeffs, dim3(dv.dm.B), dim3(64), 0, s, dv);
+}
+
+// ------------------------------------------------------------------ K5: direction
+__global__ __launch_bounds__(VEC_THREADS) void k_direction(const Dev dv)
+{
+    __shared__ double red[(VEC_THREADS / 64) * DP_N];
+    const Dims &dm = dv.dm;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const SeedState &s = dv.st[b];
+    if (!s.dir) return;
+    const size_t vo = (size_t)b * dm.ld;
+    const double *g = dv.g + vo;
+    double *d = dv.d + vo;
+    const int col = s.col;
+    const double cg = s.cg;
+    constexpr int E = VEC_CHUNK / VEC_THREADS / 2;
+    const int tid = threadIdx.x;
+    double2 acc[E], gv[E];
+    int idx[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        idx[e] = chunk * VEC_CHUNK + (e * VEC_THREADS + tid) * 2;
+        gv[e] = make_double2(0.0, 0.0);
+        if (idx[e] < dm.ld) gv[e] = *reinterpret_cast<const double2 *>(g + idx[e]);
+        acc[e] = make_double2(cg * gv[e].x, cg * gv[e].y);
+    }
+    for (int j = 0; j < col; ++j) {
+        const int sj = s.order[j];
+        const double cy = s.cY[sj], cs = s.cS[sj];
+        const double *Sj = dv.S + ((size_t)b * dm.m + sj) * dm.ld;
+        const double *Yj = dv.Y + ((size_t)b * dm.m + sj) * dm.ld;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (idx[e] >= dm.ld) continue;
+            const double2 yv = *reinterpret_cast<const double2 *>(Yj + idx[e]);
+            const double2 sv = *reinterpret_cast<const double2 *>(Sj + idx[e]);
+            acc[e].x += cy * yv.x; acc[e].y += cy * yv.y;
+            acc[e].x += cs * sv.x; acc[e].y += cs * sv.y;
+        }
+    }
+    double gd = 0.0, dd = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (idx[e] >= dm.ld) continue;
+        *reinterpret_cast<double2 *>(d + idx[e]) = acc[e];
+        gd += gv[e].x * acc[e].x + gv[e].y * acc[e].y;
+        dd += acc[e].x * acc[e].x + acc[e].y * acc[e].y;
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    gd = wave_sum(gd); dd = wave_sum(dd);
+    if (lane == 0) { red[wave * DP_N + DP_GD] = gd; red[wave * DP_N + DP_DD] = dd; }
+    __syncthreads();
+    if (tid < DP_N) {
+        double v = red[tid];
+#pragma unroll
+        for (int ww = 1; ww < VEC_THREADS / 64; ++ww) v += red[ww * DP_N + tid];
+        dv.dpp[((size_t)b * dm.nchunks + chunk) * DP_N + tid] = v;
+    }
+}
+void launch_direction(const Dev &dv, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_direction, dim3(dv.dm.nchunks, dv.dm.B), dim3(VEC_THREADS), 0, s, dv);
+}
+
+}  // namespace va
