@@ -70,6 +70,32 @@ def cpu_baseline(D, N, Y, Lidx, XP, P, budget_s=10.0):
                       % (n, D, N, dt, os.cpu_count() or 0)}
 
 
+def ladder_mode(args, pb0, XP, P, D, N, B, Y, Lidx, device):
+    """Whole ladder (alpha=1.5, beta=0..nbeta-1, SciPy-equal stopping rules) for B seeds;
+    reports end-to-end seed-evaluations/s including every L-BFGS vector kernel."""
+    from varanneal_amd import _capi, twin
+    pb0.close()
+    nb = args.nbeta
+    rf = 1.5 ** np.arange(nb)
+    opts = {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000000, 'maxiter': 1000000}
+    pb = _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", device=device,
+                       max_beta=nb, tile_rows=args.tile_rows)
+    pb.anneal(XP, rf[:2], opts)                                   # warm-up (allocations, code load)
+    t0 = time.perf_counter()
+    r = pb.anneal(XP, rf, opts)
+    dt = time.perf_counter() - t0
+    c = pb.counters()
+    nfev = int(r["nfev"].sum()); nit = int(r["nit"].sum())
+    print(json.dumps({"mode": "ladder", "workload": "D=%d N=%d B=%d nbeta=%d" % (D, N, B, nb),
+                      "seconds": dt, "seed_evals": nfev, "seed_evals_per_s": nfev / dt,
+                      "lbfgs_iterations": nit, "cycles": c["cycles"],
+                      "us_per_cycle": dt * 1e6 / max(1, c["cycles"] - 0),
+                      "A_final_median": float(np.median(r["A"][:, -1])),
+                      "k_final_median": float(np.median(r["pest"][:, -1, 0])),
+                      "status_counts": np.bincount(r["status"].ravel(), minlength=3).tolist()}), flush=True)
+    pb.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +104,10 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--tile-rows", type=int, default=0)
+    ap.add_argument("--mode", default="eval", choices=["eval", "ladder"],
+                    help="eval: the contract line (batched A/gradA launches); ladder: a whole "
+                         "RF ladder through va_anneal, extra information (stderr-style JSON)")
+    ap.add_argument("--nbeta", type=int, default=30)
     args = ap.parse_args()
 
     import torch
@@ -99,6 +129,9 @@ def main():
     pb = _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid",
                        device=local_rank, tile_rows=args.tile_rows)
     info = pb.info()
+    if args.mode == "ladder":
+        ladder_mode(args, pb, XP, P, D, N, B, Y, Lidx, local_rank)
+        return
     A, me, fe, g = pb.action_grad(XP, RF_SCALE)          # paths now resident in HBM
 
     def barrier():
