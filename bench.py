@@ -79,7 +79,7 @@ def ladder_mode(args, pb0, XP, P, D, N, B, Y, Lidx, device):
     rf = 1.5 ** np.arange(nb)
     opts = {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000000, 'maxiter': 1000000}
     pb = _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", device=device,
-                       max_beta=nb, tile_rows=args.tile_rows)
+                       max_beta=nb, tile_rows=args.tile_rows, eval_kernel=args.eval_kernel)
     pb.anneal(XP, rf[:2], opts)                                   # warm-up (allocations, code load)
     t0 = time.perf_counter()
     r = pb.anneal(XP, rf, opts)
@@ -108,6 +108,7 @@ def main():
                     help="eval: the contract line (batched A/gradA launches); ladder: a whole "
                          "RF ladder through va_anneal, extra information (stderr-style JSON)")
     ap.add_argument("--nbeta", type=int, default=30)
+    ap.add_argument("--eval-kernel", type=int, default=0, help="0 auto, 1 flat-mapped, 2 column-mapped")
     args = ap.parse_args()
 
     import torch
@@ -127,7 +128,7 @@ def main():
     D, N, B = w["D"], w["N"], w["B"]
     Y, Lidx, XP, P = make_inputs(D, N, B, rank)
     pb = _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid",
-                       device=local_rank, tile_rows=args.tile_rows)
+                       device=local_rank, tile_rows=args.tile_rows, eval_kernel=args.eval_kernel)
     info = pb.info()
     if args.mode == "ladder":
         ladder_mode(args, pb, XP, P, D, N, B, Y, Lidx, local_rank)

@@ -77,6 +77,7 @@ typedef struct va_problem_desc {
     int32_t max_beta;         /* longest ladder va_anneal will be asked for (>=1)    */
     int32_t keep_paths;       /* 1: keep every beta step's path on device (minpaths) */
     int32_t tile_rows;        /* 0 = auto; time rows per workgroup                   */
+    int32_t eval_kernel;      /* 0 = auto; 1 = flat-mapped, 2 = column-mapped tile kernel */
     void *stream;             /* hipStream_t to run on; NULL = library-owned stream  */
 } va_problem_desc;
 

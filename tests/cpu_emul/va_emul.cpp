@@ -11,6 +11,7 @@
 
 #include "../../include/varanneal_amd.h"
 #include "../../varanneal_amd/csrc/va_core.h"
+#include "../../varanneal_amd/csrc/va_tile2.h"
 
 using namespace va;
 
@@ -32,6 +33,13 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     m.m = d->lbfgs_m > 0 ? d->lbfgs_m : 10; m.disc = d->disc;
     m.ld = ((m.ND + m.NPest + 15) / 16) * 16;
     if (m.disc == DISC_SH && (T & 1)) ++T;
+    m.emode = d->eval_kernel == 1 ? 1 : 2;
+    m.RY = tile2_RY(m.D); m.NT = tile2_threads(m.D); m.maxr = 16;
+    if (m.emode == 2) {                      // a lane walks at most 16 rows of the staged tile
+        const int HLR = m.disc == DISC_SH ? 3 : 2;
+        if (T + HLR > 16 * m.RY) T = 16 * m.RY - HLR;
+        if (m.disc == DISC_SH && (T & 1)) --T;
+    }
     m.T = T; m.ntiles = (m.N + T - 1) / T;
     m.chunk = 1000; m.nchunks = (m.ld + m.chunk - 1) / m.chunk;
     m.dt = d->dt_model; m.cme = 1.0 / ((double)m.L * m.N_data); m.cfe = 1.0 / ((double)m.D * (m.N - 1));
@@ -84,11 +92,50 @@ void eval_seed(const Emul &E, int b, const double *x, const double *d, int use_d
     }
 }
 
+// K1, column-mapped variant (va_tile2.h): emulate the (ty, tx) threads phase by phase.
+template <class RHS, int DISC>
+void eval_seed2(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
+                double rf_scale, double *gt, double *ev)
+{
+    const Dims &dm = E.dm;
+    constexpr int MAXR = 16;
+    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
+    constexpr bool FUSE = RHS::CHEAP_F && DISC != DISC_SH;
+    const int D = dm.D, R = dm.T + HL + HR, RY = dm.RY, NTH = D * RY;
+    std::vector<double> xs(R * D), fs(R * D), qs(R * D);
+    for (int k = 0; k < EP_N; ++k) ev[k] = 0.0;
+    for (int tile = 0; tile < dm.ntiles; ++tile) {
+        std::vector<Tile2> th(NTH);
+        std::vector<TRegs<MAXR>> rg(NTH);
+        std::vector<ThreadAcc> acc(NTH);
+        for (int t = 0; t < NTH; ++t) {
+            Tile2 &c = th[t];
+            c.n0 = tile * dm.T; c.R = R; c.RY = RY; c.ty = t / D; c.use_d = use_d;
+            c.col = make_cols(t % D, D); c.l = E.lmap[t % D];
+            c.stp = stp; c.c = 2.0 * rf_scale * dm.cfe;
+            c.xs = xs.data(); c.fs = fs.data(); c.qs = qs.data();
+            c.xg = x; c.dg = d; c.gtg = gt;
+            tile2_params<RHS>(dm, E.pp, b, c);
+            acc[t].clear();
+        }
+        for (int t = 0; t < NTH; ++t) tile2_load<DISC, MAXR>(dm, E.pp, th[t], rg[t]);
+        if (!FUSE) for (int t = 0; t < NTH; ++t) tile2_f<RHS, DISC, MAXR>(dm, th[t], rg[t]);
+        for (int t = 0; t < NTH; ++t) tile2_q<RHS, DISC, MAXR, FUSE>(dm, E.pp, th[t], rg[t], acc[t]);
+        for (int t = 0; t < NTH; ++t) tile2_g<RHS, DISC, MAXR>(dm, th[t], rg[t], acc[t]);
+        for (int t = 0; t < NTH; ++t)
+            for (int k = 0; k < EP_N; ++k) {
+                if (k == EP_GMAX) ev[k] = fmax(ev[k], acc[t].v[k]);
+                else ev[k] += acc[t].v[k];
+            }
+    }
+}
+
 template <int DISC>
 void eval_seed_rhs(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
                    double rf_scale, double *gt, double *ev)
 {
-    eval_seed<RhsL96, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+    if (E.dm.emode == 2) eval_seed2<RhsL96c, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+    else eval_seed<RhsL96, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
 }
 
 void eval_dispatch(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,

@@ -13,20 +13,24 @@ from varanneal_amd import _capi
 OPTS = {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000000, 'maxiter': 1000000}
 
 
-def _desc(c, batch=1):
+def _desc(c, batch=1, eval_kernel=0):
     N, D = int(c["N_model"]), int(c["D"])
     RM, RF0 = rm_rf_for(c)
     return _capi.make_desc(batch, D, N, c["Y"], c["Lidx"], c["dt_model"], RM, RF0,
                            np.tile(c["XP"][N * D:], (batch, 1)), [0], disc=str(c["disc"]),
-                           merr_nskip=int(c["merr_nskip"]))
+                           merr_nskip=int(c["merr_nskip"]), eval_kernel=eval_kernel)
 
 
-def test_tile_phases_match_golden_for_every_tiling(golden_single):
+@pytest.mark.parametrize("eval_kernel", [1, 2])
+def test_tile_phases_match_golden_for_every_tiling(golden_single, eval_kernel):
+    """flat-mapped (va_core.h) and column-mapped (va_tile2.h) tiles, every discretisation,
+    scalar/vector RM/RF, nskip 1 and 2."""
     for name, c in golden_single.items():
-        desc, keep = _desc(c)
+        desc, keep = _desc(c, eval_kernel=eval_kernel)
         for T in (2, 7, 50, 400):        # tiny tiles, ragged last tile, single tile
             A, me, fe, g = emul.action_grad(desc, T, c["XP"][None, :], c["rf_scale"])
             assert abs(A[0] - c["A"]) <= 1e-12 * abs(c["A"]), (name, T)
+            assert abs(me[0] - c["me"]) <= 1e-12 * max(abs(c["me"]), abs(c["A"])), (name, T)
             if "grad" in c:
                 assert np.abs(g[0] - c["grad"]).max() <= 1e-11 * np.abs(c["grad"]).max(), (name, T)
 

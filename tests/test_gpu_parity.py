@@ -33,11 +33,13 @@ def gpu_problem(capi, c, batch=1, **kw):
                         disc=str(c["disc"]), merr_nskip=int(c["merr_nskip"]), **kw)
 
 
-def test_all_golden_single_evals(capi, golden_single):
+@pytest.mark.parametrize("eval_kernel", [1, 2])
+def test_all_golden_single_evals(capi, golden_single, eval_kernel):
+    """both tile kernels (1 flat-mapped, 2 column-mapped), auto and tiny tiles"""
     worstA = worstG = 0.0
     for name, c in golden_single.items():
         for tile_rows in (0, 6):
-            with gpu_problem(capi, c, tile_rows=tile_rows) as pb:
+            with gpu_problem(capi, c, tile_rows=tile_rows, eval_kernel=eval_kernel) as pb:
                 A, me, fe, g = pb.action_grad(c["XP"][None, :], c["rf_scale"])
             eA = abs(A[0] - c["A"]) / abs(c["A"])
             assert eA <= RTOL_A, (name, tile_rows, eA)

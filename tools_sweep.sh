@@ -1,0 +1,12 @@
+#!/bin/bash
+# usage: tools_sweep.sh <workload> <steps> "<tile rows list>" [eval_kernel]
+w=$1; steps=$2; ek=${4:-0}
+for T in $3; do
+  python bench.py --workload $w --steps $steps --warmup 50 --no-cpu --tile-rows $T --eval-kernel $ek 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    l=l.strip()
+    if l.startswith('{'):
+        j=json.loads(l); print('$w ek=$ek T=%3d ntiles=%4d kernel_us=%9.2f frac=%.3f evals/s=%.3e' % (j['config']['tile_rows'], j['config']['ntiles'], j['roofline']['kernel_us'], j['roofline']['frac'], j['value']))
+"
+done

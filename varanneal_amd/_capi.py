@@ -44,7 +44,7 @@ class ProblemDesc(C.Structure):
                 ("NP", C.c_int32), ("NPest", C.c_int32), ("Pidx", c_ip), ("P", c_dp),
                 ("disc", C.c_int32), ("rhs", C.c_int32), ("lbfgs_m", C.c_int32),
                 ("max_beta", C.c_int32), ("keep_paths", C.c_int32), ("tile_rows", C.c_int32),
-                ("stream", C.c_void_p)]
+                ("eval_kernel", C.c_int32), ("stream", C.c_void_p)]
 
 
 class LbfgsOpts(C.Structure):
@@ -66,7 +66,7 @@ def _f64(a):
 
 def make_desc(batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, disc="trapezoid",
               rhs="lorenz96", merr_nskip=1, lbfgs_m=10, max_beta=1, keep_paths=0, tile_rows=0,
-              device=0, stream=None):
+              eval_kernel=0, device=0, stream=None):
     """Build a ProblemDesc plus the list of arrays that must outlive it."""
     Y = _f64(Y)
     N_data, L = Y.shape
@@ -105,6 +105,7 @@ def make_desc(batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, disc="trap
     d.disc = DISC[disc] if isinstance(disc, str) else int(disc)
     d.rhs = RHS[rhs] if isinstance(rhs, str) else int(rhs)
     d.lbfgs_m, d.max_beta, d.keep_paths, d.tile_rows = lbfgs_m, max_beta, keep_paths, tile_rows
+    d.eval_kernel = eval_kernel
     d.stream = stream
     return d, keep
 

@@ -68,16 +68,37 @@ struct va_problem_s {
 
 namespace {
 
-int pick_tile_rows(const va_problem_desc *d)
+// Tile geometry of the eval kernel: which mapping, rows per workgroup, threads.
+void pick_eval_geometry(const va_problem_desc *d, Dims &dm)
 {
-    const int D = d->D, N = d->N_model, HLR = (d->disc == VA_DISC_SIMPSON_HERMITE) ? 3 : 2;
-    // LDS: 3 staged arrays of (T+halo) rows; keep a workgroup under ~48 KiB so several fit a CU
-    int tmax = (int)((48 * 1024) / (3 * sizeof(double) * D)) - HLR;
+    const int D = d->D, N = d->N_model;
+    const bool sh = d->disc == VA_DISC_SIMPSON_HERMITE;
+    const int HLR = sh ? 3 : 2;
+    dm.emode = d->eval_kernel;
+    if (dm.emode != 1 && dm.emode != 2) dm.emode = (D <= 256) ? 2 : 1;
+    if (D > 256) dm.emode = 1;                            // column mapping needs a row per <=256 lanes
+    int tmin, tmax;
+    if (dm.emode == 2) {
+        dm.RY = tile2_RY(D); dm.NT = tile2_threads(D);
+        const int narr = sh ? 3 : 2;
+        const int lds_rows = (int)((60 * 1024) / (narr * sizeof(double) * D));
+        // 8 rows per lane keeps the register tile small; go to 16 when that would leave
+        // tiles so short that the halo rows dominate (large D)
+        dm.maxr = (8 * dm.RY - HLR >= 24) ? 8 : 16;
+        int rmax = dm.maxr * dm.RY;
+        if (rmax > lds_rows) rmax = lds_rows;
+        tmax = rmax - HLR;
+        tmin = dm.RY;
+    } else {
+        dm.RY = 0; dm.NT = EVAL_THREADS; dm.maxr = 0;
+        // LDS: 3 staged arrays of (T+halo) rows; keep a workgroup under ~48 KiB so several fit a CU
+        tmax = (int)((48 * 1024) / (3 * sizeof(double) * D)) - HLR;
+        tmin = (EVAL_THREADS + D - 1) / D;               // >= one element per lane
+    }
     if (tmax < 2) tmax = 2;
-    int tmin = (EVAL_THREADS + D - 1) / D;               // >= one element per lane
     if (tmin > tmax) tmin = tmax;
     int T;
-    if (d->tile_rows > 0) T = d->tile_rows;
+    if (d->tile_rows > 0) T = d->tile_rows < tmax ? d->tile_rows : tmax;
     else {
         // enough workgroups to cover 256 CUs a few times over
         int want = (1024 + d->batch - 1) / d->batch;     // tiles per seed
@@ -86,9 +107,10 @@ int pick_tile_rows(const va_problem_desc *d)
         if (T > tmax) T = tmax;
     }
     if (T > N) T = N;
-    if (d->disc == VA_DISC_SIMPSON_HERMITE && (T & 1)) ++T;
+    if (sh && (T & 1)) T += (T + 1 <= tmax) ? 1 : -1;
     if (T < 2) T = 2;
-    return T;
+    dm.T = T;
+    dm.ntiles = (N + T - 1) / T;
 }
 
 int copy_in(va_handle h, const double *XP, int64_t ld, int32_t mem)
@@ -204,8 +226,9 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     if (d->struct_size != (int32_t)sizeof(va_problem_desc)) return fail(VA_EINVAL, "struct_size %d != %zu", d->struct_size, sizeof(va_problem_desc));
     if (d->batch < 1 || d->D < 1 || d->N_model < 2 || d->N_data < 1 || d->L < 0 || d->merr_nskip < 1)
         return fail(VA_EINVAL, "bad sizes (batch=%d D=%d N_model=%d N_data=%d L=%d nskip=%d)", d->batch, d->D, d->N_model, d->N_data, d->L, d->merr_nskip);
-    if ((int64_t)(d->N_data - 1) * d->merr_nskip + 1 > d->N_model)
-        return fail(VA_EINVAL, "observations reach past the path: (N_data-1)*nskip+1 > N_model");
+    if ((int64_t)(d->N_data - 1) * d->merr_nskip + 1 != d->N_model)      /* va_ode.py:557 */
+        return fail(VA_EINVAL, "N_model (%d) must equal (N_data-1)*merr_nskip+1 (%lld)", d->N_model,
+                    (long long)(d->N_data - 1) * d->merr_nskip + 1);
     if (d->disc < VA_DISC_EULER || d->disc > VA_DISC_FORWARDMAP) return fail(VA_EINVAL, "unknown disc %d", d->disc);
     if (d->disc == VA_DISC_SIMPSON_HERMITE && (d->N_model % 2) == 0)
         return fail(VA_EINVAL, "SimpsonHermite needs an odd number of time points (N_model=%d)", d->N_model);
@@ -243,8 +266,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dm.nskip = d->merr_nskip; dm.NP = d->NP; dm.NPest = d->NPest; dm.B = d->batch; dm.m = m;
     dm.disc = d->disc;
     dm.ld = ((dm.ND + dm.NPest + 15) / 16) * 16;
-    dm.T = pick_tile_rows(d);
-    dm.ntiles = (dm.N + dm.T - 1) / dm.T;
+    pick_eval_geometry(d, dm);
     dm.chunk = VEC_CHUNK; dm.nchunks = (dm.ld + VEC_CHUNK - 1) / VEC_CHUNK;
     dm.dt = d->dt_model;
     dm.cme = d->L > 0 ? 1.0 / ((double)dm.L * dm.N_data) : 0.0;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "va_core.h"
+#include "va_tile2.h"
 
 namespace va {
 

@@ -96,11 +96,73 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
     }
 }
 
+// ------------------------------------------------------------------ K1 (fast path): column-mapped
+template <class RHS, int DISC, int MAXR>
+__global__ __launch_bounds__(256) void k_eval2(const Dev dv)
+{
+    extern __shared__ double smem[];
+    const Dims &dm = dv.dm;
+    const int nwork = dm.B * dm.ntiles;
+    const int w = xcd_swizzle(blockIdx.x, nwork);
+    if (w >= nwork) return;
+    const int b = w / dm.ntiles, tile = w - b * dm.ntiles;
+    const SeedState &st = dv.st[b];
+    const int phase = st.phase;
+    if (phase != PH_START && phase != PH_LS) return;
+
+    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
+    constexpr int K = EP_GP + RHS::NP;
+    constexpr bool FUSE = RHS::CHEAP_F && DISC != DISC_SH;
+    const int D = dm.D, R = dm.T + HL + HR, RD = R * D;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int ty = tid / D, tx = tid - ty * D;
+    const bool active = ty < dm.RY;
+
+    Tile2 t;
+    t.n0 = tile * dm.T; t.R = R; t.RY = dm.RY; t.ty = ty; t.use_d = (phase == PH_LS);
+    t.col = make_cols(tx, D);
+    t.l = active ? dv.pp.lmap[tx] : -1;
+    t.stp = st.stp; t.c = 2.0 * st.rf_scale * dm.cfe;
+    t.xs = smem; t.qs = smem + RD; t.fs = smem + 2 * RD;
+    double *red = smem + (FUSE ? 2 : 3) * RD;
+    t.xg = dv.x + (size_t)b * dm.ld; t.dg = dv.d + (size_t)b * dm.ld;
+    t.gtg = dv.gt + (size_t)b * dm.ld;
+    tile2_params<RHS>(dm, dv.pp, b, t);
+
+    TRegs<MAXR> rg;
+    ThreadAcc acc;
+    acc.clear();
+    if (active) tile2_load<DISC, MAXR>(dm, dv.pp, t, rg);
+    __syncthreads();
+    if (!FUSE) {
+        if (active) tile2_f<RHS, DISC, MAXR>(dm, t, rg);
+        __syncthreads();
+    }
+    if (active) tile2_q<RHS, DISC, MAXR, FUSE>(dm, dv.pp, t, rg, acc);
+    __syncthreads();
+    if (active) tile2_g<RHS, DISC, MAXR>(dm, t, rg, acc);
+
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double v = (k == EP_GMAX) ? wave_max(acc.v[k]) : wave_sum(acc.v[k]);
+        if (lane == 0) red[wave * K + k] = v;
+    }
+    __syncthreads();
+    if (tid < K) {
+        double v = red[tid];
+        for (int ww = 1; ww < nw; ++ww)
+            v = (tid == EP_GMAX) ? fmax(v, red[ww * K + tid]) : v + red[ww * K + tid];
+        dv.evp[((size_t)b * dm.ntiles + tile) * EP_N + tid] = v;
+    }
+}
+
 size_t eval_lds_bytes(const Dims &dm)
 {
     const int HL = dm.disc == DISC_SH ? 2 : 1;
     const int R = dm.T + HL + 1;
-    return sizeof(double) * ((size_t)3 * R * dm.D + (EVAL_THREADS / 64) * EP_N);
+    const int narr = (dm.emode == 2 && dm.disc != DISC_SH) ? 2 : 3;
+    return sizeof(double) * ((size_t)narr * R * dm.D + (256 / 64) * EP_N);
 }
 int eval_grid(const Dims &dm) { return ((dm.B * dm.ntiles + 7) / 8) * 8; }
 
@@ -117,10 +179,28 @@ static void launch_eval_rhs(const Dev &dv, hipStream_t s)
     }
 }
 
+template <class RHS, int MAXR>
+static void launch_eval2_rhs(const Dev &dv, hipStream_t s)
+{
+    const dim3 grid(eval_grid(dv.dm)), block(dv.dm.NT);
+    const size_t lds = eval_lds_bytes(dv.dm);
+    switch (dv.dm.disc) {
+    case DISC_EULER: hipLaunchKernelGGL((k_eval2<RHS, DISC_EULER, MAXR>), grid, block, lds, s, dv); break;
+    case DISC_TRAPEZOID: hipLaunchKernelGGL((k_eval2<RHS, DISC_TRAPEZOID, MAXR>), grid, block, lds, s, dv); break;
+    case DISC_SH: hipLaunchKernelGGL((k_eval2<RHS, DISC_SH, MAXR>), grid, block, lds, s, dv); break;
+    default: hipLaunchKernelGGL((k_eval2<RHS, DISC_FWDMAP, MAXR>), grid, block, lds, s, dv); break;
+    }
+}
+
 void launch_eval(const Dev &dv, int rhs, hipStream_t s)
 {
     (void)rhs;                 // VA_RHS_LORENZ96 is the only built-in RHS so far
-    launch_eval_rhs<RhsL96>(dv, s);
+    if (dv.dm.emode == 2) {
+        if (dv.dm.maxr <= 8) launch_eval2_rhs<RhsL96c, 8>(dv, s);
+        else launch_eval2_rhs<RhsL96c, 16>(dv, s);
+    } else {
+        launch_eval_rhs<RhsL96>(dv, s);
+    }
 }
 
 // reduce the tile partials of seed b: lane k owns column k.  Fixed order -> deterministic.
