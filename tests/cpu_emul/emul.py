@@ -12,6 +12,7 @@ _SO = os.path.join(_HERE, "libva_emul.so")
 _SRCS = [os.path.join(_HERE, "va_emul.cpp"),
          os.path.join(_HERE, "..", "..", "varanneal_amd", "csrc", "va_core.h"),
          os.path.join(_HERE, "..", "..", "varanneal_amd", "csrc", "va_tile2.h"),
+         os.path.join(_HERE, "..", "..", "varanneal_amd", "csrc", "va_tile3.h"),
          os.path.join(_HERE, "..", "..", "include", "varanneal_amd.h")]
 _lib = None
 

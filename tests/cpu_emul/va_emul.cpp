@@ -12,6 +12,7 @@
 #include "../../include/varanneal_amd.h"
 #include "../../varanneal_amd/csrc/va_core.h"
 #include "../../varanneal_amd/csrc/va_tile2.h"
+#include "../../varanneal_amd/csrc/va_tile3.h"
 
 using namespace va;
 
@@ -33,8 +34,13 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     m.m = d->lbfgs_m > 0 ? d->lbfgs_m : 10; m.disc = d->disc;
     m.ld = ((m.ND + m.NPest + 15) / 16) * 16;
     if (m.disc == DISC_SH && (T & 1)) ++T;
-    m.emode = d->eval_kernel == 1 ? 1 : 2;
+    m.emode = (d->eval_kernel >= 1 && d->eval_kernel <= 3) ? d->eval_kernel : 3;
     m.RY = tile2_RY(m.D); m.NT = tile2_threads(m.D); m.maxr = 16;
+    if (m.emode == 3) {                      // column-run: T = RY*K, K in {4,6,8}
+        int K = (T + m.RY - 1) / m.RY;
+        K = K <= 4 ? 4 : (K <= 6 ? 6 : 8);
+        m.maxr = K; T = m.RY * K;
+    }
     if (m.emode == 2) {                      // a lane walks at most 16 rows of the staged tile
         const int HLR = m.disc == DISC_SH ? 3 : 2;
         if (T + HLR > 16 * m.RY) T = 16 * m.RY - HLR;
@@ -130,11 +136,68 @@ void eval_seed2(const Emul &E, int b, const double *x, const double *d, int use_
     }
 }
 
+// K1, column-run variant (va_tile3.h)
+template <class RHS, int DISC, int K>
+void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
+                double rf_scale, double *gt, double *ev)
+{
+    const Dims &dm = E.dm;
+    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
+    const int D = dm.D, T = dm.T, R = T + HL + HR, RY = dm.RY, NTH = D * RY, NT = dm.NT;
+    std::vector<double> xs(R * D), ds(R * D), ss(T * D);
+    for (int k = 0; k < EP_N; ++k) ev[k] = 0.0;
+    for (int tile = 0; tile < dm.ntiles; ++tile) {
+        std::vector<Tile3> th(NT);
+        std::vector<T3Regs<K>> rg(NT);
+        std::vector<ThreadAcc> acc(NT);
+        for (int t = 0; t < NT; ++t) {
+            Tile3 &c = th[t];
+            c.n0 = tile * T; c.ty = t / D; c.r0 = c.n0 + c.ty * K; c.use_d = use_d;
+            c.col = make_cols(t % D, D); c.l = E.lmap[t % D];
+            c.stp = stp; c.c = 2.0 * rf_scale * dm.cfe;
+            c.xs = xs.data(); c.ds = ds.data(); c.ss = ss.data();
+            c.xg = x; c.dg = d; c.gtg = gt;
+            Tile2 tmp; tmp.xg = x; tmp.dg = d; tmp.use_d = use_d; tmp.stp = stp;
+            tile2_params<RHS>(dm, E.pp, b, tmp);
+            for (int k = 0; k < RHS_MAX_NP; ++k) c.p[k] = tmp.p[k];
+            acc[t].clear();
+        }
+        const bool edge = (tile * T - HL < 0) || (tile * T + T + HR > dm.N);
+        for (int t = 0; t < NT; ++t) {
+            if (edge) {
+                if (use_d) tile3_stage<DISC, 0, true, true>(dm, th[t], t, NT);
+                else tile3_stage<DISC, 0, true, false>(dm, th[t], t, NT);
+            } else {
+                if (use_d) tile3_stage<DISC, 0, false, true>(dm, th[t], t, NT);
+                else tile3_stage<DISC, 0, false, false>(dm, th[t], t, NT);
+            }
+        }
+        for (int t = 0; t < NTH; ++t) tile3_obs<K>(dm, E.pp, th[t], rg[t]);
+        for (int t = 0; t < NTH; ++t) {
+            if (edge) tile3_rows<RHS, DISC, K, true, 0>(dm, E.pp, th[t], rg[t], acc[t]);
+            else tile3_rows<RHS, DISC, K, false, 0>(dm, E.pp, th[t], rg[t], acc[t]);
+        }
+        for (int t = 0; t < NTH; ++t) {
+            if (edge) tile3_grad<RHS, DISC, K, true, 0>(dm, th[t], rg[t], acc[t]);
+            else tile3_grad<RHS, DISC, K, false, 0>(dm, th[t], rg[t], acc[t]);
+        }
+        for (int t = 0; t < NTH; ++t)
+            for (int k = 0; k < EP_N; ++k) {
+                if (k == EP_GMAX) ev[k] = fmax(ev[k], acc[t].v[k]);
+                else ev[k] += acc[t].v[k];
+            }
+    }
+}
+
 template <int DISC>
 void eval_seed_rhs(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
                    double rf_scale, double *gt, double *ev)
 {
-    if (E.dm.emode == 2) eval_seed2<RhsL96c, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+    if (E.dm.emode == 3) {
+        if (E.dm.maxr == 4) eval_seed3<RhsL96c, DISC, 4>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 6) eval_seed3<RhsL96c, DISC, 6>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else eval_seed3<RhsL96c, DISC, 8>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+    } else if (E.dm.emode == 2) eval_seed2<RhsL96c, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
     else eval_seed<RhsL96, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
 }
 

@@ -21,10 +21,10 @@ def _desc(c, batch=1, eval_kernel=0):
                            merr_nskip=int(c["merr_nskip"]), eval_kernel=eval_kernel)
 
 
-@pytest.mark.parametrize("eval_kernel", [1, 2])
+@pytest.mark.parametrize("eval_kernel", [1, 2, 3])
 def test_tile_phases_match_golden_for_every_tiling(golden_single, eval_kernel):
-    """flat-mapped (va_core.h) and column-mapped (va_tile2.h) tiles, every discretisation,
-    scalar/vector RM/RF, nskip 1 and 2."""
+    """flat-mapped (va_core.h), column-mapped (va_tile2.h) and column-run (va_tile3.h) tiles,
+    every discretisation, scalar/vector RM/RF, nskip 1 and 2."""
     for name, c in golden_single.items():
         desc, keep = _desc(c, eval_kernel=eval_kernel)
         for T in (2, 7, 50, 400):        # tiny tiles, ragged last tile, single tile

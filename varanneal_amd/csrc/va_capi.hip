@@ -75,9 +75,28 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm)
     const bool sh = d->disc == VA_DISC_SIMPSON_HERMITE;
     const int HLR = sh ? 3 : 2;
     dm.emode = d->eval_kernel;
-    if (dm.emode != 1 && dm.emode != 2) dm.emode = (D <= 256) ? 2 : 1;
-    if (D > 256) dm.emode = 1;                            // column mapping needs a row per <=256 lanes
+    // auto: column-run when a workgroup holds >= 4 lanes per column, row-strided columns for
+    // wider states (their short runs would be mostly halo), flat mapping beyond 256 columns
+    if (dm.emode < 1 || dm.emode > 3) dm.emode = (D <= 64) ? 3 : ((D <= 256) ? 2 : 1);
+    if (D > 256) dm.emode = 1;                            // column mappings need a row per <=256 lanes
     int tmin, tmax;
+    if (dm.emode == 3) {
+        // column-run kernel: T = RY*K exactly, K rows per lane in {4, 6, 8}
+        dm.RY = tile2_RY(D); dm.NT = tile2_threads(D);
+        int K = 6;
+        if (d->tile_rows > 0) {
+            K = (d->tile_rows + dm.RY - 1) / dm.RY;
+            K = K <= 4 ? 4 : (K <= 6 ? 6 : 8);
+        }
+        for (;;) {                                        // shrink until the staging arrays fit in LDS
+            const int T = dm.RY * K, R = T + HLR;
+            if (sizeof(double) * (size_t)(2 * R + T) * D <= 60 * 1024 || K == 4) break;
+            K -= 2;
+        }
+        dm.maxr = K; dm.T = dm.RY * K;
+        dm.ntiles = (N + dm.T - 1) / dm.T;
+        return;
+    }
     if (dm.emode == 2) {
         dm.RY = tile2_RY(D); dm.NT = tile2_threads(D);
         const int narr = sh ? 3 : 2;

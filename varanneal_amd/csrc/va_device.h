@@ -4,6 +4,7 @@
 
 #include "va_core.h"
 #include "va_tile2.h"
+#include "va_tile3.h"
 
 namespace va {
 

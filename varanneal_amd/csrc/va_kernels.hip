@@ -157,12 +157,115 @@ __global__ __launch_bounds__(256) void k_eval2(const Dev dv)
     }
 }
 
+// ------------------------------------------------------------------ K1 (production): column-run
+template <class RHS, int DISC, int K, int DC>
+__global__ __launch_bounds__(256) void k_eval3(const Dev dv)
+{
+    extern __shared__ double smem[];
+    const Dims &dm = dv.dm;
+    const int nwork = dm.B * dm.ntiles;
+    const int w = xcd_swizzle(blockIdx.x, nwork);
+    if (w >= nwork) return;
+    const int b = w / dm.ntiles, tile = w - b * dm.ntiles;
+    const SeedState &st = dv.st[b];
+    const int phase = st.phase;
+    if (phase != PH_START && phase != PH_LS) return;
+
+    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
+    constexpr int KP = EP_GP + RHS::NP;
+    const int D = DC > 0 ? DC : dm.D, T = dm.T, RD = (T + HL + HR) * D;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int ty = tid / D, tx = tid - ty * D;
+    const bool active = ty < dm.RY;
+
+    Tile3 t;
+    t.n0 = tile * T; t.ty = ty; t.r0 = t.n0 + ty * K; t.use_d = (phase == PH_LS);
+    t.col = make_cols(tx, D);
+    t.l = active ? dv.pp.lmap[tx] : -1;
+    t.stp = st.stp; t.c = 2.0 * st.rf_scale * dm.cfe;
+    t.xs = smem; t.ds = smem + RD; t.ss = smem + 2 * RD;
+    double *red = smem + 2 * RD + T * D;
+    t.xg = dv.x + (size_t)b * dm.ld; t.dg = dv.d + (size_t)b * dm.ld;
+    t.gtg = dv.gt + (size_t)b * dm.ld;
+    {   // parameters (same select-chain as tile2_params)
+#pragma unroll
+        for (int k = 0; k < RHS::NP; ++k) t.p[k] = dv.pp.Pfull[(size_t)b * dm.NP + k];
+        for (int k = 0; k < dm.NPest; ++k) {
+            double v = t.xg[dm.ND + k];
+            if (t.use_d) v = trial(v, t.stp, t.dg[dm.ND + k]);
+            const int dst = dv.pp.Pidx[k];
+#pragma unroll
+            for (int j = 0; j < RHS::NP; ++j) t.p[j] = (dst == j) ? v : t.p[j];
+        }
+    }
+    T3Regs<K> rg;
+    ThreadAcc acc;
+    acc.clear();
+    const bool edge = (t.n0 - HL < 0) || (t.n0 + T + HR > dm.N);     // workgroup-uniform
+    if (edge) {
+        if (t.use_d) tile3_stage<DISC, DC, true, true>(dm, t, tid, nt);
+        else tile3_stage<DISC, DC, true, false>(dm, t, tid, nt);
+    } else {
+        if (t.use_d) tile3_stage<DISC, DC, false, true>(dm, t, tid, nt);
+        else tile3_stage<DISC, DC, false, false>(dm, t, tid, nt);
+    }
+    if (active) tile3_obs<K>(dm, dv.pp, t, rg);
+    __syncthreads();
+    if (active) {
+        if (edge) tile3_rows<RHS, DISC, K, true, DC>(dm, dv.pp, t, rg, acc);
+        else tile3_rows<RHS, DISC, K, false, DC>(dm, dv.pp, t, rg, acc);
+    }
+    __syncthreads();
+    if (active) {
+        if (edge) tile3_grad<RHS, DISC, K, true, DC>(dm, t, rg, acc);
+        else tile3_grad<RHS, DISC, K, false, DC>(dm, t, rg, acc);
+    }
+
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        double v = (k == EP_GMAX) ? wave_max(acc.v[k]) : wave_sum(acc.v[k]);
+        if (lane == 0) red[wave * KP + k] = v;
+    }
+    __syncthreads();
+    if (tid < KP) {
+        double v = red[tid];
+        for (int ww = 1; ww < nw; ++ww)
+            v = (tid == EP_GMAX) ? fmax(v, red[ww * KP + tid]) : v + red[ww * KP + tid];
+        dv.evp[((size_t)b * dm.ntiles + tile) * EP_N + tid] = v;
+    }
+}
+
 size_t eval_lds_bytes(const Dims &dm)
 {
     const int HL = dm.disc == DISC_SH ? 2 : 1;
     const int R = dm.T + HL + 1;
-    const int narr = (dm.emode == 2 && dm.disc != DISC_SH) ? 2 : 3;
-    return sizeof(double) * ((size_t)narr * R * dm.D + (256 / 64) * EP_N);
+    size_t elems;
+    if (dm.emode == 3) elems = (size_t)(2 * R + dm.T) * dm.D;
+    else elems = (size_t)((dm.emode == 2 && dm.disc != DISC_SH) ? 2 : 3) * R * dm.D;
+    return sizeof(double) * (elems + (256 / 64) * EP_N);
+}
+
+template <class RHS, int K, int DC>
+static void launch_eval3_rhs(const Dev &dv, hipStream_t s)
+{
+    const dim3 grid(eval_grid(dv.dm)), block(dv.dm.NT);
+    const size_t lds = eval_lds_bytes(dv.dm);
+    switch (dv.dm.disc) {
+    case DISC_EULER: hipLaunchKernelGGL((k_eval3<RHS, DISC_EULER, K, DC>), grid, block, lds, s, dv); break;
+    case DISC_TRAPEZOID: hipLaunchKernelGGL((k_eval3<RHS, DISC_TRAPEZOID, K, DC>), grid, block, lds, s, dv); break;
+    case DISC_SH: hipLaunchKernelGGL((k_eval3<RHS, DISC_SH, K, DC>), grid, block, lds, s, dv); break;
+    default: hipLaunchKernelGGL((k_eval3<RHS, DISC_FWDMAP, K, DC>), grid, block, lds, s, dv); break;
+    }
+}
+
+// D fixed at compile time for the state sizes of the reference's own Lorenz-96 examples
+// (D = 20: examples/Lorenz96_D20); any other D runs the same kernel with D in a register.
+template <class RHS, int K>
+static void launch_eval3_d(const Dev &dv, hipStream_t s)
+{
+    if (dv.dm.D == 20) launch_eval3_rhs<RHS, K, 20>(dv, s);
+    else launch_eval3_rhs<RHS, K, 0>(dv, s);
 }
 int eval_grid(const Dims &dm) { return ((dm.B * dm.ntiles + 7) / 8) * 8; }
 
@@ -195,7 +298,11 @@ static void launch_eval2_rhs(const Dev &dv, hipStream_t s)
 void launch_eval(const Dev &dv, int rhs, hipStream_t s)
 {
     (void)rhs;                 // VA_RHS_LORENZ96 is the only built-in RHS so far
-    if (dv.dm.emode == 2) {
+    if (dv.dm.emode == 3) {
+        if (dv.dm.maxr == 4) launch_eval3_d<RhsL96c, 4>(dv, s);
+        else if (dv.dm.maxr == 6) launch_eval3_d<RhsL96c, 6>(dv, s);
+        else launch_eval3_d<RhsL96c, 8>(dv, s);
+    } else if (dv.dm.emode == 2) {
         if (dv.dm.maxr <= 8) launch_eval2_rhs<RhsL96c, 8>(dv, s);
         else launch_eval2_rhs<RhsL96c, 16>(dv, s);
     } else {
