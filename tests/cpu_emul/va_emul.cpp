@@ -144,7 +144,7 @@ void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_
     const Dims &dm = E.dm;
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
     const int D = dm.D, T = dm.T, R = T + HL + HR, RY = dm.RY, NTH = D * RY, NT = dm.NT;
-    std::vector<double> xs(R * D), ds(R * D), ss(T * D);
+    std::vector<double> xs(tile3_stage_elems(K, D, RY, HL + HR)), ds(xs.size()), ss(tile3_s_elems(K, D, RY));
     for (int k = 0; k < EP_N; ++k) ev[k] = 0.0;
     for (int tile = 0; tile < dm.ntiles; ++tile) {
         std::vector<Tile3> th(NT);
@@ -165,11 +165,11 @@ void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_
         const bool edge = (tile * T - HL < 0) || (tile * T + T + HR > dm.N);
         for (int t = 0; t < NT; ++t) {
             if (edge) {
-                if (use_d) tile3_stage<DISC, 0, true, true>(dm, th[t], t, NT);
-                else tile3_stage<DISC, 0, true, false>(dm, th[t], t, NT);
+                if (use_d) tile3_stage<DISC, K, 0, true, true>(dm, th[t], t, NT);
+                else tile3_stage<DISC, K, 0, true, false>(dm, th[t], t, NT);
             } else {
-                if (use_d) tile3_stage<DISC, 0, false, true>(dm, th[t], t, NT);
-                else tile3_stage<DISC, 0, false, false>(dm, th[t], t, NT);
+                if (use_d) tile3_stage<DISC, K, 0, false, true>(dm, th[t], t, NT);
+                else tile3_stage<DISC, K, 0, false, false>(dm, th[t], t, NT);
             }
         }
         for (int t = 0; t < NTH; ++t) tile3_obs<K>(dm, E.pp, th[t], rg[t]);

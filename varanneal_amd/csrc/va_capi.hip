@@ -286,6 +286,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dm.disc = d->disc;
     dm.ld = ((dm.ND + dm.NPest + 15) / 16) * 16;
     pick_eval_geometry(d, dm);
+    dm.nprow = dm.emode == 3 ? dm.ntiles * 4 : dm.ntiles;
     dm.chunk = VEC_CHUNK; dm.nchunks = (dm.ld + VEC_CHUNK - 1) / VEC_CHUNK;
     dm.dt = d->dt_model;
     dm.cme = d->L > 0 ? 1.0 / ((double)dm.L * dm.N_data) : 0.0;
@@ -314,7 +315,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     TRY(h->alloc(&dv.gt, B * ld)); TRY(h->alloc(&dv.d, B * ld));
     TRY(h->alloc(&dv.S, B * m * ld)); TRY(h->alloc(&dv.Y, B * m * ld));
     TRY(h->alloc(&dv.st, B));
-    TRY(h->alloc(&dv.evp, B * dm.ntiles * EP_N));
+    TRY(h->alloc(&dv.evp, B * dm.nprow * EP_N));
     TRY(h->alloc(&dv.upp, B * dm.nchunks * dv.ups));
     TRY(h->alloc(&dv.dpp, B * dm.nchunks * DP_N));
     TRY(h->alloc(&h->d_rf, (size_t)max_beta));

@@ -173,18 +173,21 @@ __global__ __launch_bounds__(256) void k_eval3(const Dev dv)
 
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
     constexpr int KP = EP_GP + RHS::NP;
-    const int D = DC > 0 ? DC : dm.D, T = dm.T, RD = (T + HL + HR) * D;
+    // with D fixed at compile time the whole tile geometry (and every LDS offset) is constant
+    const int D = DC > 0 ? DC : dm.D;
+    const int RY = DC > 0 ? tile2_RY(DC > 0 ? DC : 1) : dm.RY;
+    const int T = RY * K;
+    const int SE = tile3_stage_elems(K, D, RY, HL + HR);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int ty = tid / D, tx = tid - ty * D;
-    const bool active = ty < dm.RY;
+    const bool active = ty < RY;
 
     Tile3 t;
     t.n0 = tile * T; t.ty = ty; t.r0 = t.n0 + ty * K; t.use_d = (phase == PH_LS);
     t.col = make_cols(tx, D);
     t.l = active ? dv.pp.lmap[tx] : -1;
     t.stp = st.stp; t.c = 2.0 * st.rf_scale * dm.cfe;
-    t.xs = smem; t.ds = smem + RD; t.ss = smem + 2 * RD;
-    double *red = smem + 2 * RD + T * D;
+    t.xs = smem; t.ss = smem + SE; t.ds = smem + SE + tile3_s_elems(K, D, RY);
     t.xg = dv.x + (size_t)b * dm.ld; t.dg = dv.d + (size_t)b * dm.ld;
     t.gtg = dv.gt + (size_t)b * dm.ld;
     {   // parameters (same select-chain as tile2_params)
@@ -203,11 +206,11 @@ __global__ __launch_bounds__(256) void k_eval3(const Dev dv)
     acc.clear();
     const bool edge = (t.n0 - HL < 0) || (t.n0 + T + HR > dm.N);     // workgroup-uniform
     if (edge) {
-        if (t.use_d) tile3_stage<DISC, DC, true, true>(dm, t, tid, nt);
-        else tile3_stage<DISC, DC, true, false>(dm, t, tid, nt);
+        if (t.use_d) tile3_stage<DISC, K, DC, true, true>(dm, t, tid, nt);
+        else tile3_stage<DISC, K, DC, true, false>(dm, t, tid, nt);
     } else {
-        if (t.use_d) tile3_stage<DISC, DC, false, true>(dm, t, tid, nt);
-        else tile3_stage<DISC, DC, false, false>(dm, t, tid, nt);
+        if (t.use_d) tile3_stage<DISC, K, DC, false, true>(dm, t, tid, nt);
+        else tile3_stage<DISC, K, DC, false, false>(dm, t, tid, nt);
     }
     if (active) tile3_obs<K>(dm, dv.pp, t, rg);
     __syncthreads();
@@ -221,19 +224,17 @@ __global__ __launch_bounds__(256) void k_eval3(const Dev dv)
         else tile3_grad<RHS, DISC, K, false, DC>(dm, t, rg, acc);
     }
 
-    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    // every wave writes its own partial row (no LDS, no barrier: a __syncthreads here would
+    // also wait for the gradient stores to land); k_ls sums the rows in a fixed order.
+    const int lane = tid & 63, wave = tid >> 6;
+    double out = 0.0;
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
         double v = (k == EP_GMAX) ? wave_max(acc.v[k]) : wave_sum(acc.v[k]);
-        if (lane == 0) red[wave * KP + k] = v;
+        v = __shfl(v, 0, 64);
+        out = (lane == k) ? v : out;
     }
-    __syncthreads();
-    if (tid < KP) {
-        double v = red[tid];
-        for (int ww = 1; ww < nw; ++ww)
-            v = (tid == EP_GMAX) ? fmax(v, red[ww * KP + tid]) : v + red[ww * KP + tid];
-        dv.evp[((size_t)b * dm.ntiles + tile) * EP_N + tid] = v;
-    }
+    if (lane < KP) dv.evp[(((size_t)b * dm.ntiles + tile) * 4 + wave) * EP_N + lane] = out;
 }
 
 size_t eval_lds_bytes(const Dims &dm)
@@ -241,7 +242,8 @@ size_t eval_lds_bytes(const Dims &dm)
     const int HL = dm.disc == DISC_SH ? 2 : 1;
     const int R = dm.T + HL + 1;
     size_t elems;
-    if (dm.emode == 3) elems = (size_t)(2 * R + dm.T) * dm.D;
+    if (dm.emode == 3)
+        elems = (size_t)2 * tile3_stage_elems(dm.maxr, dm.D, dm.RY, HL + 1) + tile3_s_elems(dm.maxr, dm.D, dm.RY);
     else elems = (size_t)((dm.emode == 2 && dm.disc != DISC_SH) ? 2 : 3) * R * dm.D;
     return sizeof(double) * (elems + (256 / 64) * EP_N);
 }
@@ -313,10 +315,10 @@ void launch_eval(const Dev &dv, int rhs, hipStream_t s)
 // reduce the tile partials of seed b: lane k owns column k.  Fixed order -> deterministic.
 __device__ __forceinline__ double reduce_eval_col(const Dev &dv, int b, int k)
 {
-    const double *p = dv.evp + (size_t)b * dv.dm.ntiles * EP_N + k;
+    const double *p = dv.evp + (size_t)b * dv.dm.nprow * EP_N + k;
     double v = 0.0;
-    if (k == EP_GMAX) { for (int t = 0; t < dv.dm.ntiles; ++t) v = fmax(v, p[(size_t)t * EP_N]); }
-    else { for (int t = 0; t < dv.dm.ntiles; ++t) v += p[(size_t)t * EP_N]; }
+    if (k == EP_GMAX) { for (int t = 0; t < dv.dm.nprow; ++t) v = fmax(v, p[(size_t)t * EP_N]); }
+    else { for (int t = 0; t < dv.dm.nprow; ++t) v += p[(size_t)t * EP_N]; }
     return v;
 }
 

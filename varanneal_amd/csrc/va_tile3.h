@@ -2,8 +2,8 @@
 //
 // A workgroup owns T = RY*K consecutive time rows of one seed.  Lane (ty, tx) owns
 // state column tx and the CONTIGUOUS run of K rows r0 = n0 + ty*K .. r0+K-1:
-//   phase A  flat, fully coalesced staging of rows [n0-HL, n0+T+HR) of x (or the
-//            trial point x + stp*d) -- and of d when a line search needs g.d -- into LDS;
+//   phase A  flat, fully coalesced 16-byte staging of rows [n0-HL, n0+T+HR) of x (or
+//            the trial point x + stp*d) -- and of d when a line search needs g.d -- into LDS;
 //   barrier
 //   phase B  each lane pulls its run (+halo rows) of its column and of the stencil's
 //            neighbour columns out of LDS ONCE, evaluates f for K+HL+HR rows, the
@@ -12,10 +12,14 @@
 //   barrier
 //   phase C  J_m^T s_m from the three neighbour columns of s (LDS), measurement term,
 //            gradient store, parameter-gradient / line-search partial sums.
-// Interior tiles run a variant with every row-range predicate compiled out.
-// Instruction count per element is ~4x below the row-strided mapping of va_tile2.h
-// (which recomputes f and re-reads q from LDS); HBM traffic is unchanged: x read
-// once (+halo), grad written once.
+// Interior tiles run a variant with every row-range predicate compiled out; with D
+// fixed at compile time every LDS address is one base register + an immediate.
+//
+// LDS layout: staged row R (0 = row n0-HL) lives at  R*D + P*run(R),  run(R) =
+// (R-HL+K)/K, i.e. P doubles of padding after every K-row run, with P chosen so that
+// (K*D + P) == D (mod 32).  The lanes of a wave then hit LDS double-word banks
+// ty*D + tx + const = linear lane id (mod 32): conflict-free ds_read_b64, where the
+// unpadded layout is 4-way conflicted for D=20, K=8 (measured: 70% of LDS cycles).
 //
 // Arithmetic restated from the reference: see va_core.h.  Shared with tests/cpu_emul.
 #pragma once
@@ -25,18 +29,23 @@ namespace va {
 
 template <int K> struct T3Regs {
     double direct[K], sown[K], xown[K], yv[K], wv[K];
-    unsigned meas;
 };
 
 struct Tile3 {
     int n0, ty, use_d, l, r0;     // r0 = first owned row of this lane
     Cols col;
     double stp, c;
-    double *xs, *ds, *ss;         // LDS: staged x rows [R*D], staged d rows [R*D], s rows [T*D]
+    double *xs, *ds, *ss;         // LDS: staged x, staged d (line search only), s rows
     const double *xg, *dg;
     double *gtg;
     double p[RHS_MAX_NP];
 };
+
+// run padding in doubles: (K*D + P) == D (mod 32), P even when D is even
+VA_HD constexpr int tile3_pad(int K, int D) { return (((1 - K) * D) % 32 + 32) % 32; }
+// doubles of LDS for the staged arrays (x and d) and for s
+VA_HD constexpr int tile3_stage_elems(int K, int D, int RY, int HLR) { return (RY * K + HLR) * D + tile3_pad(K, D) * (RY + 2); }
+VA_HD constexpr int tile3_s_elems(int K, int D, int RY) { return RY * K * D + tile3_pad(K, D) * RY; }
 
 // 16-byte accesses (addresses are even-element offsets of 128-byte aligned rows)
 VA_HD void ld2(const double *p, double &a, double &b)
@@ -58,16 +67,17 @@ VA_HD void st2(double *p, double a, double b)
 }
 
 // phase A: flat staging.  rows outside [0,N) read as 0.  `tid`/`nt` are linear.
-template <int DISC, int DC, bool EDGE, bool USE_D>
+template <int DISC, int K, int DC, bool EDGE, bool USE_D>
 VA_HD void tile3_stage(const Dims &dm, const Tile3 &t, int tid, int nt)
 {
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
     const int D = DC > 0 ? DC : dm.D;
+    const int P = tile3_pad(K, D);
     const long base = (long)(t.n0 - HL) * D;
     const int tot = (dm.T + HL + HR) * D;
+    const double *xsrc = t.xg + base, *dsrc = t.dg + base;
     if ((D & 1) == 0) {
         // rows are 16-byte aligned when D is even: move two doubles per lane per access
-        const double *xsrc = t.xg + base, *dsrc = t.dg + base;
         for (int e = 2 * tid; e < tot; e += 2 * nt) {
             double x0 = 0.0, x1 = 0.0, d0 = 0.0, d1 = 0.0;
             if (!EDGE || (base + e >= 0 && base + e + 1 < dm.ND)) {
@@ -77,32 +87,32 @@ VA_HD void tile3_stage(const Dims &dm, const Tile3 &t, int tid, int nt)
                     x0 = trial(x0, t.stp, d0); x1 = trial(x1, t.stp, d1);
                 }
             }
-            st2(t.xs + e, x0, x1);
-            if (USE_D) st2(t.ds + e, d0, d1);
+            const int a = e + P * ((e / D - HL + K) / K);
+            st2(t.xs + a, x0, x1);
+            if (USE_D) st2(t.ds + a, d0, d1);
         }
     } else {
         for (int e = tid; e < tot; e += nt) {
-            const long gi = base + e;
             double x0 = 0.0, d0 = 0.0;
-            if (gi >= 0 && gi < dm.ND) {
-                x0 = t.xg[gi];
-                if (USE_D) { d0 = t.dg[gi]; x0 = trial(x0, t.stp, d0); }
+            if (!EDGE || (base + e >= 0 && base + e < dm.ND)) {
+                x0 = xsrc[e];
+                if (USE_D) { d0 = dsrc[e]; x0 = trial(x0, t.stp, d0); }
             }
-            t.xs[e] = x0;
-            if (USE_D) t.ds[e] = d0;
+            const int a = e + P * ((e / D - HL + K) / K);
+            t.xs[a] = x0;
+            if (USE_D) t.ds[a] = d0;
         }
     }
 }
 
 // observations of the lane's own rows (issued before the first barrier so that the
-// global loads overlap the staging)
+// global loads overlap the staging).  Unobserved entries get weight 0.
 template <int K>
 VA_HD void tile3_obs(const Dims &dm, const ProblemPtrs &pp, const Tile3 &t, T3Regs<K> &rg)
 {
-    rg.meas = 0u;
     if (dm.nskip == 1) {
         // common case (dt_model == dt_data): every row is an observation time.  Branch-free:
-        // unobserved lanes read entry 0 and get weight 0.
+        // unobserved lanes read entry 0.
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int m = t.r0 + k;
@@ -136,19 +146,19 @@ VA_HD void tile3_obs(const Dims &dm, const ProblemPtrs &pp, const Tile3 &t, T3Re
 }
 
 // phase B: f, residuals, q, direct, s for the lane's run -- registers only.
-// DC > 0 fixes D at compile time: every LDS address becomes base register + immediate.
 template <class RHS, int DISC, int K, bool EDGE, int DC>
 VA_HD void tile3_rows(const Dims &dm, const ProblemPtrs &pp, const Tile3 &t, T3Regs<K> &rg, ThreadAcc &acc)
 {
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, NR = K + HL + HR, NQ = K + HL;
     const int D = DC > 0 ? DC : dm.D, N = dm.N, i = t.col.i;
+    const int P = tile3_pad(K, D);
     const double dt = dm.dt;
-    // staged-row index of the lane's first needed row (r0 - HL): (r0 - n0) rows into the tile
-    const double *xbase = t.xs + (t.r0 - t.n0) * D;
+    // the lane's first needed row r0-HL is staged row ty*K: LDS offset ty*(K*D+P)
+    const double *xbase = t.xs + t.ty * (K * D + P);
     double xo[NR], fo[NR], q[NQ], w[NQ];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        const double *xr = xbase + j * D;
+        const double *xr = xbase + j * D + P * ((j - HL + K) / K);
         xo[j] = xr[i];
         const int row = t.r0 - HL + j;
         if (!EDGE || (row >= 0 && row < N)) fo[j] = RHS::f(xr, t.col, xo[j], t.p);
@@ -193,6 +203,7 @@ VA_HD void tile3_rows(const Dims &dm, const ProblemPtrs &pp, const Tile3 &t, T3R
         if (j >= HL) acc.v[EP_FE] += wr * r;        // rows of this lane's own run
     }
     // direct_m, s_m (same linear combinations as disc_direct_s, on registers)
+    double *sbase = t.ss + t.ty * (K * D + P) + i;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int j = k + HL;
@@ -210,7 +221,7 @@ VA_HD void tile3_rows(const Dims &dm, const ProblemPtrs &pp, const Tile3 &t, T3R
         }
         if (EDGE && t.r0 + k >= N) { direct = 0.0; s = 0.0; }
         rg.direct[k] = direct; rg.sown[k] = s; rg.xown[k] = xo[j];
-        t.ss[(t.r0 - t.n0 + k) * D + i] = s;
+        sbase[k * D] = s;
     }
 }
 
@@ -220,29 +231,35 @@ VA_HD void tile3_grad(const Dims &dm, const Tile3 &t, const T3Regs<K> &rg, Threa
 {
     constexpr int HL = Halo<DISC>::HL;
     const int D = DC > 0 ? DC : dm.D, i = t.col.i;
-    const int lt0 = t.r0 - t.n0;
+    const int P = tile3_pad(K, D);
+    const int runoff = t.ty * (K * D + P);
+    // own rows k = 0..K-1 are staged rows ty*K + HL + k, all in run ty+1
+    const double *xrun = t.xs + runoff + HL * D + P;
+    const double *drun = t.ds + runoff + HL * D + P;
+    const double *srun = t.ss + runoff;
     double dval[K];
     if (t.use_d) {                                  // workgroup-uniform
 #pragma unroll
-        for (int k = 0; k < K; ++k) dval[k] = t.ds[(lt0 + k + HL) * D + i];
+        for (int k = 0; k < K; ++k) dval[k] = drun[k * D + i];
     } else {
 #pragma unroll
         for (int k = 0; k < K; ++k) dval[k] = 0.0;
     }
     const double two_cme = 2.0 * dm.cme;
     double gmax = acc.v[EP_GMAX];
+    double *gout = t.gtg + (long)t.r0 * D + i;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int m = t.r0 + k;
-        const double *sr = t.ss + (lt0 + k) * D;
-        const double *xr = t.xs + (lt0 + k + HL) * D;
+        const double *sr = srun + k * D;
+        const double *xr = xrun + k * D;
         double g = rg.direct[k] + RHS::vjp(xr, t.col, sr[t.col.ip1], sr[t.col.im1], sr[t.col.ip2], rg.sown[k], t.p);
         RHS::pgrad(rg.sown[k], acc.v + EP_GP);
         // measurement term: wv = 0 on unobserved entries, so no branch
-        const double wd = rg.wv[k] * (rg.xown[k] - rg.yv[k]);
-        acc.v[EP_ME] += wd * (rg.xown[k] - rg.yv[k]);
+        const double diff = rg.xown[k] - rg.yv[k];
+        const double wd = rg.wv[k] * diff;
+        acc.v[EP_ME] += wd * diff;
         g += two_cme * wd;
-        if (!EDGE || m < dm.N) t.gtg[(long)m * D + i] = g; else g = 0.0;
+        if (!EDGE || t.r0 + k < dm.N) gout[k * D] = g; else g = 0.0;
         acc.v[EP_GTD] += g * dval[k];
         acc.v[EP_GN2] += g * g;
         const double ag = fabs(g);
