@@ -47,6 +47,7 @@ int setup(const va_problem_desc *d, int T, Emul &E)
         if (m.disc == DISC_SH && (T & 1)) --T;
     }
     m.T = T; m.ntiles = (m.N + T - 1) / T;
+    m.nprow = m.ntiles; m.dbg = 0;
     m.chunk = 1000; m.nchunks = (m.ld + m.chunk - 1) / m.chunk;
     m.dt = d->dt_model; m.cme = 1.0 / ((double)m.L * m.N_data); m.cfe = 1.0 / ((double)m.D * (m.N - 1));
     m.rm = d->rm; m.rf0 = d->rf0;

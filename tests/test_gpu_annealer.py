@@ -1,0 +1,70 @@
+"""GPU: the drop-in Annealer end to end on the device (reference script flow:
+examples/Lorenz96_D20/Lorenz96_anneal.py:75-92) against the golden ladders."""
+import numpy as np
+import pytest
+
+from varanneal_amd import twin, va_ode
+
+pytestmark = pytest.mark.gpu
+OPTS = {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000000, 'maxiter': 1000000}
+
+
+def _run(c, disc, fused, nb=None, **kw):
+    a = va_ode.Annealer()
+    a.set_model(twin.l96, int(c["D"]))
+    a.set_data(c["Y"], t=c["t"])
+    beta = c["beta"] if nb is None else c["beta"][:nb]
+    a.anneal(c["X0"].copy(), c["P0"].copy(), float(c["alpha"]), beta, 4.0, 4e-6, list(c["Lidx"]), [0],
+             dt_model=float(c["t"][1] - c["t"][0]), init_to_data=True, disc=disc, method='L-BFGS-B',
+             opt_args=OPTS, adolcID=0, verbose=False, fused=fused, **kw)
+    return a
+
+
+@pytest.mark.parametrize("name,disc", [("g4_c1_trapezoid_N200", "trapezoid"),
+                                        ("g4_shipped_SH_N161", "SimpsonHermite")])
+def test_reference_script_flow(golden_ladders, name, disc, tmp_path):
+    c = golden_ladders[name]
+    a = _run(c, disc, fused=True)
+    N, D, nb = int(c["N"]), int(c["D"]), len(c["beta"])
+    assert np.all(np.abs(a.A_array[:12] - c["A_array"][:12]) <= 1e-8)
+    assert abs(a.A_array[-1] - c["A_array"][-1]) <= 1e-3 * c["A_array"][-1]
+    assert abs(a.P[0] - c["params"][-1, 0]) <= 2e-3 * abs(c["params"][-1, 0])
+    assert list(a.nit_array[:7]) == list(c["nit"][:7])
+    # the S1 evaluator agrees with the stored results at the final RF
+    A, g = a.A_gradA_taped(a.minpaths[-1])
+    assert abs(A - a.A_array[-1]) <= 1e-12 * A and np.abs(g).max() < 1e-3
+    a.save_paths(str(tmp_path / "p.npy"))
+    assert np.load(str(tmp_path / "p.npy")).shape == (nb, N, D + 1)
+    a.close()
+
+
+def test_stepwise_equals_fused(golden_ladders):
+    c = golden_ladders["g4_c1_trapezoid_N200"]
+    f = _run(c, "trapezoid", fused=True, nb=14)
+    s = _run(c, "trapezoid", fused=False, nb=14)
+    assert np.array_equal(f.A_array, s.A_array) and np.array_equal(f.minpaths, s.minpaths)
+    assert np.array_equal(f.nfev_array, s.nfev_array)
+    f.close(); s.close()
+
+
+def test_bounds_route_uses_device_evaluator(golden_ladders):
+    c = golden_ladders["g4_c1_trapezoid_N200"]
+    bounds = [(-15.0, 15.0)] * 20 + [(6.5, 10.0)]
+    a = _run(c, "trapezoid", fused=None, nb=16, bounds=bounds)
+    assert np.all(a.minpaths[:, -1] >= 6.5 - 1e-12)
+    assert np.all(np.abs(a.A_array[:12] - c["A_array"][:12]) <= 1e-7)   # bounds inactive early on
+    a.close()
+
+
+def test_batched_seeds_independent():
+    D, N, B, nb = 20, 200, 6, 10
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    X0 = np.empty((B, N, D)); P0 = np.empty((B, 1))
+    for b in range(B):
+        X0[b], P0[b] = twin.initial_guess(N, D, b)
+    a = va_ode.Annealer(); a.set_model("lorenz96", D); a.set_data(Y, t=t)
+    a.anneal(X0.copy(), P0.copy(), 1.5, np.arange(nb), 4.0, 4e-6, Lidx, [0], opt_args=OPTS, verbose=False)
+    s = va_ode.Annealer(); s.set_model("lorenz96", D); s.set_data(Y, t=t)
+    s.anneal(X0[4].copy(), P0[4].copy(), 1.5, np.arange(nb), 4.0, 4e-6, Lidx, [0], opt_args=OPTS, verbose=False)
+    assert np.array_equal(a.A_array[4], s.A_array) and np.array_equal(a.minpaths[4], s.minpaths)
+    a.close(); s.close()

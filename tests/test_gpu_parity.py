@@ -33,9 +33,10 @@ def gpu_problem(capi, c, batch=1, **kw):
                         disc=str(c["disc"]), merr_nskip=int(c["merr_nskip"]), **kw)
 
 
-@pytest.mark.parametrize("eval_kernel", [1, 2])
+@pytest.mark.parametrize("eval_kernel", [1, 2, 3])
 def test_all_golden_single_evals(capi, golden_single, eval_kernel):
-    """both tile kernels (1 flat-mapped, 2 column-mapped), auto and tiny tiles"""
+    """all three tile kernels (1 flat-mapped, 2 column-mapped, 3 column-run = production),
+    auto and tiny tiles"""
     worstA = worstG = 0.0
     for name, c in golden_single.items():
         for tile_rows in (0, 6):

@@ -1,0 +1,64 @@
+"""CPU, world_size 2 (gloo): seed sharding + the single all-gather of per-seed result
+tables that closes a multi-GPU run (varanneal_amd/parallel.py).  On the GPU box the
+same code runs with backend "nccl" (RCCL) on device tensors (bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, n_seeds, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from varanneal_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = parallel.seed_range(n_seeds, rank, world)
+    seeds = np.arange(lo, hi)
+    local = {"A": 0.5 + seeds[:, None] * np.ones((1, 4)),                 # (B_loc, nbeta)
+             "pest": np.stack([seeds * 10.0, seeds * 10.0 + 1], 1)[:, :, None] * np.ones((1, 1, 1)),
+             "status": (seeds % 3).astype(np.int32)}
+    out = parallel.gather_tables(local, n_seeds)
+    q.put((rank, {k: v.copy() for k, v in out.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_seeds", [8, 7])          # even split and ragged split
+def test_gather_tables_world2(n_seeds):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_seeds, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    seeds = np.arange(n_seeds)
+    for r in range(world):
+        o = got[r]
+        assert o["A"].shape == (n_seeds, 4) and np.array_equal(o["A"][:, 2], 0.5 + seeds)
+        assert o["pest"].shape == (n_seeds, 2, 1) and np.array_equal(o["pest"][:, 1, 0], seeds * 10.0 + 1)
+        assert o["status"].dtype == np.int32 and np.array_equal(o["status"], seeds % 3)
+
+
+def test_seed_range_partitions_exactly():
+    from varanneal_amd.parallel import seed_range
+    for n in (1, 7, 64, 512):
+        for w in (1, 2, 3, 8):
+            cuts = [seed_range(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in cuts) - min(h - l for l, h in cuts) <= 1

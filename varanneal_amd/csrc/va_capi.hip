@@ -7,6 +7,7 @@
 // the host only polls a device counter of unfinished seeds every few cycles.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -83,7 +84,9 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm)
     if (dm.emode == 3) {
         // column-run kernel: T = RY*K exactly, K rows per lane in {4, 6, 8}
         dm.RY = tile2_RY(D); dm.NT = tile2_threads(D);
-        int K = 6;
+        // longest run (least halo, fewest workgroups) that still gives every CU a workgroup
+        int K = 8;
+        while (K > 4 && (long)d->batch * ((N + dm.RY * K - 1) / (dm.RY * K)) < 256) K -= 2;
         if (d->tile_rows > 0) {
             K = (d->tile_rows + dm.RY - 1) / dm.RY;
             K = K <= 4 ? 4 : (K <= 6 ? 6 : 8);
@@ -287,6 +290,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dm.ld = ((dm.ND + dm.NPest + 15) / 16) * 16;
     pick_eval_geometry(d, dm);
     dm.nprow = dm.emode == 3 ? dm.ntiles * 4 : dm.ntiles;
+    { const char *e = getenv("VA_DEBUG_EVAL"); dm.dbg = e ? atoi(e) : 0; }   // profiling ablations only
     dm.chunk = VEC_CHUNK; dm.nchunks = (dm.ld + VEC_CHUNK - 1) / VEC_CHUNK;
     dm.dt = d->dt_model;
     dm.cme = d->L > 0 ? 1.0 / ((double)dm.L * dm.N_data) : 0.0;

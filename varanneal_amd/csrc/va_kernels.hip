@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256) void k_eval3(const Dev dv)
 
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
     constexpr int KP = EP_GP + RHS::NP;
+    if (dm.dbg & 8) return;              // ablation: launch + dispatch only
     // with D fixed at compile time the whole tile geometry (and every LDS offset) is constant
     const int D = DC > 0 ? DC : dm.D;
     const int RY = DC > 0 ? tile2_RY(DC > 0 ? DC : 1) : dm.RY;
@@ -214,6 +215,12 @@ __global__ __launch_bounds__(256) void k_eval3(const Dev dv)
     }
     if (active) tile3_obs<K>(dm, dv.pp, t, rg);
     __syncthreads();
+    if (dm.dbg & 2) {                    // ablation: copy kernel (stage -> store), no arithmetic
+        if (active && !edge)
+            for (int k = 0; k < K; ++k)
+                t.gtg[(long)(t.r0 + k) * D + tx] = t.xs[ty * (K * D + tile3_pad(K, D)) + (k + HL) * D + tile3_pad(K, D) + tx];
+        return;
+    }
     if (active) {
         if (edge) tile3_rows<RHS, DISC, K, true, DC>(dm, dv.pp, t, rg, acc);
         else tile3_rows<RHS, DISC, K, false, DC>(dm, dv.pp, t, rg, acc);

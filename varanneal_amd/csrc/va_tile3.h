@@ -80,7 +80,8 @@ VA_HD void tile3_stage(const Dims &dm, const Tile3 &t, int tid, int nt)
         // rows are 16-byte aligned when D is even: move two doubles per lane per access
         for (int e = 2 * tid; e < tot; e += 2 * nt) {
             double x0 = 0.0, x1 = 0.0, d0 = 0.0, d1 = 0.0;
-            if (!EDGE || (base + e >= 0 && base + e + 1 < dm.ND)) {
+            if (dm.dbg & 4) { x0 = 1e-3 * e; x1 = 1e-3 * (e + 1); }      // ablation: no global loads
+            else if (!EDGE || (base + e >= 0 && base + e + 1 < dm.ND)) {
                 ld2(xsrc + e, x0, x1);
                 if (USE_D) {
                     ld2(dsrc + e, d0, d1);
@@ -259,7 +260,7 @@ VA_HD void tile3_grad(const Dims &dm, const Tile3 &t, const T3Regs<K> &rg, Threa
         const double wd = rg.wv[k] * diff;
         acc.v[EP_ME] += wd * diff;
         g += two_cme * wd;
-        if (!EDGE || t.r0 + k < dm.N) gout[k * D] = g; else g = 0.0;
+        if (!EDGE || t.r0 + k < dm.N) { if (!(dm.dbg & 1)) gout[k * D] = g; } else g = 0.0;
         acc.v[EP_GTD] += g * dval[k];
         acc.v[EP_GN2] += g * g;
         const double ag = fabs(g);

@@ -1,0 +1,50 @@
+"""Built-in right-hand sides and recognition of a user callable.
+
+The reference's `set_model(f, D)` takes an arbitrary Python callable
+`f(t, x, p)` acting on whole time slices (varanneal/va_ode.py:56-67; called at
+:356, :377-378, :430-432, :454).  The device kernels need `f` and `J^T v` as
+HIP code, so a callable is matched against the built-in registry by probing it
+numerically on random rows.  Generic callables (traced -> generated HIP) are the
+next row of SURVEY.md 8(f); until then an unrecognised `f` raises
+NotImplementedError instead of silently running something else.
+"""
+import numpy as np
+
+
+def lorenz96(t, x, k):
+    """examples/Lorenz96_D20/Lorenz96_anneal.py:15-16"""
+    return np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - x + k
+
+
+# name -> (numpy implementation, number of parameters, minimum D)
+REGISTRY = {"lorenz96": (lorenz96, 1, 4)}
+
+
+def recognise(f, D):
+    """Return the registry name whose output matches `f` on random probes, or None."""
+    if isinstance(f, str):
+        return f if f in REGISTRY else None
+    tag = getattr(f, "va_rhs", None)
+    if tag in REGISTRY:
+        return tag
+    rng = np.random.RandomState(20260101)
+    for name, (impl, NP, Dmin) in REGISTRY.items():
+        if D < Dmin:
+            continue
+        ok = True
+        for _ in range(3):
+            x = rng.randn(6, D)
+            p = 1.0 + rng.rand(NP)
+            t = np.arange(6, dtype=np.float64)
+            try:
+                got = np.asarray(f(t, x, p), dtype=np.float64)
+            except Exception:
+                ok = False
+                break
+            want = impl(t, x, p)
+            if got.shape != want.shape or not np.allclose(got, want, rtol=1e-12, atol=1e-12):
+                ok = False
+                break
+        if ok:
+            return name
+    return None
