@@ -28,8 +28,12 @@ def _worker(rank, world, port, n_seeds, q):
     local = {"A": 0.5 + seeds[:, None] * np.ones((1, 4)),                 # (B_loc, nbeta)
              "pest": np.stack([seeds * 10.0, seeds * 10.0 + 1], 1)[:, :, None] * np.ones((1, 1, 1)),
              "status": (seeds % 3).astype(np.int32)}
-    out = parallel.gather_tables(local, n_seeds)
-    q.put((rank, {k: v.copy() for k, v in out.items()}))
+    try:
+        out = parallel.gather_tables(local, n_seeds)
+        q.put((rank, {k: v.copy() for k, v in out.items()}))
+    except Exception as e:                                  # surface the failure instead of a timeout
+        q.put((rank, {"error": repr(e)}))
+        raise
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,6 +53,7 @@ def test_gather_tables_world2(n_seeds):
     seeds = np.arange(n_seeds)
     for r in range(world):
         o = got[r]
+        assert "error" not in o, o
         assert o["A"].shape == (n_seeds, 4) and np.array_equal(o["A"][:, 2], 0.5 + seeds)
         assert o["pest"].shape == (n_seeds, 2, 1) and np.array_equal(o["pest"][:, 1, 0], seeds * 10.0 + 1)
         assert o["status"].dtype == np.int32 and np.array_equal(o["status"], seeds % 3)

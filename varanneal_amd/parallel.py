@@ -48,9 +48,9 @@ def gather_tables(local, n_seeds, group=None):
     send = torch.from_numpy(buf)
     if use_cuda:
         send = send.cuda()
-    recv = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+    recv = torch.empty((world * maxloc, row), dtype=send.dtype, device=send.device)
     dist.all_gather_into_tensor(recv, send, group=group)        # the single RCCL gather
-    recv = recv.cpu().numpy()
+    recv = recv.cpu().numpy().reshape(world, maxloc, row)
     out = {n: np.empty((n_seeds,) + s, dtype=np.asarray(local[n]).dtype) for n, s in zip(names, shapes)}
     for r in range(world):
         rlo, rhi = seed_range(n_seeds, r, world)
