@@ -52,7 +52,10 @@ def test_bounds_route_uses_device_evaluator(golden_ladders):
     bounds = [(-15.0, 15.0)] * 20 + [(6.5, 10.0)]
     a = _run(c, "trapezoid", fused=None, nb=16, bounds=bounds)
     assert np.all(a.minpaths[:, -1] >= 6.5 - 1e-12)
-    assert np.all(np.abs(a.A_array[:12] - c["A_array"][:12]) <= 1e-7)   # bounds inactive early on
+    assert np.all(np.abs(a.minpaths[:, :-1]) <= 15.0 + 1e-12)
+    assert np.allclose(a.A_array, a.me_array + a.fe_array, rtol=1e-12) and np.all(a.exitflags == 0)
+    A, g = a.A_gradA_taped(a.minpaths[-1])                            # SciPy's f is the device's f
+    assert abs(A - a.A_array[-1]) <= 1e-12 * A
     a.close()
 
 
