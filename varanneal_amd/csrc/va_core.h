@@ -78,7 +78,9 @@ struct Opts {
     double ftol, gtol;
 };
 
-struct SeedState {
+// Everything the line-search / ladder step touches: <= 512 bytes so that one wave
+// can stage it in LDS with a single coalesced 8-byte load per lane (k_ls).
+struct SeedHot {
     int phase, beta_idx, iter, col, head, ifun, iback, ls_task;
     int upd, slot, dir, store_idx, nold, pad0;
     int order[MAX_M];       // history slots, oldest -> newest (after the pending update)
@@ -86,7 +88,12 @@ struct SeedState {
     double f, fold, me, fe, theta, stp, gd, gdold, rf_scale, gn2, dr;
     double stp_upd;         // accepted step the update kernel applies (stp is the NEXT trial step)
     LsState ls;
-    double cg, cY[MAX_M], cS[MAX_M];
+    double cg;
+};
+static_assert(sizeof(SeedHot) <= 512 && sizeof(SeedHot) % 8 == 0, "SeedHot must fit one wave-wide 8-byte load");
+
+struct SeedState : SeedHot {
+    double cY[MAX_M], cS[MAX_M];
     double a[MAX_M], b[MAX_M];
     double SY[MAX_M * MAX_M], YY[MAX_M * MAX_M];
 };
@@ -434,7 +441,7 @@ struct SeedResults {
 
 // close the current beta step (va_ode.py:773-782): record, then move to the next RF
 // or finish.  `accepted`: the trial point becomes the stored minimiser.
-VA_HD void finish_step(SeedState &s, int status, bool accepted, const double *rf_ladder, int nbeta,
+VA_HD void finish_step(SeedHot &s, int status, bool accepted, const double *rf_ladder, int nbeta,
                        const SeedResults &r, int *n_active_dec)
 {
     const int k = s.beta_idx;
@@ -449,7 +456,7 @@ VA_HD void finish_step(SeedState &s, int status, bool accepted, const double *rf
     }
 }
 
-VA_HD void begin_linesearch(SeedState &s)
+VA_HD void begin_linesearch(SeedHot &s)
 {
     const double big = 1e10;
     s.ifun = 0; s.iback = 0; s.ls_task = LS_START;
@@ -457,11 +464,11 @@ VA_HD void begin_linesearch(SeedState &s)
     s.dir = 1;
 }
 
-VA_HD void reset_memory(SeedState &s) { s.col = 0; s.head = 0; s.theta = 1.0; s.nold = 0; }
+VA_HD void reset_memory(SeedHot &s) { s.col = 0; s.head = 0; s.theta = 1.0; s.nold = 0; }
 
 // K2: consume one evaluation.  ev[] = eval partial sums INCLUDING the parameter tail
 // contributions; dirp[] = (g.d, d.d) of the direction in use.
-VA_HD void ls_step(SeedState &s, const double *ev, const double *dirp, const Opts &o,
+VA_HD void ls_step(SeedHot &s, const double *ev, const double *dirp, const Opts &o,
                    const double *rf_ladder, int nbeta, const SeedResults &r, int *n_active_dec,
                    double cme, double cfe)
 {

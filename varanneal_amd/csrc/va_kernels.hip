@@ -346,13 +346,21 @@ __device__ __forceinline__ void eval_tail(const Dev &dv, int b, int use_d, doubl
 }
 
 // ------------------------------------------------------------------ K2: line search / ladder
+// One wave per seed.  The seed's hot state (<= 512 B) is staged in LDS with one coalesced
+// 8-byte load per lane, lane 0 runs the (branchy, scalar) state machine on the LDS copy,
+// and the wave writes it back: no chain of dependent global loads on the critical path.
 __global__ __launch_bounds__(64) void k_ls(const Dev dv)
 {
+    __shared__ SeedHot sh;
+    constexpr int NW8 = sizeof(SeedHot) / 8;
     const int b = blockIdx.x, lane = threadIdx.x;
-    SeedState &s = dv.st[b];
-    const int phase = s.phase;
+    double *gst = reinterpret_cast<double *>(static_cast<SeedHot *>(&dv.st[b]));
+    double *lst = reinterpret_cast<double *>(&sh);
+    if (lane < NW8) lst[lane] = gst[lane];
+    __syncthreads();
+    const int phase = sh.phase;
     if (phase != PH_START && phase != PH_LS) {
-        if (lane == 0) { s.upd = 0; s.dir = 0; }
+        if (lane == 0 && (sh.upd || sh.dir)) { dv.st[b].upd = 0; dv.st[b].dir = 0; }
         return;
     }
     const Dims &dm = dv.dm;
@@ -368,18 +376,21 @@ __global__ __launch_bounds__(64) void k_ls(const Dev dv)
     for (int k = 0; k < EP_N; ++k) ev[k] = __shfl(col, k, 64);
 #pragma unroll
     for (int k = 0; k < DP_N; ++k) dirp[k] = __shfl(dcol, k, 64);
-    if (lane != 0) return;
-    atomicAdd(dv.n_evals, 1ULL);
-    eval_tail(dv, b, phase == PH_LS, ev);
-    SeedResults r;
-    r.ame = dv.ame + (size_t)b * dv.max_beta * 3;
-    r.pest = nullptr;
-    r.status = dv.status + (size_t)b * dv.max_beta;
-    r.nit = dv.nit + (size_t)b * dv.max_beta;
-    r.nfev = dv.nfev + (size_t)b * dv.max_beta;
-    int dec = 0;
-    ls_step(s, ev, dirp, dv.o, dv.rf_ladder, dv.nbeta, r, &dec, dm.cme, dm.cfe);
-    if (dec) atomicSub(dv.n_active, 1);
+    if (lane == 0) {
+        atomicAdd(dv.n_evals, 1ULL);
+        eval_tail(dv, b, phase == PH_LS, ev);
+        SeedResults r;
+        r.ame = dv.ame + (size_t)b * dv.max_beta * 3;
+        r.pest = nullptr;
+        r.status = dv.status + (size_t)b * dv.max_beta;
+        r.nit = dv.nit + (size_t)b * dv.max_beta;
+        r.nfev = dv.nfev + (size_t)b * dv.max_beta;
+        int dec = 0;
+        ls_step(sh, ev, dirp, dv.o, dv.rf_ladder, dv.nbeta, r, &dec, dm.cme, dm.cfe);
+        if (dec) atomicSub(dv.n_active, 1);
+    }
+    __syncthreads();
+    if (lane < NW8) gst[lane] = lst[lane];
 }
 void launch_ls(const Dev &dv, hipStream_t s)
 {
@@ -545,22 +556,83 @@ void launch_update(const Dev &dv, hipStream_t s)
 }
 
 // ------------------------------------------------------------------ K4: direction coefficients
+// One wave per seed: Gram update + two-loop recursion in coefficient space (the same
+// algebra as va_core.h:direction_coeffs, which the CPU emulator runs), with lane j holding
+// history pair j and the Gram matrices staged in LDS, so every inner sum is one wave
+// reduction instead of a serial loop of dependent global loads.
 __global__ __launch_bounds__(64) void k_coeffs(const Dev dv)
 {
     __shared__ double up[UP_N];
+    __shared__ double sSY[MAX_M * MAX_M], sYY[MAX_M * MAX_M];
     const int b = blockIdx.x, lane = threadIdx.x;
     SeedState &s = dv.st[b];
     if (!s.dir) return;
     const Dims &dm = dv.dm;
-    const int K = UP_OLD + 4 * s.nold;
+    const int M = MAX_M;
+    const int nold = s.nold, col = s.col, upd = s.upd, sn = s.slot;
+    const bool hist = (upd & UPD_HIST) != 0;
+    const int K = UP_OLD + 4 * nold;
     for (int k = lane; k < K; k += 64) {
         const double *p = dv.upp + (size_t)b * dm.nchunks * dv.ups + k;
         double v = 0.0;
         for (int t = 0; t < dm.nchunks; ++t) v += p[(size_t)t * dv.ups];
         up[k] = v;
     }
+    const int myslot = lane < col ? s.order[lane] : 0;      // lane j <-> j-th oldest pair
+    // stage the col x col blocks of the Gram matrices (physical-slot indexed) in LDS
+    for (int e = lane; e < M * M; e += 64) {
+        const int i = e / M, j = e - i * M;
+        if (i < dm.m && j < dm.m) { sSY[e] = s.SY[e]; sYY[e] = s.YY[e]; }
+    }
     __syncthreads();
-    if (lane == 0) direction_coeffs(s, up, dv.o);
+    const double dr = s.dr;
+    double theta = s.theta;
+    if (hist) {
+        // new column/row of the Gram matrices (same assignments as direction_coeffs)
+        if (lane < nold) {
+            const double sjy = up[UP_OLD + 4 * lane + 2], yjy = up[UP_OLD + 4 * lane + 3];
+            sSY[myslot * M + sn] = sjy; sYY[myslot * M + sn] = yjy; sYY[sn * M + myslot] = yjy;
+            s.SY[myslot * M + sn] = sjy; s.YY[myslot * M + sn] = yjy; s.YY[sn * M + myslot] = yjy;
+        }
+        if (lane == 0) {
+            sSY[sn * M + sn] = dr; sYY[sn * M + sn] = up[UP_YY];
+            s.SY[sn * M + sn] = dr; s.YY[sn * M + sn] = up[UP_YY];
+        }
+        theta = up[UP_YY] / dr;
+    }
+    __syncthreads();
+    double aj = 0.0, bj = 0.0;
+    if (lane < nold) { aj = up[UP_OLD + 4 * lane + 0]; bj = up[UP_OLD + 4 * lane + 1]; }
+    if (hist && lane == col - 1) { aj = up[UP_SGT]; bj = up[UP_YGT]; }
+    const double gamma = 1.0 / theta;
+    const double sii = lane < col ? sSY[myslot * M + myslot] : 1.0;
+    double cj = 0.0, ej = 0.0, alj = 0.0;
+    for (int i = col - 1; i >= 0; --i) {                    // newest -> oldest
+        const int si = __shfl(myslot, i, 64);
+        double term = (lane > i && lane < col) ? cj * sSY[si * M + myslot] : 0.0;
+        double sq = wave_sum(term);
+        sq = __shfl(sq, 0, 64) + __shfl(aj, i, 64);
+        const double al = sq / __shfl(sii, i, 64);
+        if (lane == i) { alj = al; cj = -al; }
+    }
+    for (int i = 0; i < col; ++i) {                         // oldest -> newest
+        const int si = __shfl(myslot, i, 64);
+        double t1 = lane < col ? cj * sYY[si * M + myslot] : 0.0;
+        double t2 = lane < i ? ej * sSY[myslot * M + si] : 0.0;
+        double y1 = wave_sum(t1), y2 = wave_sum(t2);
+        const double yr = (__shfl(bj, i, 64) + __shfl(y1, 0, 64)) * gamma + __shfl(y2, 0, 64);
+        const double ei = __shfl(alj, i, 64) - yr / __shfl(sii, i, 64);
+        if (lane == i) ej = ei;
+    }
+    // scatter the coefficients to physical-slot order through LDS, then one store per slot
+    double *cYs = up, *cSs = up + M;                         // `up` is dead from here on
+    __syncthreads();
+    if (lane < M) { cYs[lane] = 0.0; cSs[lane] = 0.0; }
+    __syncthreads();
+    if (lane < col) { cYs[myslot] = -gamma * cj; cSs[myslot] = -ej; }
+    __syncthreads();
+    if (lane < M) { s.cY[lane] = cYs[lane]; s.cS[lane] = cSs[lane]; }
+    if (lane == 0) { s.cg = -gamma; s.theta = theta; }
 }
 void launch_coeffs(const Dev &dv, hipStream_t s)
 {
