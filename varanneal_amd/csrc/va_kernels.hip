@@ -319,14 +319,38 @@ void launch_eval(const Dev &dv, int rhs, hipStream_t s)
     }
 }
 
-// reduce the tile partials of seed b: lane k owns column k.  Fixed order -> deterministic.
-__device__ __forceinline__ double reduce_eval_col(const Dev &dv, int b, int k)
+// Sum (or max) rows r0, r0+rstep, ... of one column of a partial table.  Loads are issued
+// eight at a time before any is consumed (a plain `v += p[t]` loop serialises on memory
+// latency: 44 rows x ~0.4 us was most of k_ls).  Fixed order -> deterministic.
+__device__ __forceinline__ double col_reduce(const double *p, int nrows, int stride, int r0, int rstep, bool is_max)
 {
-    const double *p = dv.evp + (size_t)b * dv.dm.nprow * EP_N + k;
     double v = 0.0;
-    if (k == EP_GMAX) { for (int t = 0; t < dv.dm.nprow; ++t) v = fmax(v, p[(size_t)t * EP_N]); }
-    else { for (int t = 0; t < dv.dm.nprow; ++t) v += p[(size_t)t * EP_N]; }
+    for (int t0 = r0; t0 < nrows; t0 += 8 * rstep) {
+        double tmp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + u * rstep;
+            tmp[u] = t < nrows ? p[(size_t)t * stride] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v = is_max ? fmax(v, tmp[u]) : v + tmp[u];
+    }
     return v;
+}
+
+// reduce the eval partial rows of seed b with the whole wave: lane = (row group r, column k),
+// 4 row groups x 16 columns; returns the column totals broadcast into ev[].
+__device__ __forceinline__ void reduce_eval(const Dev &dv, int b, int lane, double *ev)
+{
+    const int k = lane & 15, r = lane >> 4;
+    double v = 0.0;
+    if (k < EP_N) v = col_reduce(dv.evp + (size_t)b * dv.dm.nprow * EP_N + k, dv.dm.nprow, EP_N, r, 4, k == EP_GMAX);
+    // combine the 4 row groups (lanes k, k+16, k+32, k+48) in a fixed order
+    const double v1 = __shfl(v, k + 16, 64), v2 = __shfl(v, k + 32, 64), v3 = __shfl(v, k + 48, 64);
+    const double v0 = __shfl(v, k, 64);
+    const double tot = (k == EP_GMAX) ? fmax(fmax(v0, v1), fmax(v2, v3)) : ((v0 + v1) + (v2 + v3));
+#pragma unroll
+    for (int c = 0; c < EP_N; ++c) ev[c] = __shfl(tot, c, 64);
 }
 
 // parameter tail of grad A (sum over tiles of the per-tile parameter partials) and its
@@ -364,18 +388,16 @@ __global__ __launch_bounds__(64) void k_ls(const Dev dv)
         return;
     }
     const Dims &dm = dv.dm;
-    double col = (lane < EP_N) ? reduce_eval_col(dv, b, lane) : 0.0;
-    // direction partials (g.d, d.d) left by k_direction
-    double dcol = 0.0;
-    if (lane < DP_N) {
-        const double *p = dv.dpp + (size_t)b * dm.nchunks * DP_N + lane;
-        for (int t = 0; t < dm.nchunks; ++t) dcol += p[(size_t)t * DP_N];
-    }
     double ev[EP_N], dirp[DP_N];
+    reduce_eval(dv, b, lane, ev);
+    {   // direction partials (g.d, d.d) left by k_direction: lane = (row group, column), 32 x 2
+        const int k = lane & 1, r = lane >> 1;
+        double v = col_reduce(dv.dpp + (size_t)b * dm.nchunks * DP_N + k, dm.nchunks, DP_N, r, 32, false);
 #pragma unroll
-    for (int k = 0; k < EP_N; ++k) ev[k] = __shfl(col, k, 64);
+        for (int o = 32; o >= 2; o >>= 1) v += __shfl_down(v, o, 64);     // lanes 0 and 1 hold the totals
 #pragma unroll
-    for (int k = 0; k < DP_N; ++k) dirp[k] = __shfl(dcol, k, 64);
+        for (int c = 0; c < DP_N; ++c) dirp[c] = __shfl(v, c, 64);
+    }
     if (lane == 0) {
         atomicAdd(dv.n_evals, 1ULL);
         eval_tail(dv, b, phase == PH_LS, ev);
@@ -401,10 +423,8 @@ void launch_ls(const Dev &dv, hipStream_t s)
 __global__ __launch_bounds__(64) void k_finalize_eval(const Dev dv)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
-    double col = (lane < EP_N) ? reduce_eval_col(dv, b, lane) : 0.0;
     double ev[EP_N];
-#pragma unroll
-    for (int k = 0; k < EP_N; ++k) ev[k] = __shfl(col, k, 64);
+    reduce_eval(dv, b, lane, ev);
     if (lane != 0) return;
     eval_tail(dv, b, 0, ev);
     const double me = ev[EP_ME] * dv.dm.cme, fe = ev[EP_FE] * dv.dm.cfe * dv.st[b].rf_scale;
@@ -572,12 +592,8 @@ __global__ __launch_bounds__(64) void k_coeffs(const Dev dv)
     const int nold = s.nold, col = s.col, upd = s.upd, sn = s.slot;
     const bool hist = (upd & UPD_HIST) != 0;
     const int K = UP_OLD + 4 * nold;
-    for (int k = lane; k < K; k += 64) {
-        const double *p = dv.upp + (size_t)b * dm.nchunks * dv.ups + k;
-        double v = 0.0;
-        for (int t = 0; t < dm.nchunks; ++t) v += p[(size_t)t * dv.ups];
-        up[k] = v;
-    }
+    for (int k = lane; k < K; k += 64)
+        up[k] = col_reduce(dv.upp + (size_t)b * dm.nchunks * dv.ups + k, dm.nchunks, dv.ups, 0, 1, false);
     const int myslot = lane < col ? s.order[lane] : 0;      // lane j <-> j-th oldest pair
     // stage the col x col blocks of the Gram matrices (physical-slot indexed) in LDS
     for (int e = lane; e < M * M; e += 64) {
