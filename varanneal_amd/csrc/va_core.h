@@ -546,11 +546,22 @@ VA_HD void ls_step(SeedHot &s, const double *ev, const double *dirp, const Opts 
 }
 
 // K4: Gram update + two-loop recursion carried out in coefficient space.
-// up[] = update-kernel dot products (UP_* layout, old slots in s.order[0..nold)).
+// up[] = update-kernel dot products (UP_* layout, old slots in order[0..nold)).
 // Produces d = cg*g + sum_j cY[slot]*Y[slot] + cS[slot]*S[slot].
-VA_HD void direction_coeffs(SeedState &s, const double *up, const Opts &o)
+// Works on a view so that the device can run it on LDS copies (k_coeffs) and the
+// host/emulator on the SeedState itself.
+struct CoefView {
+    int upd, slot, nold, col;
+    const int *order;
+    double dr;
+    double *theta, *cg;
+    double *SY, *YY;            // [MAX_M*MAX_M], physical-slot indexed
+    double *a, *b, *cY, *cS;    // [MAX_M]
+    double *c, *e, *al;         // [MAX_M] work arrays
+};
+
+VA_HD void direction_coeffs_view(const CoefView &s, const double *up)
 {
-    (void)o;
     const int M = MAX_M;
     const bool hist = (s.upd & UPD_HIST) != 0;
     const int nold = s.nold, col = s.col;
@@ -563,15 +574,15 @@ VA_HD void direction_coeffs(SeedState &s, const double *up, const Opts &o)
         }
         s.SY[sn * M + sn] = s.dr;                                // s.y as the line search saw it
         s.YY[sn * M + sn] = up[UP_YY];
-        s.theta = up[UP_YY] / s.dr;
+        *s.theta = up[UP_YY] / s.dr;
     }
     for (int j = 0; j < nold; ++j) {
         s.a[j] = up[UP_OLD + 4 * j + 0];                         // S_j . g
         s.b[j] = up[UP_OLD + 4 * j + 1];                         // Y_j . g
     }
     if (hist) { s.a[col - 1] = up[UP_SGT]; s.b[col - 1] = up[UP_YGT]; }
-    const double gamma = 1.0 / s.theta;
-    double c[MAX_M], e[MAX_M], al[MAX_M];
+    const double gamma = 1.0 / *s.theta;
+    double *c = s.c, *e = s.e, *al = s.al;
     for (int j = 0; j < col; ++j) { c[j] = 0.0; e[j] = 0.0; }
     for (int i = col - 1; i >= 0; --i) {                         // newest -> oldest
         const int si = s.order[i];
@@ -588,9 +599,20 @@ VA_HD void direction_coeffs(SeedState &s, const double *up, const Opts &o)
         for (int j = 0; j < i; ++j) yr += e[j] * s.SY[s.order[j] * M + si];
         e[i] = al[i] - yr / s.SY[si * M + si];
     }
-    s.cg = -gamma;
+    *s.cg = -gamma;
     for (int j = 0; j < MAX_M; ++j) { s.cY[j] = 0.0; s.cS[j] = 0.0; }
     for (int j = 0; j < col; ++j) { s.cY[s.order[j]] = -gamma * c[j]; s.cS[s.order[j]] = -e[j]; }
+}
+
+VA_HD void direction_coeffs(SeedState &s, const double *up, const Opts &o)
+{
+    (void)o;
+    double c[MAX_M], e[MAX_M], al[MAX_M];
+    CoefView v;
+    v.upd = s.upd; v.slot = s.slot; v.nold = s.nold; v.col = s.col; v.order = s.order; v.dr = s.dr;
+    v.theta = &s.theta; v.cg = &s.cg; v.SY = s.SY; v.YY = s.YY; v.a = s.a; v.b = s.b;
+    v.cY = s.cY; v.cS = s.cS; v.c = c; v.e = e; v.al = al;
+    direction_coeffs_view(v, up);
 }
 
 }  // namespace va

@@ -576,79 +576,64 @@ void launch_update(const Dev &dv, hipStream_t s)
 }
 
 // ------------------------------------------------------------------ K4: direction coefficients
-// One wave per seed: Gram update + two-loop recursion in coefficient space (the same
-// algebra as va_core.h:direction_coeffs, which the CPU emulator runs), with lane j holding
-// history pair j and the Gram matrices staged in LDS, so every inner sum is one wave
-// reduction instead of a serial loop of dependent global loads.
+// One wave per seed: Gram update + two-loop recursion in coefficient space
+// (va_core.h: direction_coeffs_view -- the code the CPU emulator also runs).  Everything it
+// touches is staged in LDS by the whole wave first, so the O(m^2) scalar recursion runs on
+// LDS operands instead of a chain of dependent global loads; results go back coalesced.
 __global__ __launch_bounds__(64) void k_coeffs(const Dev dv)
 {
     __shared__ double up[UP_N];
     __shared__ double sSY[MAX_M * MAX_M], sYY[MAX_M * MAX_M];
+    __shared__ double wk[7 * MAX_M];                      // a, b, cY, cS, c, e, al
+    __shared__ int sorder[MAX_M];
+    __shared__ double sc[2];                              // theta, cg
     const int b = blockIdx.x, lane = threadIdx.x;
     SeedState &s = dv.st[b];
     if (!s.dir) return;
     const Dims &dm = dv.dm;
-    const int M = MAX_M;
-    const int nold = s.nold, col = s.col, upd = s.upd, sn = s.slot;
-    const bool hist = (upd & UPD_HIST) != 0;
+    const int M = MAX_M, m = dm.m;
+    const int nold = s.nold;
     const int K = UP_OLD + 4 * nold;
     for (int k = lane; k < K; k += 64)
         up[k] = col_reduce(dv.upp + (size_t)b * dm.nchunks * dv.ups + k, dm.nchunks, dv.ups, 0, 1, false);
-    const int myslot = lane < col ? s.order[lane] : 0;      // lane j <-> j-th oldest pair
-    // stage the col x col blocks of the Gram matrices (physical-slot indexed) in LDS
-    for (int e = lane; e < M * M; e += 64) {
-        const int i = e / M, j = e - i * M;
-        if (i < dm.m && j < dm.m) { sSY[e] = s.SY[e]; sYY[e] = s.YY[e]; }
-    }
-    __syncthreads();
-    const double dr = s.dr;
-    double theta = s.theta;
-    if (hist) {
-        // new column/row of the Gram matrices (same assignments as direction_coeffs)
-        if (lane < nold) {
-            const double sjy = up[UP_OLD + 4 * lane + 2], yjy = up[UP_OLD + 4 * lane + 3];
-            sSY[myslot * M + sn] = sjy; sYY[myslot * M + sn] = yjy; sYY[sn * M + myslot] = yjy;
-            s.SY[myslot * M + sn] = sjy; s.YY[myslot * M + sn] = yjy; s.YY[sn * M + myslot] = yjy;
+    if (lane < M) sorder[lane] = s.order[lane];
+    {   // the m x m blocks of the Gram matrices: two independent loads per lane per pass
+        double t0[4], t1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = lane + 64 * u;
+            const int i = e / m, j = e - i * m;
+            t0[u] = e < m * m ? s.SY[i * M + j] : 0.0;
+            t1[u] = e < m * m ? s.YY[i * M + j] : 0.0;
         }
-        if (lane == 0) {
-            sSY[sn * M + sn] = dr; sYY[sn * M + sn] = up[UP_YY];
-            s.SY[sn * M + sn] = dr; s.YY[sn * M + sn] = up[UP_YY];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = lane + 64 * u;
+            const int i = e / m, j = e - i * m;
+            if (e < m * m) { sSY[i * M + j] = t0[u]; sYY[i * M + j] = t1[u]; }
         }
-        theta = up[UP_YY] / dr;
+        for (int e = lane + 256; e < m * m; e += 64) {    // m > 16 only
+            const int i = e / m, j = e - i * m;
+            sSY[i * M + j] = s.SY[i * M + j]; sYY[i * M + j] = s.YY[i * M + j];
+        }
+    }
+    if (lane == 0) { sc[0] = s.theta; sc[1] = s.cg; }
+    __syncthreads();
+    if (lane == 0) {
+        CoefView v;
+        v.upd = s.upd; v.slot = s.slot; v.nold = nold; v.col = s.col; v.order = sorder; v.dr = s.dr;
+        v.theta = &sc[0]; v.cg = &sc[1]; v.SY = sSY; v.YY = sYY;
+        v.a = wk; v.b = wk + M; v.cY = wk + 2 * M; v.cS = wk + 3 * M;
+        v.c = wk + 4 * M; v.e = wk + 5 * M; v.al = wk + 6 * M;
+        direction_coeffs_view(v, up);
     }
     __syncthreads();
-    double aj = 0.0, bj = 0.0;
-    if (lane < nold) { aj = up[UP_OLD + 4 * lane + 0]; bj = up[UP_OLD + 4 * lane + 1]; }
-    if (hist && lane == col - 1) { aj = up[UP_SGT]; bj = up[UP_YGT]; }
-    const double gamma = 1.0 / theta;
-    const double sii = lane < col ? sSY[myslot * M + myslot] : 1.0;
-    double cj = 0.0, ej = 0.0, alj = 0.0;
-    for (int i = col - 1; i >= 0; --i) {                    // newest -> oldest
-        const int si = __shfl(myslot, i, 64);
-        double term = (lane > i && lane < col) ? cj * sSY[si * M + myslot] : 0.0;
-        double sq = wave_sum(term);
-        sq = __shfl(sq, 0, 64) + __shfl(aj, i, 64);
-        const double al = sq / __shfl(sii, i, 64);
-        if (lane == i) { alj = al; cj = -al; }
+    for (int e = lane; e < m * m; e += 64) {
+        const int i = e / m, j = e - i * m;
+        s.SY[i * M + j] = sSY[i * M + j]; s.YY[i * M + j] = sYY[i * M + j];
     }
-    for (int i = 0; i < col; ++i) {                         // oldest -> newest
-        const int si = __shfl(myslot, i, 64);
-        double t1 = lane < col ? cj * sYY[si * M + myslot] : 0.0;
-        double t2 = lane < i ? ej * sSY[myslot * M + si] : 0.0;
-        double y1 = wave_sum(t1), y2 = wave_sum(t2);
-        const double yr = (__shfl(bj, i, 64) + __shfl(y1, 0, 64)) * gamma + __shfl(y2, 0, 64);
-        const double ei = __shfl(alj, i, 64) - yr / __shfl(sii, i, 64);
-        if (lane == i) ej = ei;
-    }
-    // scatter the coefficients to physical-slot order through LDS, then one store per slot
-    double *cYs = up, *cSs = up + M;                         // `up` is dead from here on
-    __syncthreads();
-    if (lane < M) { cYs[lane] = 0.0; cSs[lane] = 0.0; }
-    __syncthreads();
-    if (lane < col) { cYs[myslot] = -gamma * cj; cSs[myslot] = -ej; }
-    __syncthreads();
-    if (lane < M) { s.cY[lane] = cYs[lane]; s.cS[lane] = cSs[lane]; }
-    if (lane == 0) { s.cg = -gamma; s.theta = theta; }
+    if (lane < M) { s.cY[lane] = wk[2 * M + lane]; s.cS[lane] = wk[3 * M + lane]; }
+    if (lane == 0) { s.theta = sc[0]; s.cg = sc[1]; }
 }
 void launch_coeffs(const Dev &dv, hipStream_t s)
 {
