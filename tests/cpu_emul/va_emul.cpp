@@ -48,6 +48,8 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     }
     m.T = T; m.ntiles = (m.N + T - 1) / T;
     m.nprow = m.ntiles; m.dbg = 0;
+    m.obsmask = 0ull;
+    if (m.D <= 64) for (int l = 0; l < d->L; ++l) m.obsmask |= 1ull << d->Lidx[l];
     m.chunk = 1000; m.nchunks = (m.ld + m.chunk - 1) / m.chunk;
     m.dt = d->dt_model; m.cme = 1.0 / ((double)m.L * m.N_data); m.cfe = 1.0 / ((double)m.D * (m.N - 1));
     m.rm = d->rm; m.rf0 = d->rf0;
@@ -137,15 +139,15 @@ void eval_seed2(const Emul &E, int b, const double *x, const double *d, int use_
     }
 }
 
-// K1, column-run variant (va_tile3.h)
+// K1, column-run variant (va_tile3.h): ghosted + padded LDS layout, split staging
 template <class RHS, int DISC, int K>
 void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
                 double rf_scale, double *gt, double *ev)
 {
     const Dims &dm = E.dm;
-    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
-    const int D = dm.D, T = dm.T, R = T + HL + HR, RY = dm.RY, NTH = D * RY, NT = dm.NT;
-    std::vector<double> xs(tile3_stage_elems(K, D, RY, HL + HR)), ds(xs.size()), ss(tile3_s_elems(K, D, RY));
+    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, G = RHS::GHOST, NS = K / 2 + 1;
+    const int D = dm.D, T = dm.T, RY = dm.RY, NTH = D * RY, NT = dm.NT;
+    std::vector<double> xs(tile3_stage_elems(K, D, G, RY, HL + HR)), ds(xs.size()), ss(tile3_s_elems(K, D, G, RY));
     for (int k = 0; k < EP_N; ++k) ev[k] = 0.0;
     for (int tile = 0; tile < dm.ntiles; ++tile) {
         std::vector<Tile3> th(NT);
@@ -153,24 +155,32 @@ void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_
         std::vector<ThreadAcc> acc(NT);
         for (int t = 0; t < NT; ++t) {
             Tile3 &c = th[t];
-            c.n0 = tile * T; c.ty = t / D; c.r0 = c.n0 + c.ty * K; c.use_d = use_d;
-            c.col = make_cols(t % D, D); c.l = E.lmap[t % D];
+            c.n0 = tile * T; c.ty = t / D; c.tx = t % D; c.r0 = c.n0 + c.ty * K; c.use_d = use_d;
+            c.l = obs_index(dm.obsmask, c.tx);
             c.stp = stp; c.c = 2.0 * rf_scale * dm.cfe;
             c.xs = xs.data(); c.ds = ds.data(); c.ss = ss.data();
             c.xg = x; c.dg = d; c.gtg = gt;
             Tile2 tmp; tmp.xg = x; tmp.dg = d; tmp.use_d = use_d; tmp.stp = stp;
-            tile2_params<RHS>(dm, E.pp, b, tmp);
+            tile2_params<RhsL96c>(dm, E.pp, b, tmp);
             for (int k = 0; k < RHS_MAX_NP; ++k) c.p[k] = tmp.p[k];
             acc[t].clear();
         }
         const bool edge = (tile * T - HL < 0) || (tile * T + T + HR > dm.N);
         for (int t = 0; t < NT; ++t) {
-            if (edge) {
-                if (use_d) tile3_stage<DISC, K, 0, true, true>(dm, th[t], t, NT);
-                else tile3_stage<DISC, K, 0, true, false>(dm, th[t], t, NT);
+            if ((D & 1) == 0) {
+                double xr[NS][2];
+                if (edge) tile3_stage_load<DISC, K, 0, true, NS>(dm, th[t].n0, x, t, NT, xr);
+                else tile3_stage_load<DISC, K, 0, false, NS>(dm, th[t].n0, x, t, NT, xr);
+                if (edge) {
+                    if (use_d) tile3_stage_store<RHS, DISC, K, 0, true, true, NS>(dm, th[t], t, NT, xr);
+                    else tile3_stage_store<RHS, DISC, K, 0, true, false, NS>(dm, th[t], t, NT, xr);
+                } else {
+                    if (use_d) tile3_stage_store<RHS, DISC, K, 0, false, true, NS>(dm, th[t], t, NT, xr);
+                    else tile3_stage_store<RHS, DISC, K, 0, false, false, NS>(dm, th[t], t, NT, xr);
+                }
             } else {
-                if (use_d) tile3_stage<DISC, K, 0, false, true>(dm, th[t], t, NT);
-                else tile3_stage<DISC, K, 0, false, false>(dm, th[t], t, NT);
+                if (use_d) tile3_stage_odd<RHS, DISC, K, 0, true, true>(dm, th[t], t, NT);
+                else tile3_stage_odd<RHS, DISC, K, 0, true, false>(dm, th[t], t, NT);
             }
         }
         for (int t = 0; t < NTH; ++t) tile3_obs<K>(dm, E.pp, th[t], rg[t]);
@@ -195,9 +205,9 @@ void eval_seed_rhs(const Emul &E, int b, const double *x, const double *d, int u
                    double rf_scale, double *gt, double *ev)
 {
     if (E.dm.emode == 3) {
-        if (E.dm.maxr == 4) eval_seed3<RhsL96c, DISC, 4>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
-        else if (E.dm.maxr == 6) eval_seed3<RhsL96c, DISC, 6>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
-        else eval_seed3<RhsL96c, DISC, 8>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        if (E.dm.maxr == 4) eval_seed3<RhsL96g, DISC, 4>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 6) eval_seed3<RhsL96g, DISC, 6>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else eval_seed3<RhsL96g, DISC, 8>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
     } else if (E.dm.emode == 2) eval_seed2<RhsL96c, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
     else eval_seed<RhsL96, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
 }

@@ -92,8 +92,8 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm)
             K = K <= 4 ? 4 : (K <= 6 ? 6 : 8);
         }
         for (;;) {                                        // shrink until the staging arrays fit in LDS
-            const int T = dm.RY * K, R = T + HLR;
-            if (sizeof(double) * (size_t)(2 * R + T) * D <= 60 * 1024 || K == 4) break;
+            const size_t elems = (size_t)2 * tile3_stage_elems(K, D, 2, dm.RY, HLR) + tile3_s_elems(K, D, 2, dm.RY);
+            if (sizeof(double) * elems <= 60 * 1024 || K == 4) break;
             K -= 2;
         }
         dm.maxr = K; dm.T = dm.RY * K;
@@ -290,6 +290,8 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dm.ld = ((dm.ND + dm.NPest + 15) / 16) * 16;
     pick_eval_geometry(d, dm);
     dm.nprow = dm.emode == 3 ? dm.ntiles * 4 : dm.ntiles;
+    dm.obsmask = 0ull;
+    if (dm.D <= 64) for (int l = 0; l < d->L; ++l) dm.obsmask |= 1ull << d->Lidx[l];
     { const char *e = getenv("VA_DEBUG_EVAL"); dm.dbg = e ? atoi(e) : 0; }   // profiling ablations only
     dm.chunk = VEC_CHUNK; dm.nchunks = (dm.ld + VEC_CHUNK - 1) / VEC_CHUNK;
     dm.dt = d->dt_model;

@@ -167,29 +167,41 @@ __global__ __launch_bounds__(256) void k_eval3(const Dev dv)
     const int w = xcd_swizzle(blockIdx.x, nwork);
     if (w >= nwork) return;
     const int b = w / dm.ntiles, tile = w - b * dm.ntiles;
-    const SeedState &st = dv.st[b];
-    const int phase = st.phase;
-    if (phase != PH_START && phase != PH_LS) return;
 
-    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
+    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, G = RHS::GHOST;
     constexpr int KP = EP_GP + RHS::NP;
-    if (dm.dbg & 8) return;              // ablation: launch + dispatch only
+    constexpr int NS = K / 2 + 1;        // staged double2 per lane: ceil((RY*K+3)*D / (2*NT)) <= K/2+1
     // with D fixed at compile time the whole tile geometry (and every LDS offset) is constant
     const int D = DC > 0 ? DC : dm.D;
     const int RY = DC > 0 ? tile2_RY(DC > 0 ? DC : 1) : dm.RY;
     const int T = RY * K;
-    const int SE = tile3_stage_elems(K, D, RY, HL + HR);
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int n0 = tile * T;
+    const bool edge = (n0 - HL < 0) || (n0 + T + HR > dm.N);          // workgroup-uniform
+    const bool evenD = (D & 1) == 0;
+    const double *xg = dv.x + (size_t)b * dm.ld;
+
+    // phase A step 1: x loads in flight before anything else is waited for
+    double xr[NS][2];
+    if (evenD) {
+        if (edge) tile3_stage_load<DISC, K, DC, true, NS>(dm, n0, xg, tid, nt, xr);
+        else tile3_stage_load<DISC, K, DC, false, NS>(dm, n0, xg, tid, nt, xr);
+    }
+
+    const SeedState &st = dv.st[b];
+    const int phase = st.phase;
+    if (phase != PH_START && phase != PH_LS) return;
+    if (dm.dbg & 8) return;              // ablation: launch + dispatch only
+
     const int ty = tid / D, tx = tid - ty * D;
     const bool active = ty < RY;
-
+    const int SE = tile3_stage_elems(K, D, G, RY, HL + HR);
     Tile3 t;
-    t.n0 = tile * T; t.ty = ty; t.r0 = t.n0 + ty * K; t.use_d = (phase == PH_LS);
-    t.col = make_cols(tx, D);
-    t.l = active ? dv.pp.lmap[tx] : -1;
+    t.n0 = n0; t.ty = ty; t.tx = tx; t.r0 = n0 + ty * K; t.use_d = (phase == PH_LS);
+    t.l = active ? obs_index(dm.obsmask, tx) : -1;
     t.stp = st.stp; t.c = 2.0 * st.rf_scale * dm.cfe;
-    t.xs = smem; t.ss = smem + SE; t.ds = smem + SE + tile3_s_elems(K, D, RY);
-    t.xg = dv.x + (size_t)b * dm.ld; t.dg = dv.d + (size_t)b * dm.ld;
+    t.xs = smem; t.ss = smem + SE; t.ds = smem + SE + tile3_s_elems(K, D, G, RY);
+    t.xg = xg; t.dg = dv.d + (size_t)b * dm.ld;
     t.gtg = dv.gt + (size_t)b * dm.ld;
     {   // parameters (same select-chain as tile2_params)
 #pragma unroll
@@ -205,20 +217,25 @@ __global__ __launch_bounds__(256) void k_eval3(const Dev dv)
     T3Regs<K> rg;
     ThreadAcc acc;
     acc.clear();
-    const bool edge = (t.n0 - HL < 0) || (t.n0 + T + HR > dm.N);     // workgroup-uniform
-    if (edge) {
-        if (t.use_d) tile3_stage<DISC, K, DC, true, true>(dm, t, tid, nt);
-        else tile3_stage<DISC, K, DC, true, false>(dm, t, tid, nt);
-    } else {
-        if (t.use_d) tile3_stage<DISC, K, DC, false, true>(dm, t, tid, nt);
-        else tile3_stage<DISC, K, DC, false, false>(dm, t, tid, nt);
-    }
     if (active) tile3_obs<K>(dm, dv.pp, t, rg);
+    // phase A step 2: (+ d for a line-search point) -> LDS incl. ghost columns
+    if (evenD) {
+        if (edge) {
+            if (t.use_d) tile3_stage_store<RHS, DISC, K, DC, true, true, NS>(dm, t, tid, nt, xr);
+            else tile3_stage_store<RHS, DISC, K, DC, true, false, NS>(dm, t, tid, nt, xr);
+        } else {
+            if (t.use_d) tile3_stage_store<RHS, DISC, K, DC, false, true, NS>(dm, t, tid, nt, xr);
+            else tile3_stage_store<RHS, DISC, K, DC, false, false, NS>(dm, t, tid, nt, xr);
+        }
+    } else {
+        if (t.use_d) tile3_stage_odd<RHS, DISC, K, DC, true, true>(dm, t, tid, nt);
+        else tile3_stage_odd<RHS, DISC, K, DC, true, false>(dm, t, tid, nt);
+    }
     __syncthreads();
     if (dm.dbg & 2) {                    // ablation: copy kernel (stage -> store), no arithmetic
         if (active && !edge)
             for (int k = 0; k < K; ++k)
-                t.gtg[(long)(t.r0 + k) * D + tx] = t.xs[ty * (K * D + tile3_pad(K, D)) + (k + HL) * D + tile3_pad(K, D) + tx];
+                t.gtg[(long)(t.r0 + k) * D + tx] = t.xs[tile3_addr(ty * K + HL + k, tx, K, D, G, HL)];
         return;
     }
     if (active) {
@@ -250,7 +267,7 @@ size_t eval_lds_bytes(const Dims &dm)
     const int R = dm.T + HL + 1;
     size_t elems;
     if (dm.emode == 3)
-        elems = (size_t)2 * tile3_stage_elems(dm.maxr, dm.D, dm.RY, HL + 1) + tile3_s_elems(dm.maxr, dm.D, dm.RY);
+        elems = (size_t)2 * tile3_stage_elems(dm.maxr, dm.D, 2, dm.RY, HL + 1) + tile3_s_elems(dm.maxr, dm.D, 2, dm.RY);
     else elems = (size_t)((dm.emode == 2 && dm.disc != DISC_SH) ? 2 : 3) * R * dm.D;
     return sizeof(double) * (elems + (256 / 64) * EP_N);
 }
@@ -308,9 +325,9 @@ void launch_eval(const Dev &dv, int rhs, hipStream_t s)
 {
     (void)rhs;                 // VA_RHS_LORENZ96 is the only built-in RHS so far
     if (dv.dm.emode == 3) {
-        if (dv.dm.maxr == 4) launch_eval3_d<RhsL96c, 4>(dv, s);
-        else if (dv.dm.maxr == 6) launch_eval3_d<RhsL96c, 6>(dv, s);
-        else launch_eval3_d<RhsL96c, 8>(dv, s);
+        if (dv.dm.maxr == 4) launch_eval3_d<RhsL96g, 4>(dv, s);
+        else if (dv.dm.maxr == 6) launch_eval3_d<RhsL96g, 6>(dv, s);
+        else launch_eval3_d<RhsL96g, 8>(dv, s);
     } else if (dv.dm.emode == 2) {
         if (dv.dm.maxr <= 8) launch_eval2_rhs<RhsL96c, 8>(dv, s);
         else launch_eval2_rhs<RhsL96c, 16>(dv, s);

@@ -3,23 +3,28 @@
 // A workgroup owns T = RY*K consecutive time rows of one seed.  Lane (ty, tx) owns
 // state column tx and the CONTIGUOUS run of K rows r0 = n0 + ty*K .. r0+K-1:
 //   phase A  flat, fully coalesced 16-byte staging of rows [n0-HL, n0+T+HR) of x (or
-//            the trial point x + stp*d) -- and of d when a line search needs g.d -- into LDS;
+//            the trial point x + stp*d) -- and of d when a line search needs g.d -- into
+//            LDS.  The global loads are issued into registers BEFORE the seed's state
+//            is read, so the two round trips overlap;
 //   barrier
 //   phase B  each lane pulls its run (+halo rows) of its column and of the stencil's
 //            neighbour columns out of LDS ONCE, evaluates f for K+HL+HR rows, the
 //            residuals/q for K+HL rows and direct_m, s_m for its K rows entirely in
 //            registers (no f or q ever goes through LDS), and publishes only s_m;
 //   barrier
-//   phase C  J_m^T s_m from the three neighbour columns of s (LDS), measurement term,
+//   phase C  J_m^T s_m from the neighbour columns of s (LDS), measurement term,
 //            gradient store, parameter-gradient / line-search partial sums.
 // Interior tiles run a variant with every row-range predicate compiled out; with D
 // fixed at compile time every LDS address is one base register + an immediate.
 //
-// LDS layout: staged row R (0 = row n0-HL) lives at  R*D + P*run(R),  run(R) =
-// (R-HL+K)/K, i.e. P doubles of padding after every K-row run, with P chosen so that
-// (K*D + P) == D (mod 32).  The lanes of a wave then hit LDS double-word banks
-// ty*D + tx + const = linear lane id (mod 32): conflict-free ds_read_b64, where the
-// unpadded layout is 4-way conflicted for D=20, K=8 (measured: 70% of LDS cycles).
+// LDS layout.  Rows carry G = RHS::GHOST ghost columns on each side holding the cyclic
+// neighbours (x_{D-2}, x_{D-1} | x_0 .. x_{D-1} | x_0, x_1), so the stencil reads
+// x[c-2..c+2] are plain offsets from ONE per-lane base address -- no wrap selects, and
+// adjacent columns pair into ds_read2_b64.  Row pitch DP = D + 2G; after every K-row
+// run there are P doubles of padding with (K*DP + P) == D (mod 32): the lanes of a wave
+// then hit double-word banks ty*D + tx + const = linear lane id (mod 32), i.e.
+// conflict-free (the unpadded, unghosted layout measured 70% of its LDS cycles in bank
+// conflicts for D=20, K=8).
 //
 // Arithmetic restated from the reference: see va_core.h.  Shared with tests/cpu_emul.
 #pragma once
@@ -27,25 +32,60 @@
 
 namespace va {
 
+// Lorenz-96 on a ghosted row: xc points at the lane's own column
+struct RhsL96g {
+    static constexpr int NP = 1;
+    static constexpr int GHOST = 2;
+    static VA_HD double f(const double *xc, double xi, const double *p)
+    {
+        return xc[-1] * (xc[1] - xc[-2]) - xi + p[0];
+    }
+    // (J^T s)_j = s_{j+1}(x_{j+2} - x_{j-1}) + s_{j-1} x_{j-2} - s_{j+2} x_{j+1} - s_j
+    static VA_HD double vjp(const double *xc, const double *sc, double s_own, const double *)
+    {
+        return sc[1] * (xc[2] - xc[-1]) + sc[-1] * xc[-2] - sc[2] * xc[1] - s_own;
+    }
+    static VA_HD void pgrad(double s_own, double *acc) { acc[0] += s_own; }
+};
+
 template <int K> struct T3Regs {
     double direct[K], sown[K], xown[K], yv[K], wv[K];
 };
 
 struct Tile3 {
-    int n0, ty, use_d, l, r0;     // r0 = first owned row of this lane
-    Cols col;
+    int n0, ty, tx, use_d, l, r0;   // r0 = first owned row of this lane
     double stp, c;
-    double *xs, *ds, *ss;         // LDS: staged x, staged d (line search only), s rows
+    double *xs, *ds, *ss;           // LDS: staged x, staged d (line search only), s rows
     const double *xg, *dg;
     double *gtg;
     double p[RHS_MAX_NP];
 };
 
-// run padding in doubles: (K*D + P) == D (mod 32), P even when D is even
-VA_HD constexpr int tile3_pad(int K, int D) { return (((1 - K) * D) % 32 + 32) % 32; }
-// doubles of LDS for the staged arrays (x and d) and for s
-VA_HD constexpr int tile3_stage_elems(int K, int D, int RY, int HLR) { return (RY * K + HLR) * D + tile3_pad(K, D) * (RY + 2); }
-VA_HD constexpr int tile3_s_elems(int K, int D, int RY) { return RY * K * D + tile3_pad(K, D) * RY; }
+// geometry helpers (G = ghost columns per side)
+VA_HD constexpr int tile3_dp(int D, int G) { return D + 2 * G; }
+VA_HD constexpr int tile3_pad(int K, int D, int G) { return ((D - K * tile3_dp(D, G)) % 32 + 32) % 32; }
+VA_HD constexpr int tile3_runpitch(int K, int D, int G) { return K * tile3_dp(D, G) + tile3_pad(K, D, G); }
+VA_HD constexpr int tile3_stage_elems(int K, int D, int G, int RY, int HLR)
+{
+    return (RY * K + HLR) * tile3_dp(D, G) + tile3_pad(K, D, G) * (RY + 2);
+}
+VA_HD constexpr int tile3_s_elems(int K, int D, int G, int RY) { return RY * tile3_runpitch(K, D, G); }
+// staged-row address: row R (0 = n0-HL), column c
+VA_HD constexpr int tile3_addr(int R, int c, int K, int D, int G, int HL)
+{
+    return R * tile3_dp(D, G) + tile3_pad(K, D, G) * ((R - HL + K) / K) + G + c;
+}
+// observed-component lookup without a load when D <= 64: index among the set bits
+VA_HD int obs_index(unsigned long long mask, int tx)
+{
+    if (!((mask >> tx) & 1ull)) return -1;
+    const unsigned long long below = mask & ((1ull << tx) - 1ull);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(below);
+#else
+    return __builtin_popcountll(below);
+#endif
+}
 
 // 16-byte accesses (addresses are even-element offsets of 128-byte aligned rows)
 VA_HD void ld2(const double *p, double &a, double &b)
@@ -66,43 +106,78 @@ VA_HD void st2(double *p, double a, double b)
 #endif
 }
 
-// phase A: flat staging.  rows outside [0,N) read as 0.  `tid`/`nt` are linear.
-template <int DISC, int K, int DC, bool EDGE, bool USE_D>
-VA_HD void tile3_stage(const Dims &dm, const Tile3 &t, int tid, int nt)
+// write one staged value pair (even D) and its ghost copies
+template <int G>
+VA_HD void tile3_put2(double *base, int a, int col, int D, double v0, double v1)
+{
+    st2(base + a, v0, v1);
+    if (col < G) st2(base + a + D, v0, v1);             // x_0, x_1 also right of x_{D-1}
+    if (col >= D - G) st2(base + a - D, v0, v1);        // x_{D-2}, x_{D-1} also left of x_0
+}
+
+// phase A, step 1 (even D): issue the global loads of x into registers.  NS pairs per lane.
+template <int DISC, int K, int DC, bool EDGE, int NS>
+VA_HD void tile3_stage_load(const Dims &dm, int n0, const double *xg, int tid, int nt, double (&xr)[NS][2])
 {
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
     const int D = DC > 0 ? DC : dm.D;
-    const int P = tile3_pad(K, D);
+    const long base = (long)(n0 - HL) * D;
+    const int tot = (dm.T + HL + HR) * D;
+    const double *xsrc = xg + base;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int e = 2 * (tid + u * nt);
+        xr[u][0] = 0.0; xr[u][1] = 0.0;
+        if (e < tot && !(dm.dbg & 4) && (!EDGE || (base + e >= 0 && base + e + 1 < dm.ND)))
+            ld2(xsrc + e, xr[u][0], xr[u][1]);
+    }
+}
+
+// phase A, step 2 (even D): combine with d (line search) and write LDS incl. ghosts.
+template <class RHS, int DISC, int K, int DC, bool EDGE, bool USE_D, int NS>
+VA_HD void tile3_stage_store(const Dims &dm, const Tile3 &t, int tid, int nt, double (&xr)[NS][2])
+{
+    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, G = RHS::GHOST;
+    const int D = DC > 0 ? DC : dm.D;
     const long base = (long)(t.n0 - HL) * D;
     const int tot = (dm.T + HL + HR) * D;
-    const double *xsrc = t.xg + base, *dsrc = t.dg + base;
-    if ((D & 1) == 0) {
-        // rows are 16-byte aligned when D is even: move two doubles per lane per access
-        for (int e = 2 * tid; e < tot; e += 2 * nt) {
-            double x0 = 0.0, x1 = 0.0, d0 = 0.0, d1 = 0.0;
-            if (dm.dbg & 4) { x0 = 1e-3 * e; x1 = 1e-3 * (e + 1); }      // ablation: no global loads
-            else if (!EDGE || (base + e >= 0 && base + e + 1 < dm.ND)) {
-                ld2(xsrc + e, x0, x1);
-                if (USE_D) {
-                    ld2(dsrc + e, d0, d1);
-                    x0 = trial(x0, t.stp, d0); x1 = trial(x1, t.stp, d1);
-                }
-            }
-            const int a = e + P * ((e / D - HL + K) / K);
-            st2(t.xs + a, x0, x1);
-            if (USE_D) st2(t.ds + a, d0, d1);
+    const double *dsrc = t.dg + base;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int e = 2 * (tid + u * nt);
+        if (e >= tot) continue;
+        double x0 = xr[u][0], x1 = xr[u][1], d0 = 0.0, d1 = 0.0;
+        if (USE_D && (!EDGE || (base + e >= 0 && base + e + 1 < dm.ND))) {
+            ld2(dsrc + e, d0, d1);
+            x0 = trial(x0, t.stp, d0); x1 = trial(x1, t.stp, d1);
         }
-    } else {
-        for (int e = tid; e < tot; e += nt) {
-            double x0 = 0.0, d0 = 0.0;
-            if (!EDGE || (base + e >= 0 && base + e < dm.ND)) {
-                x0 = xsrc[e];
-                if (USE_D) { d0 = dsrc[e]; x0 = trial(x0, t.stp, d0); }
-            }
-            const int a = e + P * ((e / D - HL + K) / K);
-            t.xs[a] = x0;
-            if (USE_D) t.ds[a] = d0;
+        const int row = e / D, col = e - row * D;
+        const int a = tile3_addr(row, col, K, D, G, HL);
+        tile3_put2<G>(t.xs, a, col, D, x0, x1);
+        if (USE_D) st2(t.ds + a, d0, d1);
+    }
+}
+
+// phase A for odd D (scalar accesses; rare): loads and stores in one loop
+template <class RHS, int DISC, int K, int DC, bool EDGE, bool USE_D>
+VA_HD void tile3_stage_odd(const Dims &dm, const Tile3 &t, int tid, int nt)
+{
+    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, G = RHS::GHOST;
+    const int D = DC > 0 ? DC : dm.D;
+    const long base = (long)(t.n0 - HL) * D;
+    const int tot = (dm.T + HL + HR) * D;
+    for (int e = tid; e < tot; e += nt) {
+        double x0 = 0.0, d0 = 0.0;
+        if (!EDGE || (base + e >= 0 && base + e < dm.ND)) {
+            x0 = t.xg[base + e];
+            if (USE_D) { d0 = t.dg[base + e]; x0 = trial(x0, t.stp, d0); }
         }
+        const int row = e / D, col = e - row * D;
+        const int a = tile3_addr(row, col, K, D, G, HL);
+        t.xs[a] = x0;
+        if (col < G) t.xs[a + D] = x0;
+        if (col >= D - G) t.xs[a - D] = x0;
+        if (USE_D) t.ds[a] = d0;
     }
 }
 
@@ -150,19 +225,19 @@ VA_HD void tile3_obs(const Dims &dm, const ProblemPtrs &pp, const Tile3 &t, T3Re
 template <class RHS, int DISC, int K, bool EDGE, int DC>
 VA_HD void tile3_rows(const Dims &dm, const ProblemPtrs &pp, const Tile3 &t, T3Regs<K> &rg, ThreadAcc &acc)
 {
-    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, NR = K + HL + HR, NQ = K + HL;
-    const int D = DC > 0 ? DC : dm.D, N = dm.N, i = t.col.i;
-    const int P = tile3_pad(K, D);
+    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, NR = K + HL + HR, NQ = K + HL, G = RHS::GHOST;
+    const int D = DC > 0 ? DC : dm.D, N = dm.N, i = t.tx;
+    const int DP = tile3_dp(D, G), P = tile3_pad(K, D, G);
     const double dt = dm.dt;
-    // the lane's first needed row r0-HL is staged row ty*K: LDS offset ty*(K*D+P)
-    const double *xbase = t.xs + t.ty * (K * D + P);
+    // the lane's first needed row r0-HL is staged row ty*K; its own column sits at +G+tx
+    const double *xc0 = t.xs + t.ty * (K * DP + P) + G + i;
     double xo[NR], fo[NR], q[NQ], w[NQ];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        const double *xr = xbase + j * D + P * ((j - HL + K) / K);
-        xo[j] = xr[i];
+        const double *xc = xc0 + j * DP + P * ((j - HL + K) / K);
+        xo[j] = xc[0];
         const int row = t.r0 - HL + j;
-        if (!EDGE || (row >= 0 && row < N)) fo[j] = RHS::f(xr, t.col, xo[j], t.p);
+        if (!EDGE || (row >= 0 && row < N)) fo[j] = RHS::f(xc, xo[j], t.p);
         else fo[j] = 0.0;
     }
     // model-error weights RF0[n, i] (va_ode.py:203-209) or the scalar; one uniform branch
@@ -203,8 +278,8 @@ VA_HD void tile3_rows(const Dims &dm, const ProblemPtrs &pp, const Tile3 &t, T3R
         q[j] = t.c * wr;
         if (j >= HL) acc.v[EP_FE] += wr * r;        // rows of this lane's own run
     }
-    // direct_m, s_m (same linear combinations as disc_direct_s, on registers)
-    double *sbase = t.ss + t.ty * (K * D + P) + i;
+    // direct_m, s_m (same linear combinations as disc_direct_s, on registers); s with ghosts
+    double *sc0 = t.ss + t.ty * (K * DP + P) + G + i;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int j = k + HL;
@@ -222,7 +297,9 @@ VA_HD void tile3_rows(const Dims &dm, const ProblemPtrs &pp, const Tile3 &t, T3R
         }
         if (EDGE && t.r0 + k >= N) { direct = 0.0; s = 0.0; }
         rg.direct[k] = direct; rg.sown[k] = s; rg.xown[k] = xo[j];
-        sbase[k * D] = s;
+        sc0[k * DP] = s;
+        if (i < G) sc0[k * DP + D] = s;             // ghost copies for the cyclic neighbours
+        if (i >= D - G) sc0[k * DP - D] = s;
     }
 }
 
@@ -230,18 +307,18 @@ VA_HD void tile3_rows(const Dims &dm, const ProblemPtrs &pp, const Tile3 &t, T3R
 template <class RHS, int DISC, int K, bool EDGE, int DC>
 VA_HD void tile3_grad(const Dims &dm, const Tile3 &t, const T3Regs<K> &rg, ThreadAcc &acc)
 {
-    constexpr int HL = Halo<DISC>::HL;
-    const int D = DC > 0 ? DC : dm.D, i = t.col.i;
-    const int P = tile3_pad(K, D);
-    const int runoff = t.ty * (K * D + P);
+    constexpr int HL = Halo<DISC>::HL, G = RHS::GHOST;
+    const int D = DC > 0 ? DC : dm.D, i = t.tx;
+    const int DP = tile3_dp(D, G), P = tile3_pad(K, D, G);
+    const int runoff = t.ty * (K * DP + P) + G + i;
     // own rows k = 0..K-1 are staged rows ty*K + HL + k, all in run ty+1
-    const double *xrun = t.xs + runoff + HL * D + P;
-    const double *drun = t.ds + runoff + HL * D + P;
+    const double *xrun = t.xs + runoff + HL * DP + P;
+    const double *drun = t.ds + runoff + HL * DP + P;
     const double *srun = t.ss + runoff;
     double dval[K];
     if (t.use_d) {                                  // workgroup-uniform
 #pragma unroll
-        for (int k = 0; k < K; ++k) dval[k] = drun[k * D + i];
+        for (int k = 0; k < K; ++k) dval[k] = drun[k * DP];
     } else {
 #pragma unroll
         for (int k = 0; k < K; ++k) dval[k] = 0.0;
@@ -251,9 +328,7 @@ VA_HD void tile3_grad(const Dims &dm, const Tile3 &t, const T3Regs<K> &rg, Threa
     double *gout = t.gtg + (long)t.r0 * D + i;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const double *sr = srun + k * D;
-        const double *xr = xrun + k * D;
-        double g = rg.direct[k] + RHS::vjp(xr, t.col, sr[t.col.ip1], sr[t.col.im1], sr[t.col.ip2], rg.sown[k], t.p);
+        double g = rg.direct[k] + RHS::vjp(xrun + k * DP, srun + k * DP, rg.sown[k], t.p);
         RHS::pgrad(rg.sown[k], acc.v + EP_GP);
         // measurement term: wv = 0 on unobserved entries, so no branch
         const double diff = rg.xown[k] - rg.yv[k];
