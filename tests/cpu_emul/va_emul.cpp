@@ -147,7 +147,7 @@ void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_
     const Dims &dm = E.dm;
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, G = RHS::GHOST, NS = K / 2 + 1;
     const int D = dm.D, T = dm.T, RY = dm.RY, NTH = D * RY, NT = dm.NT;
-    std::vector<double> xs(tile3_stage_elems(K, D, G, RY, HL + HR)), ds(xs.size()), ss(tile3_s_elems(K, D, G, RY));
+    std::vector<double> xs(tile3_stage_elems(K, D, G, RY, HL + HR)), ss(tile3_s_elems(K, D, G, RY));
     for (int k = 0; k < EP_N; ++k) ev[k] = 0.0;
     for (int tile = 0; tile < dm.ntiles; ++tile) {
         std::vector<Tile3> th(NT);
@@ -158,7 +158,7 @@ void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_
             c.n0 = tile * T; c.ty = t / D; c.tx = t % D; c.r0 = c.n0 + c.ty * K; c.use_d = use_d;
             c.l = obs_index(dm.obsmask, c.tx);
             c.stp = stp; c.c = 2.0 * rf_scale * dm.cfe;
-            c.xs = xs.data(); c.ds = ds.data(); c.ss = ss.data();
+            c.xs = xs.data(); c.ss = ss.data();
             c.xg = x; c.dg = d; c.gtg = gt;
             Tile2 tmp; tmp.xg = x; tmp.dg = d; tmp.use_d = use_d; tmp.stp = stp;
             tile2_params<RhsL96c>(dm, E.pp, b, tmp);

@@ -92,7 +92,7 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm)
             K = K <= 4 ? 4 : (K <= 6 ? 6 : 8);
         }
         for (;;) {                                        // shrink until the staging arrays fit in LDS
-            const size_t elems = (size_t)2 * tile3_stage_elems(K, D, 2, dm.RY, HLR) + tile3_s_elems(K, D, 2, dm.RY);
+            const size_t elems = (size_t)tile3_stage_elems(K, D, 2, dm.RY, HLR) + tile3_s_elems(K, D, 2, dm.RY);
             if (sizeof(double) * elems <= 60 * 1024 || K == 4) break;
             K -= 2;
         }

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_eval3(const Dev dv)
     t.n0 = n0; t.ty = ty; t.tx = tx; t.r0 = n0 + ty * K; t.use_d = (phase == PH_LS);
     t.l = active ? obs_index(dm.obsmask, tx) : -1;
     t.stp = st.stp; t.c = 2.0 * st.rf_scale * dm.cfe;
-    t.xs = smem; t.ss = smem + SE; t.ds = smem + SE + tile3_s_elems(K, D, G, RY);
+    t.xs = smem; t.ss = smem + SE;
     t.xg = xg; t.dg = dv.d + (size_t)b * dm.ld;
     t.gtg = dv.gt + (size_t)b * dm.ld;
     {   // parameters (same select-chain as tile2_params)
@@ -250,15 +250,46 @@ __global__ __launch_bounds__(256) void k_eval3(const Dev dv)
 
     // every wave writes its own partial row (no LDS, no barrier: a __syncthreads here would
     // also wait for the gradient stores to land); k_ls sums the rows in a fixed order.
+    // The 7 sums go through ONE halving butterfly (10 lane exchanges instead of 7 x 6): after
+    // the xor-32/16/8 steps each lane carries one value, after xor-4/2/1 its wave total.
+    static_assert(EP_GMAX == 4 && EP_GP == 5 && RHS::NP <= 3, "butterfly slot layout");
+    (void)KP;
     const int lane = tid & 63, wave = tid >> 6;
-    double out = 0.0;
+    double *prow = dv.evp + (((size_t)b * dm.ntiles + tile) * 4 + wave) * EP_N;
+    const double gm = wave_max(acc.v[EP_GMAX]);
+    double v8[8];
 #pragma unroll
-    for (int k = 0; k < KP; ++k) {
-        double v = (k == EP_GMAX) ? wave_max(acc.v[k]) : wave_sum(acc.v[k]);
-        v = __shfl(v, 0, 64);
-        out = (lane == k) ? v : out;
+    for (int k = 0; k < 8; ++k) v8[k] = (k == EP_GMAX || k - EP_GP >= RHS::NP) ? 0.0 : acc.v[k];
+    double w4[4], z2[2];
+    {
+        const bool up = (lane & 32) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double send = up ? v8[i] : v8[i + 4], keep = up ? v8[i + 4] : v8[i];
+            w4[i] = keep + __shfl_xor(send, 32, 64);
+        }
     }
-    if (lane < KP) dv.evp[(((size_t)b * dm.ntiles + tile) * 4 + wave) * EP_N + lane] = out;
+    {
+        const bool up = (lane & 16) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double send = up ? w4[i] : w4[i + 2], keep = up ? w4[i + 2] : w4[i];
+            z2[i] = keep + __shfl_xor(send, 16, 64);
+        }
+    }
+    double y;
+    {
+        const bool up = (lane & 8) != 0;
+        const double send = up ? z2[0] : z2[1], keep = up ? z2[1] : z2[0];
+        y = keep + __shfl_xor(send, 8, 64);
+    }
+    y += __shfl_xor(y, 4, 64);
+    y += __shfl_xor(y, 2, 64);
+    y += __shfl_xor(y, 1, 64);
+    // lane with bits (5,4,3) = k holds the total of value k
+    const int kcol = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+    if ((lane & 7) == 0 && kcol != EP_GMAX && kcol - EP_GP < RHS::NP) prow[kcol] = y;
+    if (lane == 0) prow[EP_GMAX] = gm;
 }
 
 size_t eval_lds_bytes(const Dims &dm)
@@ -267,7 +298,7 @@ size_t eval_lds_bytes(const Dims &dm)
     const int R = dm.T + HL + 1;
     size_t elems;
     if (dm.emode == 3)
-        elems = (size_t)2 * tile3_stage_elems(dm.maxr, dm.D, 2, dm.RY, HL + 1) + tile3_s_elems(dm.maxr, dm.D, 2, dm.RY);
+        elems = (size_t)tile3_stage_elems(dm.maxr, dm.D, 2, dm.RY, HL + 1) + tile3_s_elems(dm.maxr, dm.D, 2, dm.RY);
     else elems = (size_t)((dm.emode == 2 && dm.disc != DISC_SH) ? 2 : 3) * R * dm.D;
     return sizeof(double) * (elems + (256 / 64) * EP_N);
 }

@@ -3,9 +3,8 @@
 // A workgroup owns T = RY*K consecutive time rows of one seed.  Lane (ty, tx) owns
 // state column tx and the CONTIGUOUS run of K rows r0 = n0 + ty*K .. r0+K-1:
 //   phase A  flat, fully coalesced 16-byte staging of rows [n0-HL, n0+T+HR) of x (or
-//            the trial point x + stp*d) -- and of d when a line search needs g.d -- into
-//            LDS.  The global loads are issued into registers BEFORE the seed's state
-//            is read, so the two round trips overlap;
+//            the trial point x + stp*d) into LDS.  The global loads are issued into
+//            registers BEFORE the seed's state is read, so the two round trips overlap;
 //   barrier
 //   phase B  each lane pulls its run (+halo rows) of its column and of the stencil's
 //            neighbour columns out of LDS ONCE, evaluates f for K+HL+HR rows, the
@@ -49,13 +48,13 @@ struct RhsL96g {
 };
 
 template <int K> struct T3Regs {
-    double direct[K], sown[K], xown[K], yv[K], wv[K];
+    double direct[K], sown[K], xown[K], yv[K], wv[K], dval[K];
 };
 
 struct Tile3 {
     int n0, ty, tx, use_d, l, r0;   // r0 = first owned row of this lane
     double stp, c;
-    double *xs, *ds, *ss;           // LDS: staged x, staged d (line search only), s rows
+    double *xs, *ss;                // LDS: staged x rows, s rows
     const double *xg, *dg;
     double *gtg;
     double p[RHS_MAX_NP];
@@ -115,46 +114,55 @@ VA_HD void tile3_put2(double *base, int a, int col, int D, double v0, double v1)
     if (col >= D - G) st2(base + a - D, v0, v1);        // x_{D-2}, x_{D-1} also left of x_0
 }
 
-// phase A, step 1 (even D): issue the global loads of x into registers.  NS pairs per lane.
+// phase A (even D).  Staging lanes are laid out (sr, cp) = (tid / (D/2), tid % (D/2)): lane
+// handles the column pair cp of rows sr, sr+RP, sr+2RP, ... with RP = 2*nt/D rows per pass.
+// Consecutive lanes still read consecutive 16-byte pieces of the time-major path (fully
+// coalesced), the column is loop-invariant (no div/mod per element, ghost-copy predicates
+// hoisted) and lanes >= RP*D/2 idle during staging only.
+// step 1: issue the global loads of x into registers.  NS double2 per lane.
 template <int DISC, int K, int DC, bool EDGE, int NS>
 VA_HD void tile3_stage_load(const Dims &dm, int n0, const double *xg, int tid, int nt, double (&xr)[NS][2])
 {
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
-    const int D = DC > 0 ? DC : dm.D;
-    const long base = (long)(n0 - HL) * D;
-    const int tot = (dm.T + HL + HR) * D;
-    const double *xsrc = xg + base;
+    const int D = DC > 0 ? DC : dm.D, H = D / 2;
+    const int RP = (2 * nt) / D, R = dm.T + HL + HR;
+    const int sr = tid / H, cp = tid - sr * H;
+    const double *xsrc = xg + (long)(n0 - HL) * D + 2 * cp;
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-        const int e = 2 * (tid + u * nt);
+        const int row = sr + u * RP, grow = n0 - HL + row;
         xr[u][0] = 0.0; xr[u][1] = 0.0;
-        if (e < tot && !(dm.dbg & 4) && (!EDGE || (base + e >= 0 && base + e + 1 < dm.ND)))
-            ld2(xsrc + e, xr[u][0], xr[u][1]);
+        if (sr < RP && row < R && !(dm.dbg & 4) && (!EDGE || (grow >= 0 && grow < dm.N)))
+            ld2(xsrc + (long)row * D, xr[u][0], xr[u][1]);
     }
 }
 
-// phase A, step 2 (even D): combine with d (line search) and write LDS incl. ghosts.
+// step 2: combine with d (line search) and write LDS incl. ghost copies.
 template <class RHS, int DISC, int K, int DC, bool EDGE, bool USE_D, int NS>
 VA_HD void tile3_stage_store(const Dims &dm, const Tile3 &t, int tid, int nt, double (&xr)[NS][2])
 {
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, G = RHS::GHOST;
-    const int D = DC > 0 ? DC : dm.D;
-    const long base = (long)(t.n0 - HL) * D;
-    const int tot = (dm.T + HL + HR) * D;
-    const double *dsrc = t.dg + base;
+    const int D = DC > 0 ? DC : dm.D, H = D / 2;
+    const int DP = tile3_dp(D, G), P = tile3_pad(K, D, G);
+    const int RP = (2 * nt) / D, R = dm.T + HL + HR;
+    const int sr = tid / H, cp = tid - sr * H, col = 2 * cp;
+    if (sr >= RP) return;
+    const double *dsrc = t.dg + (long)(t.n0 - HL) * D + col;
+    const bool gr = col < G, gl = col >= D - G;          // loop-invariant ghost predicates
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-        const int e = 2 * (tid + u * nt);
-        if (e >= tot) continue;
-        double x0 = xr[u][0], x1 = xr[u][1], d0 = 0.0, d1 = 0.0;
-        if (USE_D && (!EDGE || (base + e >= 0 && base + e + 1 < dm.ND))) {
-            ld2(dsrc + e, d0, d1);
+        const int row = sr + u * RP, grow = t.n0 - HL + row;
+        if (row >= R) continue;
+        double x0 = xr[u][0], x1 = xr[u][1];
+        if (USE_D && (!EDGE || (grow >= 0 && grow < dm.N))) {
+            double d0, d1;
+            ld2(dsrc + (long)row * D, d0, d1);
             x0 = trial(x0, t.stp, d0); x1 = trial(x1, t.stp, d1);
         }
-        const int row = e / D, col = e - row * D;
-        const int a = tile3_addr(row, col, K, D, G, HL);
-        tile3_put2<G>(t.xs, a, col, D, x0, x1);
-        if (USE_D) st2(t.ds + a, d0, d1);
+        double *dst = t.xs + row * DP + P * ((row - HL + K) / K) + G + col;
+        st2(dst, x0, x1);
+        if (gr) st2(dst + D, x0, x1);                    // x_0, x_1 also right of x_{D-1}
+        if (gl) st2(dst - D, x0, x1);                    // x_{D-2}, x_{D-1} also left of x_0
     }
 }
 
@@ -177,7 +185,6 @@ VA_HD void tile3_stage_odd(const Dims &dm, const Tile3 &t, int tid, int nt)
         t.xs[a] = x0;
         if (col < G) t.xs[a + D] = x0;
         if (col >= D - G) t.xs[a - D] = x0;
-        if (USE_D) t.ds[a] = d0;
     }
 }
 
@@ -186,6 +193,17 @@ VA_HD void tile3_stage_odd(const Dims &dm, const Tile3 &t, int tid, int nt)
 template <int K>
 VA_HD void tile3_obs(const Dims &dm, const ProblemPtrs &pp, const Tile3 &t, T3Regs<K> &rg)
 {
+    // the lane's own entries of d for the g.d partial (line search only; workgroup-uniform
+    // branch).  Read again from global (L2-hot: the staging just fetched them) rather than
+    // staged: a second LDS image of the tile would cost a workgroup per CU of occupancy.
+    if (t.use_d) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            rg.dval[k] = (t.r0 + k < dm.N) ? t.dg[(long)(t.r0 + k) * dm.D + t.tx] : 0.0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) rg.dval[k] = 0.0;
+    }
     if (dm.nskip == 1) {
         // common case (dt_model == dt_data): every row is an observation time.  Branch-free:
         // unobserved lanes read entry 0.
@@ -313,16 +331,7 @@ VA_HD void tile3_grad(const Dims &dm, const Tile3 &t, const T3Regs<K> &rg, Threa
     const int runoff = t.ty * (K * DP + P) + G + i;
     // own rows k = 0..K-1 are staged rows ty*K + HL + k, all in run ty+1
     const double *xrun = t.xs + runoff + HL * DP + P;
-    const double *drun = t.ds + runoff + HL * DP + P;
     const double *srun = t.ss + runoff;
-    double dval[K];
-    if (t.use_d) {                                  // workgroup-uniform
-#pragma unroll
-        for (int k = 0; k < K; ++k) dval[k] = drun[k * DP];
-    } else {
-#pragma unroll
-        for (int k = 0; k < K; ++k) dval[k] = 0.0;
-    }
     const double two_cme = 2.0 * dm.cme;
     double gmax = acc.v[EP_GMAX];
     double *gout = t.gtg + (long)t.r0 * D + i;
@@ -336,7 +345,7 @@ VA_HD void tile3_grad(const Dims &dm, const Tile3 &t, const T3Regs<K> &rg, Threa
         acc.v[EP_ME] += wd * diff;
         g += two_cme * wd;
         if (!EDGE || t.r0 + k < dm.N) { if (!(dm.dbg & 1)) gout[k * D] = g; } else g = 0.0;
-        acc.v[EP_GTD] += g * dval[k];
+        acc.v[EP_GTD] += g * rg.dval[k];
         acc.v[EP_GN2] += g * g;
         const double ag = fabs(g);
         gmax = ag > gmax ? ag : gmax;               // compare-select: fmax() would canonicalise twice
