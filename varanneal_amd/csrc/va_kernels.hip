@@ -170,7 +170,10 @@ __global__ __launch_bounds__(256) void k_eval3(const Dev dv)
 
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, G = RHS::GHOST;
     constexpr int KP = EP_GP + RHS::NP;
-    constexpr int NS = K / 2 + 1;        // staged double2 per lane: ceil((RY*K+3)*D / (2*NT)) <= K/2+1
+    // staged double2 per lane = ceil(R / RP), RP = 2*NT/D rows per pass; <= K/2+1 for any D
+    constexpr int DCs = DC > 0 ? DC : 2;
+    constexpr int RPc = 2 * tile2_threads(DCs) / DCs;
+    constexpr int NS = DC > 0 ? (tile2_RY(DCs) * K + HL + HR + RPc - 1) / RPc : K / 2 + 1;
     // with D fixed at compile time the whole tile geometry (and every LDS offset) is constant
     const int D = DC > 0 ? DC : dm.D;
     const int RY = DC > 0 ? tile2_RY(DC > 0 ? DC : 1) : dm.RY;

@@ -119,7 +119,9 @@ VA_HD void tile3_put2(double *base, int a, int col, int D, double v0, double v1)
 // Consecutive lanes still read consecutive 16-byte pieces of the time-major path (fully
 // coalesced), the column is loop-invariant (no div/mod per element, ghost-copy predicates
 // hoisted) and lanes >= RP*D/2 idle during staging only.
-// step 1: issue the global loads of x into registers.  NS double2 per lane.
+// step 1: issue the global loads of x into registers.  NS double2 per lane.  Branch-free:
+// every lane loads from a clamped (always valid) row, so the NS loads issue back to back;
+// rows that do not exist are zeroed by a select (edge tiles) or never stored (row >= R).
 template <int DISC, int K, int DC, bool EDGE, int NS>
 VA_HD void tile3_stage_load(const Dims &dm, int n0, const double *xg, int tid, int nt, double (&xr)[NS][2])
 {
@@ -127,13 +129,19 @@ VA_HD void tile3_stage_load(const Dims &dm, int n0, const double *xg, int tid, i
     const int D = DC > 0 ? DC : dm.D, H = D / 2;
     const int RP = (2 * nt) / D, R = dm.T + HL + HR;
     const int sr = tid / H, cp = tid - sr * H;
-    const double *xsrc = xg + (long)(n0 - HL) * D + 2 * cp;
+    const double *xcol = xg + 2 * cp;
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-        const int row = sr + u * RP, grow = n0 - HL + row;
-        xr[u][0] = 0.0; xr[u][1] = 0.0;
-        if (sr < RP && row < R && !(dm.dbg & 4) && (!EDGE || (grow >= 0 && grow < dm.N)))
-            ld2(xsrc + (long)row * D, xr[u][0], xr[u][1]);
+        int row = sr + u * RP;
+        row = row < R ? row : R - 1;
+        int grow = n0 - HL + row;
+        bool ok = true;
+        if (EDGE) {
+            const int gc = grow < 0 ? 0 : (grow > dm.N - 1 ? dm.N - 1 : grow);
+            ok = gc == grow; grow = gc;
+        }
+        ld2(xcol + (long)grow * D, xr[u][0], xr[u][1]);
+        if (EDGE && !ok) { xr[u][0] = 0.0; xr[u][1] = 0.0; }
     }
 }
 
@@ -146,23 +154,30 @@ VA_HD void tile3_stage_store(const Dims &dm, const Tile3 &t, int tid, int nt, do
     const int DP = tile3_dp(D, G), P = tile3_pad(K, D, G);
     const int RP = (2 * nt) / D, R = dm.T + HL + HR;
     const int sr = tid / H, cp = tid - sr * H, col = 2 * cp;
-    if (sr >= RP) return;
-    const double *dsrc = t.dg + (long)(t.n0 - HL) * D + col;
+    const double *dcol = t.dg + col;
     const bool gr = col < G, gl = col >= D - G;          // loop-invariant ghost predicates
+    double dd[NS][2];
+    if (USE_D) {                                         // same clamped, branch-free loads for d
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            int row = sr + u * RP;
+            row = row < R ? row : R - 1;
+            int grow = t.n0 - HL + row;
+            if (EDGE) grow = grow < 0 ? 0 : (grow > dm.N - 1 ? dm.N - 1 : grow);
+            ld2(dcol + (long)grow * D, dd[u][0], dd[u][1]);
+        }
+    }
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-        const int row = sr + u * RP, grow = t.n0 - HL + row;
-        if (row >= R) continue;
+        const int row = sr + u * RP;
         double x0 = xr[u][0], x1 = xr[u][1];
-        if (USE_D && (!EDGE || (grow >= 0 && grow < dm.N))) {
-            double d0, d1;
-            ld2(dsrc + (long)row * D, d0, d1);
-            x0 = trial(x0, t.stp, d0); x1 = trial(x1, t.stp, d1);
+        if (USE_D) { x0 = trial(x0, t.stp, dd[u][0]); x1 = trial(x1, t.stp, dd[u][1]); }
+        if (sr < RP && row < R) {
+            double *dst = t.xs + row * DP + P * ((row - HL + K) / K) + G + col;
+            st2(dst, x0, x1);
+            if (gr) st2(dst + D, x0, x1);                // x_0, x_1 also right of x_{D-1}
+            if (gl) st2(dst - D, x0, x1);                // x_{D-2}, x_{D-1} also left of x_0
         }
-        double *dst = t.xs + row * DP + P * ((row - HL + K) / K) + G + col;
-        st2(dst, x0, x1);
-        if (gr) st2(dst + D, x0, x1);                    // x_0, x_1 also right of x_{D-1}
-        if (gl) st2(dst - D, x0, x1);                    // x_{D-2}, x_{D-1} also left of x_0
     }
 }
 
@@ -344,7 +359,7 @@ VA_HD void tile3_grad(const Dims &dm, const Tile3 &t, const T3Regs<K> &rg, Threa
         const double wd = rg.wv[k] * diff;
         acc.v[EP_ME] += wd * diff;
         g += two_cme * wd;
-        if (!EDGE || t.r0 + k < dm.N) { if (!(dm.dbg & 1)) gout[k * D] = g; } else g = 0.0;
+        if (!EDGE || t.r0 + k < dm.N) gout[k * D] = g; else g = 0.0;
         acc.v[EP_GTD] += g * rg.dval[k];
         acc.v[EP_GN2] += g * g;
         const double ag = fabs(g);
