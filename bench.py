@@ -30,6 +30,10 @@ WORKLOADS = {
     "c3": dict(D=20, N=1000, B=64, name="lorenz96_D20_N1000_L7_B64_trapezoid"),
     "c4": dict(D=200, N=5000, B=64, name="lorenz96_D200_N5000_L80_B64_trapezoid"),
     "c2": dict(D=20, N=1000, B=1, name="lorenz96_D20_N1000_L7_B1_trapezoid"),
+    # batch-scaling points of the C3 shape (launch overhead amortised; not BASELINE configs)
+    "c3x4": dict(D=20, N=1000, B=256, name="lorenz96_D20_N1000_L7_B256_trapezoid"),
+    "c3x16": dict(D=20, N=1000, B=1024, name="lorenz96_D20_N1000_L7_B1024_trapezoid"),
+    "c3x64": dict(D=20, N=1000, B=4096, name="lorenz96_D20_N1000_L7_B4096_trapezoid"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 RF_SCALE = 1.5 ** 15           # mid-ladder RF (value does not change the work)

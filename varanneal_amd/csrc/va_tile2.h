@@ -210,7 +210,7 @@ VA_HD void tile2_g(const Dims &dm, Tile2 &t, const TRegs<MAXR> &rg, ThreadAcc &a
 }
 
 // geometry of the column-mapped kernel for a given D
-VA_HD int tile2_RY(int D) { return D >= 256 ? 1 : 256 / D; }
-VA_HD int tile2_threads(int D) { return ((D * tile2_RY(D) + 63) / 64) * 64; }
+VA_HD constexpr int tile2_RY(int D) { return D >= 256 ? 1 : 256 / D; }
+VA_HD constexpr int tile2_threads(int D) { return ((D * tile2_RY(D) + 63) / 64) * 64; }
 
 }  // namespace va
