@@ -44,6 +44,18 @@ def bytes_alg(B, N, D, NPest, N_data, L):
     return 8 * (B * (2 * N * D + 2 * NPest + 3) + N_data * L)
 
 
+def pmc_traffic(workload_name):
+    """HBM bytes per k_eval launch from the rocprofv3 --pmc passes recorded under profiles/
+    (FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE; own
+    runs with --kernel-trace only).  Counters cannot be collected inside this process, so this
+    is the committed measurement for the same kernel and workload, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            return json.load(fh).get(workload_name, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def make_inputs(D, N, B, rank):
     from varanneal_amd import twin
     t, Y, _, Lidx = twin.make_twin(D, N)
@@ -173,9 +185,11 @@ def main():
                        "disc": "trapezoid", "tile_rows": info["tile_rows"], "ntiles": info["ntiles"],
                        "parallelism": "seeds sharded, %d per GPU" % B},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_eval<RhsL96,trapezoid>", "kernel_us": kern_s * 1e6,
-                         "bytes_alg_per_launch": balg},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(w["name"]),
+                         "kernel": {3: "k_eval3<RhsL96g,trapezoid,K=%d>" % (info["tile_rows"] // max(1, 256 // D)),
+                                    2: "k_eval2<RhsL96c,trapezoid>", 1: "k_eval<RhsL96,trapezoid>"}
+                                   .get(args.eval_kernel or (3 if D <= 64 else (2 if D <= 256 else 1))),
+                         "kernel_us": kern_s * 1e6, "bytes_alg_per_launch": balg},
             "cpu_baseline": None,
         }
         if world == 1 and not args.no_cpu:

@@ -84,9 +84,10 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm)
     if (dm.emode == 3) {
         // column-run kernel: T = RY*K exactly, K rows per lane in {4, 6, 8}
         dm.RY = tile2_RY(D); dm.NT = tile2_threads(D);
-        // longest run (least halo, fewest workgroups) that still gives every CU a workgroup
-        int K = 8;
-        while (K > 4 && (long)d->batch * ((N + dm.RY * K - 1) / (dm.RY * K)) < 256) K -= 2;
+        // K = 6 keeps the kernel at 128 VGPRs (4 waves/SIMD) and measured best from 64 to 4096
+        // seeds (profiles/r01_sweep_*.txt); drop to 4 when that leaves CUs without a workgroup
+        int K = 6;
+        if ((long)d->batch * ((N + dm.RY * K - 1) / (dm.RY * K)) < 256) K = 4;
         if (d->tile_rows > 0) {
             K = (d->tile_rows + dm.RY - 1) / dm.RY;
             K = K <= 4 ? 4 : (K <= 6 ? 6 : 8);
