@@ -37,6 +37,7 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     m.emode = (d->eval_kernel >= 1 && d->eval_kernel <= 3) ? d->eval_kernel : 3;
     m.RY = tile2_RY(m.D); m.NT = tile2_threads(m.D); m.maxr = 16;
     if (m.emode == 3) {                      // column-run: T = RY*K, K in {4,6,8}
+        m.RY = tile3_RY(m.D); m.NT = tile3_threads(m.D);
         int K = (T + m.RY - 1) / m.RY;
         K = K <= 4 ? 4 : (K <= 6 ? 6 : 8);
         m.maxr = K; T = m.RY * K;
@@ -156,7 +157,7 @@ void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_
         for (int t = 0; t < NT; ++t) {
             Tile3 &c = th[t];
             c.n0 = tile * T; c.ty = t / D; c.tx = t % D; c.r0 = c.n0 + c.ty * K; c.use_d = use_d;
-            c.l = obs_index(dm.obsmask, c.tx);
+            c.l = D <= 64 ? obs_index(dm.obsmask, c.tx) : E.lmap[c.tx];
             c.stp = stp; c.c = 2.0 * rf_scale * dm.cfe;
             c.xs = xs.data(); c.ss = ss.data();
             c.xg = x; c.dg = d; c.gtg = gt;

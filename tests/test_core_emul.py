@@ -83,3 +83,25 @@ def test_small_history_and_limits(golden_ladders):
     r = emul.anneal(desc, 50, XP0[None, :], [1.0], dict(OPTS, gtol=1e3))
     assert (r["nit"][0, 0], r["nfev"][0, 0], r["status"][0, 0]) == (0, 1, 0)
     assert np.array_equal(r["x"][0], XP0)
+
+
+@pytest.mark.parametrize("D,disc", [(7, "trapezoid"), (36, "SimpsonHermite"), (64, "euler"),
+                                    (100, "trapezoid"), (200, "SimpsonHermite")])
+def test_other_state_sizes_against_oracle(D, disc):
+    """odd D (scalar staging), 256-thread groups up to D=64, 1024-thread groups beyond."""
+    from varanneal_amd import twin
+    N = 31
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    rng = np.random.RandomState(D)
+    XP = np.append(rng.randn(N * D) * 3.0, 7.3)
+    RF0 = 4e-6 * (0.5 + rng.rand(N - 1, D))
+    opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, RF0, [7.3], [0], disc=disc)
+    Ao, meo, feo, go = opb.action_grad(XP, 1.5 ** 20)
+    for ek in (1, 2, 3):
+        if ek == 2 and D > 256:
+            continue
+        desc, keep = _capi.make_desc(1, D, N, Y, Lidx, twin.DT, 4.0, RF0, [[7.3]], [0], disc=disc, eval_kernel=ek)
+        for T in (4, 10):
+            A, me, fe, g = emul.action_grad(desc, T, XP[None, :], 1.5 ** 20)
+            assert abs(A[0] - Ao) <= 1e-12 * abs(Ao), (ek, T)
+            assert np.abs(g[0] - go).max() <= 1e-11 * np.abs(go).max(), (ek, T)

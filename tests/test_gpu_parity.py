@@ -191,3 +191,48 @@ def test_c3_shape_properties(capi):
     Ap_, _, _, gp_ = pb2.action_grad(XP[perm], 1000.0)
     assert np.array_equal(Ap_, A2[perm]) and np.array_equal(gp_, g2[perm])
     pb.close(); pb2.close()
+
+
+@pytest.mark.parametrize("D,disc", [(7, "trapezoid"), (36, "SimpsonHermite"), (64, "euler"),
+                                    (100, "forwardmap"), (200, "trapezoid"), (200, "SimpsonHermite"),
+                                    (300, "trapezoid"), (600, "trapezoid")])
+def test_other_state_sizes_against_oracle(capi, D, disc):
+    """every eval-kernel geometry: odd D, 256-thread groups (D <= 64), 1024-thread groups
+    (D = 200 compile-time, 100/300 run-time), flat fallback (D = 600); vector RF0; 3 seeds."""
+    import va_oracle
+    from varanneal_amd import twin
+    N, B = 61, 3
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    rng = np.random.RandomState(D)
+    XP = np.concatenate([rng.randn(B, N * D) * 3.0, 6.0 + 3.0 * rng.rand(B, 1)], axis=1)
+    P = XP[:, -1:].copy()
+    RF0 = 4e-6 * (0.5 + rng.rand(N - 1, D))
+    for ek in (0, 1, 2):
+        if ek == 2 and D > 256:
+            continue
+        pb = capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, RF0, P, [0], disc=disc, eval_kernel=ek)
+        A, me, fe, g = pb.action_grad(XP, 1.5 ** 20)
+        pb.close()
+        for b in range(B):
+            opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, RF0, P[b], [0], disc=disc)
+            Ao, meo, feo, go = opb.action_grad(XP[b], 1.5 ** 20)
+            assert abs(A[b] - Ao) <= RTOL_A * abs(Ao), (ek, b)
+            assert np.abs(g[b] - go).max() <= RTOL_G * np.abs(go).max(), (ek, b)
+
+
+def test_wide_state_minimisation_matches_oracle(capi):
+    """D = 200 (1024-thread groups): a short minimisation step for step."""
+    import va_oracle
+    from varanneal_amd import twin
+    D, N = 200, 41
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    X0, P0 = twin.initial_guess(N, D, 3, Y, Lidx)
+    XP0 = np.append(X0.ravel(), P0)
+    o = dict(OPTS, maxiter=12)
+    opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P0, [0], disc="trapezoid")
+    x, A, st, nit, nfev = opb.minimize_lbfgs(XP0, 1.5 ** 10, o)
+    pb = capi.Problem(1, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P0[None, :], [0], disc="trapezoid")
+    r = pb.minimize_lbfgs(XP0[None, :], 1.5 ** 10, o)
+    pb.close()
+    assert (r["nit"][0], r["nfev"][0], r["status"][0]) == (nit, nfev, st)
+    assert abs(r["A"][0] - A) <= 1e-6 * abs(A) and np.abs(r["x"][0] - x).max() <= 1e-6

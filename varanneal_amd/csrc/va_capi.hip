@@ -78,12 +78,13 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm)
     dm.emode = d->eval_kernel;
     // auto: column-run when a workgroup holds >= 4 lanes per column, row-strided columns for
     // wider states (their short runs would be mostly halo), flat mapping beyond 256 columns
-    if (dm.emode < 1 || dm.emode > 3) dm.emode = (D <= 64) ? 3 : ((D <= 256) ? 2 : 1);
-    if (D > 256) dm.emode = 1;                            // column mappings need a row per <=256 lanes
+    if (dm.emode < 1 || dm.emode > 3) dm.emode = (D <= 512) ? 3 : 1;
+    if (dm.emode == 2 && D > 256) dm.emode = 1;           // row-strided columns: a row per <=256 lanes
+    if (dm.emode == 3 && D > 512) dm.emode = 1;           // column runs: >= 2 lanes per column
     int tmin, tmax;
     if (dm.emode == 3) {
         // column-run kernel: T = RY*K exactly, K rows per lane in {4, 6, 8}
-        dm.RY = tile2_RY(D); dm.NT = tile2_threads(D);
+        dm.RY = tile3_RY(D); dm.NT = tile3_threads(D);
         // K = 6 keeps the kernel at 128 VGPRs (4 waves/SIMD) and measured best from 64 to 4096
         // seeds (profiles/r01_sweep_*.txt); drop to 4 when that leaves CUs without a workgroup
         int K = 6;
@@ -92,9 +93,10 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm)
             K = (d->tile_rows + dm.RY - 1) / dm.RY;
             K = K <= 4 ? 4 : (K <= 6 ? 6 : 8);
         }
+        if (dm.NT > 256 && K > 6) K = 6;                  // 1024-thread groups: 128-VGPR budget
         for (;;) {                                        // shrink until the staging arrays fit in LDS
             const size_t elems = (size_t)tile3_stage_elems(K, D, 2, dm.RY, HLR) + tile3_s_elems(K, D, 2, dm.RY);
-            if (sizeof(double) * elems <= 60 * 1024 || K == 4) break;
+            if (sizeof(double) * elems <= (D <= 64 ? 60 : 78) * 1024 || K == 4) break;   // 2 groups/CU at 1024 threads
             K -= 2;
         }
         dm.maxr = K; dm.T = dm.RY * K;
@@ -290,7 +292,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dm.disc = d->disc;
     dm.ld = ((dm.ND + dm.NPest + 15) / 16) * 16;
     pick_eval_geometry(d, dm);
-    dm.nprow = dm.emode == 3 ? dm.ntiles * 4 : dm.ntiles;
+    dm.nprow = dm.emode == 3 ? dm.ntiles * (dm.NT / 64) : dm.ntiles;
     dm.obsmask = 0ull;
     if (dm.D <= 64) for (int l = 0; l < d->L; ++l) dm.obsmask |= 1ull << d->Lidx[l];
     { const char *e = getenv("VA_DEBUG_EVAL"); dm.dbg = e ? atoi(e) : 0; }   // profiling ablations only
@@ -302,7 +304,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dv.ups = UP_OLD + 4 * m; dv.max_beta = max_beta; dv.nbeta = 1;
     dv.o.m = m; dv.o.maxiter = 15000; dv.o.maxls = 20; dv.o.maxfun = 15000; dv.o.ftol = 2.2204460492503131e-09; dv.o.gtol = 1e-5;
 
-    if (eval_lds_bytes(dm) > 64 * 1024) {
+    if (eval_lds_bytes(dm) > (dm.emode == 3 ? 160 : 64) * 1024) {
         va_problem_destroy(h);
         return fail(VA_EUNSUPPORTED, "tile of %d rows x D=%d needs %zu B of LDS (> 64 KiB); lower tile_rows", dm.T, dm.D, eval_lds_bytes(dm));
     }

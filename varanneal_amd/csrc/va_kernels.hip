@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void k_eval2(const Dev dv)
 }
 
 // ------------------------------------------------------------------ K1 (production): column-run
-template <class RHS, int DISC, int K, int DC>
-__global__ __launch_bounds__(256) void k_eval3(const Dev dv)
+template <class RHS, int DISC, int K, int DC, int NTMAX>
+__global__ __launch_bounds__(NTMAX) void k_eval3(const Dev dv)
 {
     extern __shared__ double smem[];
     const Dims &dm = dv.dm;
@@ -172,11 +172,11 @@ __global__ __launch_bounds__(256) void k_eval3(const Dev dv)
     constexpr int KP = EP_GP + RHS::NP;
     // staged double2 per lane = ceil(R / RP), RP = 2*NT/D rows per pass; <= K/2+1 for any D
     constexpr int DCs = DC > 0 ? DC : 2;
-    constexpr int RPc = 2 * tile2_threads(DCs) / DCs;
-    constexpr int NS = DC > 0 ? (tile2_RY(DCs) * K + HL + HR + RPc - 1) / RPc : K / 2 + 1;
+    constexpr int RPc = 2 * tile3_threads(DCs) / DCs;
+    constexpr int NS = DC > 0 ? (tile3_RY(DCs) * K + HL + HR + RPc - 1) / RPc : K / 2 + 1;
     // with D fixed at compile time the whole tile geometry (and every LDS offset) is constant
     const int D = DC > 0 ? DC : dm.D;
-    const int RY = DC > 0 ? tile2_RY(DC > 0 ? DC : 1) : dm.RY;
+    const int RY = DC > 0 ? tile3_RY(DC > 0 ? DC : 1) : dm.RY;
     const int T = RY * K;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int n0 = tile * T;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_eval3(const Dev dv)
     const int SE = tile3_stage_elems(K, D, G, RY, HL + HR);
     Tile3 t;
     t.n0 = n0; t.ty = ty; t.tx = tx; t.r0 = n0 + ty * K; t.use_d = (phase == PH_LS);
-    t.l = active ? obs_index(dm.obsmask, tx) : -1;
+    t.l = !active ? -1 : (D <= 64 ? obs_index(dm.obsmask, tx) : dv.pp.lmap[tx]);
     t.stp = st.stp; t.c = 2.0 * st.rf_scale * dm.cfe;
     t.xs = smem; t.ss = smem + SE;
     t.xg = xg; t.dg = dv.d + (size_t)b * dm.ld;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_eval3(const Dev dv)
     static_assert(EP_GMAX == 4 && EP_GP == 5 && RHS::NP <= 3, "butterfly slot layout");
     (void)KP;
     const int lane = tid & 63, wave = tid >> 6;
-    double *prow = dv.evp + (((size_t)b * dm.ntiles + tile) * 4 + wave) * EP_N;
+    double *prow = dv.evp + (((size_t)b * dm.ntiles + tile) * (nt >> 6) + wave) * EP_N;
     const double gm = wave_max(acc.v[EP_GMAX]);
     double v8[8];
 #pragma unroll
@@ -306,27 +306,43 @@ size_t eval_lds_bytes(const Dims &dm)
     return sizeof(double) * (elems + (256 / 64) * EP_N);
 }
 
-template <class RHS, int K, int DC>
-static void launch_eval3_rhs(const Dev &dv, hipStream_t s)
+template <class RHS, int DISC, int K, int DC, int NTMAX>
+static void launch_eval3_one(const Dev &dv, hipStream_t s)
 {
     const dim3 grid(eval_grid(dv.dm)), block(dv.dm.NT);
     const size_t lds = eval_lds_bytes(dv.dm);
+    static bool big_lds_ok = false;                       // per instantiation
+    if (lds > 64 * 1024 && !big_lds_ok) {
+        (void)hipFuncSetAttribute((const void *)k_eval3<RHS, DISC, K, DC, NTMAX>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        big_lds_ok = true;
+    }
+    hipLaunchKernelGGL((k_eval3<RHS, DISC, K, DC, NTMAX>), grid, block, lds, s, dv);
+}
+
+template <class RHS, int K, int DC, int NTMAX>
+static void launch_eval3_rhs(const Dev &dv, hipStream_t s)
+{
     switch (dv.dm.disc) {
-    case DISC_EULER: hipLaunchKernelGGL((k_eval3<RHS, DISC_EULER, K, DC>), grid, block, lds, s, dv); break;
-    case DISC_TRAPEZOID: hipLaunchKernelGGL((k_eval3<RHS, DISC_TRAPEZOID, K, DC>), grid, block, lds, s, dv); break;
-    case DISC_SH: hipLaunchKernelGGL((k_eval3<RHS, DISC_SH, K, DC>), grid, block, lds, s, dv); break;
-    default: hipLaunchKernelGGL((k_eval3<RHS, DISC_FWDMAP, K, DC>), grid, block, lds, s, dv); break;
+    case DISC_EULER: launch_eval3_one<RHS, DISC_EULER, K, DC, NTMAX>(dv, s); break;
+    case DISC_TRAPEZOID: launch_eval3_one<RHS, DISC_TRAPEZOID, K, DC, NTMAX>(dv, s); break;
+    case DISC_SH: launch_eval3_one<RHS, DISC_SH, K, DC, NTMAX>(dv, s); break;
+    default: launch_eval3_one<RHS, DISC_FWDMAP, K, DC, NTMAX>(dv, s); break;
     }
 }
 
-// D fixed at compile time for the state sizes of the reference's own Lorenz-96 examples
-// (D = 20: examples/Lorenz96_D20); any other D runs the same kernel with D in a register.
+// D fixed at compile time for the state sizes of the Lorenz-96 configurations the reference
+// and BASELINE.json name (D = 20: examples/Lorenz96_D20; D = 200: BASELINE config 4); any
+// other D runs the same kernel with D in a register.
 template <class RHS, int K>
 static void launch_eval3_d(const Dev &dv, hipStream_t s)
 {
-    if (dv.dm.D == 20) launch_eval3_rhs<RHS, K, 20>(dv, s);
-    else launch_eval3_rhs<RHS, K, 0>(dv, s);
+    if (dv.dm.D == 20) launch_eval3_rhs<RHS, K, 20, 256>(dv, s);
+    else if (dv.dm.D == 200) launch_eval3_rhs<RHS, K, 200, 1024>(dv, s);
+    else if (dv.dm.D <= 64) launch_eval3_rhs<RHS, K, 0, 256>(dv, s);
+    else launch_eval3_rhs<RHS, K, 0, 1024>(dv, s);
 }
+
 int eval_grid(const Dims &dm) { return ((dm.B * dm.ntiles + 7) / 8) * 8; }
 
 template <class RHS>

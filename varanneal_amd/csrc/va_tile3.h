@@ -60,6 +60,13 @@ struct Tile3 {
     double p[RHS_MAX_NP];
 };
 
+// workgroup geometry: RY lanes per state column; 256-thread groups up to D = 64, 1024-thread
+// groups (5 lanes per column at D = 200) beyond, so that a lane's run stays >= 4 rows and the
+// tile's halo rows stay a small fraction of the staged rows
+VA_HD constexpr int tile3_ntmax(int D) { return D <= 64 ? 256 : 1024; }
+VA_HD constexpr int tile3_RY(int D) { return tile3_ntmax(D) / D > 0 ? tile3_ntmax(D) / D : 1; }
+VA_HD constexpr int tile3_threads(int D) { return ((D * tile3_RY(D) + 63) / 64) * 64; }
+
 // geometry helpers (G = ghost columns per side)
 VA_HD constexpr int tile3_dp(int D, int G) { return D + 2 * G; }
 VA_HD constexpr int tile3_pad(int K, int D, int G) { return ((D - K * tile3_dp(D, G)) % 32 + 32) % 32; }
