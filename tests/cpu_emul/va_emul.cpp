@@ -48,7 +48,7 @@ int setup(const va_problem_desc *d, int T, Emul &E)
         if (m.disc == DISC_SH && (T & 1)) --T;
     }
     m.T = T; m.ntiles = (m.N + T - 1) / T;
-    m.nprow = m.ntiles; m.dbg = 0; m.ncu = 256;
+    m.nprow = m.ntiles; m.dbg = 0;
     m.obsmask = 0ull;
     if (m.D <= 64) for (int l = 0; l < d->L; ++l) m.obsmask |= 1ull << d->Lidx[l];
     m.chunk = 1000; m.nchunks = (m.ld + m.chunk - 1) / m.chunk;

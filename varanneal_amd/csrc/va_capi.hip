@@ -293,7 +293,6 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dm.ld = ((dm.ND + dm.NPest + 15) / 16) * 16;
     pick_eval_geometry(d, dm);
     dm.nprow = dm.emode == 3 ? dm.ntiles * (dm.NT / 64) : dm.ntiles;
-    { hipDeviceProp_t pr; dm.ncu = (hipGetDeviceProperties(&pr, d->device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
     dm.obsmask = 0ull;
     if (dm.D <= 64) for (int l = 0; l < d->L; ++l) dm.obsmask |= 1ull << d->Lidx[l];
     { const char *e = getenv("VA_DEBUG_EVAL"); dm.dbg = e ? atoi(e) : 0; }   // profiling ablations only

@@ -51,7 +51,6 @@ enum { DP_GD = 0, DP_DD = 1, DP_N = 2 };
 struct Dims {
     int D, N, ND, ld, L, N_data, nskip, NP, NPest, T, ntiles, B, m, disc, nchunks, chunk;
     int emode, RY, NT, maxr;   // eval kernel: 1 = flat-mapped, 2 = column-mapped (va_tile2.h), 3 = column-run (va_tile3.h)
-    int ncu;                   // compute units of the device (persistent-grid sizing)
     int nprow;                 // eval partial rows per seed (ntiles, or ntiles*4 when every wave writes its own)
     unsigned long long obsmask; // bit i set <=> state column i is observed (valid when D <= 64)
     int dbg;                   // ablation bits for profiling builds (env VA_DEBUG_EVAL; 0 in production):

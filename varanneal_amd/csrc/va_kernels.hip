@@ -158,168 +158,141 @@ __global__ __launch_bounds__(256) void k_eval2(const Dev dv)
 }
 
 // ------------------------------------------------------------------ K1 (production): column-run
-// Persistent workgroups: block p walks work items p, p+G, p+2G, ... (G = gridDim.x, a multiple
-// of 8 so that every item of a block maps to the same XCD range) and issues the global loads of
-// its NEXT tile right after staging the current one, so those loads are in flight during phases
-// B and C: memory and arithmetic overlap inside a workgroup instead of relying on occupancy
-// (at 1024 seeds the stage->store skeleton alone is bandwidth-bound at 61 us and phases B/C
-// added 40 us on top when nothing overlapped them).  With few tiles (C3: 896) the grid covers
-// them all and every block does exactly one tile, as before.
 template <class RHS, int DISC, int K, int DC, int NTMAX>
 __global__ __launch_bounds__(NTMAX) void k_eval3(const Dev dv)
 {
     extern __shared__ double smem[];
     const Dims &dm = dv.dm;
+    const int nwork = dm.B * dm.ntiles;
+    const int w = xcd_swizzle(blockIdx.x, nwork);
+    if (w >= nwork) return;
+    const int b = w / dm.ntiles, tile = w - b * dm.ntiles;
+
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, G = RHS::GHOST;
+    constexpr int KP = EP_GP + RHS::NP;
     // staged double2 per lane = ceil(R / RP), RP = 2*NT/D rows per pass; <= K/2+1 for any D
     constexpr int DCs = DC > 0 ? DC : 2;
     constexpr int RPc = 2 * tile3_threads(DCs) / DCs;
     constexpr int NS = DC > 0 ? (tile3_RY(DCs) * K + HL + HR + RPc - 1) / RPc : K / 2 + 1;
-    static_assert(EP_GMAX == 4 && EP_GP == 5 && RHS::NP <= 3, "butterfly slot layout");
     // with D fixed at compile time the whole tile geometry (and every LDS offset) is constant
     const int D = DC > 0 ? DC : dm.D;
     const int RY = DC > 0 ? tile3_RY(DC > 0 ? DC : 1) : dm.RY;
     const int T = RY * K;
-    const int nwork = dm.B * dm.ntiles;
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int n0 = tile * T;
+    const bool edge = (n0 - HL < 0) || (n0 + T + HR > dm.N);          // workgroup-uniform
     const bool evenD = (D & 1) == 0;
-    // per-lane invariants
+    const double *xg = dv.x + (size_t)b * dm.ld;
+
+    // phase A step 1: x loads in flight before anything else is waited for
+    double xr[NS][2];
+    if (evenD) {
+        if (edge) tile3_stage_load<DISC, K, DC, true, NS>(dm, n0, xg, tid, nt, xr);
+        else tile3_stage_load<DISC, K, DC, false, NS>(dm, n0, xg, tid, nt, xr);
+    }
+
+    const SeedState &st = dv.st[b];
+    const int phase = st.phase;
+    if (phase != PH_START && phase != PH_LS) return;
+    if (dm.dbg & 8) return;              // ablation: launch + dispatch only
+
     const int ty = tid / D, tx = tid - ty * D;
     const bool active = ty < RY;
-    const int lobs = !active ? -1 : (D <= 64 ? obs_index(dm.obsmask, tx) : dv.pp.lmap[tx]);
-    const int lane = tid & 63, wave = tid >> 6;
-    const int kcol = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
     const int SE = tile3_stage_elems(K, D, G, RY, HL + HR);
-
-    int wi = blockIdx.x;
-    int w = xcd_swizzle(wi, nwork);
-    bool valid = w < nwork;
-    int b = valid ? w / dm.ntiles : 0, tile = valid ? w - b * dm.ntiles : 0;
-    int n0 = tile * T;
-    bool edge = (n0 - HL < 0) || (n0 + T + HR > dm.N);                 // workgroup-uniform
-    double xr[NS][2];
-    // phase A step 1 for the first tile: x loads in flight before anything else is waited for
-    if (valid && evenD) {
-        if (edge) tile3_stage_load<DISC, K, DC, true, NS>(dm, n0, dv.x + (size_t)b * dm.ld, tid, nt, xr);
-        else tile3_stage_load<DISC, K, DC, false, NS>(dm, n0, dv.x + (size_t)b * dm.ld, tid, nt, xr);
-    }
-    for (;;) {
-        // next work item of this block (computed now so its loads can be issued early)
-        const int wi2 = wi + gridDim.x;
-        const int w2 = xcd_swizzle(wi2, nwork);
-        const bool valid2 = wi2 < (int)(((nwork + 7) >> 3) << 3) && w2 < nwork;
-        const int b2 = valid2 ? w2 / dm.ntiles : 0, tile2 = valid2 ? w2 - b2 * dm.ntiles : 0;
-        const int n02 = tile2 * T;
-        const bool edge2 = (n02 - HL < 0) || (n02 + T + HR > dm.N);
-
-        const SeedState &st = dv.st[b];
-        const int phase = valid ? st.phase : PH_IDLE;
-        const bool live = (phase == PH_START || phase == PH_LS) && !(dm.dbg & 8);
-        if (live) {
-            Tile3 t;
-            t.n0 = n0; t.ty = ty; t.tx = tx; t.r0 = n0 + ty * K; t.use_d = (phase == PH_LS);
-            t.l = lobs;
-            t.stp = st.stp; t.c = 2.0 * st.rf_scale * dm.cfe;
-            t.xs = smem; t.ss = smem + SE;
-            t.xg = dv.x + (size_t)b * dm.ld; t.dg = dv.d + (size_t)b * dm.ld;
-            t.gtg = dv.gt + (size_t)b * dm.ld;
-            {   // parameters (same select-chain as tile2_params)
+    Tile3 t;
+    t.n0 = n0; t.ty = ty; t.tx = tx; t.r0 = n0 + ty * K; t.use_d = (phase == PH_LS);
+    t.l = !active ? -1 : (D <= 64 ? obs_index(dm.obsmask, tx) : dv.pp.lmap[tx]);
+    t.stp = st.stp; t.c = 2.0 * st.rf_scale * dm.cfe;
+    t.xs = smem; t.ss = smem + SE;
+    t.xg = xg; t.dg = dv.d + (size_t)b * dm.ld;
+    t.gtg = dv.gt + (size_t)b * dm.ld;
+    {   // parameters (same select-chain as tile2_params)
 #pragma unroll
-                for (int k = 0; k < RHS::NP; ++k) t.p[k] = dv.pp.Pfull[(size_t)b * dm.NP + k];
-                for (int k = 0; k < dm.NPest; ++k) {
-                    double v = t.xg[dm.ND + k];
-                    if (t.use_d) v = trial(v, t.stp, t.dg[dm.ND + k]);
-                    const int dst = dv.pp.Pidx[k];
+        for (int k = 0; k < RHS::NP; ++k) t.p[k] = dv.pp.Pfull[(size_t)b * dm.NP + k];
+        for (int k = 0; k < dm.NPest; ++k) {
+            double v = t.xg[dm.ND + k];
+            if (t.use_d) v = trial(v, t.stp, t.dg[dm.ND + k]);
+            const int dst = dv.pp.Pidx[k];
 #pragma unroll
-                    for (int j = 0; j < RHS::NP; ++j) t.p[j] = (dst == j) ? v : t.p[j];
-                }
-            }
-            T3Regs<K> rg;
-            ThreadAcc acc;
-            acc.clear();
-            if (active) tile3_obs<K>(dm, dv.pp, t, rg);
-            // phase A step 2: (+ d for a line-search point) -> LDS incl. ghost columns
-            if (evenD) {
-                if (edge) {
-                    if (t.use_d) tile3_stage_store<RHS, DISC, K, DC, true, true, NS>(dm, t, tid, nt, xr);
-                    else tile3_stage_store<RHS, DISC, K, DC, true, false, NS>(dm, t, tid, nt, xr);
-                } else {
-                    if (t.use_d) tile3_stage_store<RHS, DISC, K, DC, false, true, NS>(dm, t, tid, nt, xr);
-                    else tile3_stage_store<RHS, DISC, K, DC, false, false, NS>(dm, t, tid, nt, xr);
-                }
-            } else {
-                if (t.use_d) tile3_stage_odd<RHS, DISC, K, DC, true, true>(dm, t, tid, nt);
-                else tile3_stage_odd<RHS, DISC, K, DC, true, false>(dm, t, tid, nt);
-            }
-            // prefetch: the next tile's x loads fly while this tile is computed
-            if (valid2 && evenD) {
-                if (edge2) tile3_stage_load<DISC, K, DC, true, NS>(dm, n02, dv.x + (size_t)b2 * dm.ld, tid, nt, xr);
-                else tile3_stage_load<DISC, K, DC, false, NS>(dm, n02, dv.x + (size_t)b2 * dm.ld, tid, nt, xr);
-            }
-            __syncthreads();
-            if (dm.dbg & 2) {                // ablation: copy kernel (stage -> store), no arithmetic
-                if (active && !edge)
-                    for (int k = 0; k < K; ++k)
-                        t.gtg[(long)(t.r0 + k) * D + tx] = t.xs[tile3_addr(ty * K + HL + k, tx, K, D, G, HL)];
-            } else {
-                if (active) {
-                    if (edge) tile3_rows<RHS, DISC, K, true, DC>(dm, dv.pp, t, rg, acc);
-                    else tile3_rows<RHS, DISC, K, false, DC>(dm, dv.pp, t, rg, acc);
-                }
-                __syncthreads();
-                if (active) {
-                    if (edge) tile3_grad<RHS, DISC, K, true, DC>(dm, t, rg, acc);
-                    else tile3_grad<RHS, DISC, K, false, DC>(dm, t, rg, acc);
-                }
-                // every wave writes its own partial row (no LDS, no barrier that would also
-                // wait for the gradient stores); k_ls sums the rows in a fixed order.  The 7
-                // sums go through ONE halving butterfly (10 lane exchanges instead of 7 x 6):
-                // after the xor-32/16/8 steps each lane carries one value, after xor-4/2/1
-                // its wave total.
-                double *prow = dv.evp + (((size_t)b * dm.ntiles + tile) * (nt >> 6) + wave) * EP_N;
-                const double gm = wave_max(acc.v[EP_GMAX]);
-                double v8[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v8[k] = (k == EP_GMAX || k - EP_GP >= RHS::NP) ? 0.0 : acc.v[k];
-                double w4[4], z2[2];
-                {
-                    const bool up = (lane & 32) != 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const double send = up ? v8[i] : v8[i + 4], keep = up ? v8[i + 4] : v8[i];
-                        w4[i] = keep + __shfl_xor(send, 32, 64);
-                    }
-                }
-                {
-                    const bool up = (lane & 16) != 0;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const double send = up ? w4[i] : w4[i + 2], keep = up ? w4[i + 2] : w4[i];
-                        z2[i] = keep + __shfl_xor(send, 16, 64);
-                    }
-                }
-                double y;
-                {
-                    const bool up = (lane & 8) != 0;
-                    const double send = up ? z2[0] : z2[1], keep = up ? z2[1] : z2[0];
-                    y = keep + __shfl_xor(send, 8, 64);
-                }
-                y += __shfl_xor(y, 4, 64);
-                y += __shfl_xor(y, 2, 64);
-                y += __shfl_xor(y, 1, 64);
-                // lane with bits (5,4,3) = k holds the total of value k
-                if ((lane & 7) == 0 && kcol != EP_GMAX && kcol - EP_GP < RHS::NP) prow[kcol] = y;
-                if (lane == 0) prow[EP_GMAX] = gm;
-            }
-        } else if (valid2 && evenD) {
-            // this seed is finished: nothing to compute, but keep the pipeline primed
-            if (edge2) tile3_stage_load<DISC, K, DC, true, NS>(dm, n02, dv.x + (size_t)b2 * dm.ld, tid, nt, xr);
-            else tile3_stage_load<DISC, K, DC, false, NS>(dm, n02, dv.x + (size_t)b2 * dm.ld, tid, nt, xr);
+            for (int j = 0; j < RHS::NP; ++j) t.p[j] = (dst == j) ? v : t.p[j];
         }
-        if (!valid2) break;
-        __syncthreads();                     // all lanes are done with this tile's LDS image
-        wi = wi2; w = w2; valid = valid2; b = b2; tile = tile2; n0 = n02; edge = edge2;
     }
+    T3Regs<K> rg;
+    ThreadAcc acc;
+    acc.clear();
+    if (active) tile3_obs<K>(dm, dv.pp, t, rg);
+    // phase A step 2: (+ d for a line-search point) -> LDS incl. ghost columns
+    if (evenD) {
+        if (edge) {
+            if (t.use_d) tile3_stage_store<RHS, DISC, K, DC, true, true, NS>(dm, t, tid, nt, xr);
+            else tile3_stage_store<RHS, DISC, K, DC, true, false, NS>(dm, t, tid, nt, xr);
+        } else {
+            if (t.use_d) tile3_stage_store<RHS, DISC, K, DC, false, true, NS>(dm, t, tid, nt, xr);
+            else tile3_stage_store<RHS, DISC, K, DC, false, false, NS>(dm, t, tid, nt, xr);
+        }
+    } else {
+        if (t.use_d) tile3_stage_odd<RHS, DISC, K, DC, true, true>(dm, t, tid, nt);
+        else tile3_stage_odd<RHS, DISC, K, DC, true, false>(dm, t, tid, nt);
+    }
+    __syncthreads();
+    if (dm.dbg & 2) {                    // ablation: copy kernel (stage -> store), no arithmetic
+        if (active && !edge)
+            for (int k = 0; k < K; ++k)
+                t.gtg[(long)(t.r0 + k) * D + tx] = t.xs[tile3_addr(ty * K + HL + k, tx, K, D, G, HL)];
+        return;
+    }
+    if (active) {
+        if (edge) tile3_rows<RHS, DISC, K, true, DC>(dm, dv.pp, t, rg, acc);
+        else tile3_rows<RHS, DISC, K, false, DC>(dm, dv.pp, t, rg, acc);
+    }
+    __syncthreads();
+    if (active) {
+        if (edge) tile3_grad<RHS, DISC, K, true, DC>(dm, t, rg, acc);
+        else tile3_grad<RHS, DISC, K, false, DC>(dm, t, rg, acc);
+    }
+
+    // every wave writes its own partial row (no LDS, no barrier: a __syncthreads here would
+    // also wait for the gradient stores to land); k_ls sums the rows in a fixed order.
+    // The 7 sums go through ONE halving butterfly (10 lane exchanges instead of 7 x 6): after
+    // the xor-32/16/8 steps each lane carries one value, after xor-4/2/1 its wave total.
+    static_assert(EP_GMAX == 4 && EP_GP == 5 && RHS::NP <= 3, "butterfly slot layout");
+    (void)KP;
+    const int lane = tid & 63, wave = tid >> 6;
+    double *prow = dv.evp + (((size_t)b * dm.ntiles + tile) * (nt >> 6) + wave) * EP_N;
+    const double gm = wave_max(acc.v[EP_GMAX]);
+    double v8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v8[k] = (k == EP_GMAX || k - EP_GP >= RHS::NP) ? 0.0 : acc.v[k];
+    double w4[4], z2[2];
+    {
+        const bool up = (lane & 32) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double send = up ? v8[i] : v8[i + 4], keep = up ? v8[i + 4] : v8[i];
+            w4[i] = keep + __shfl_xor(send, 32, 64);
+        }
+    }
+    {
+        const bool up = (lane & 16) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double send = up ? w4[i] : w4[i + 2], keep = up ? w4[i + 2] : w4[i];
+            z2[i] = keep + __shfl_xor(send, 16, 64);
+        }
+    }
+    double y;
+    {
+        const bool up = (lane & 8) != 0;
+        const double send = up ? z2[0] : z2[1], keep = up ? z2[1] : z2[0];
+        y = keep + __shfl_xor(send, 8, 64);
+    }
+    y += __shfl_xor(y, 4, 64);
+    y += __shfl_xor(y, 2, 64);
+    y += __shfl_xor(y, 1, 64);
+    // lane with bits (5,4,3) = k holds the total of value k
+    const int kcol = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+    if ((lane & 7) == 0 && kcol != EP_GMAX && kcol - EP_GP < RHS::NP) prow[kcol] = y;
+    if (lane == 0) prow[EP_GMAX] = gm;
 }
 
 size_t eval_lds_bytes(const Dims &dm)
@@ -370,14 +343,7 @@ static void launch_eval3_d(const Dev &dv, hipStream_t s)
     else launch_eval3_rhs<RHS, K, 0, 1024>(dv, s);
 }
 
-int eval_grid(const Dims &dm)
-{
-    const int all = ((dm.B * dm.ntiles + 7) / 8) * 8;
-    if (dm.emode != 3) return all;
-    // persistent column-run kernel: at most ~the resident capacity of the chip
-    const int cap = dm.ncu * (dm.NT > 256 ? 2 : 4);
-    return all < cap ? all : (cap / 8) * 8;
-}
+int eval_grid(const Dims &dm) { return ((dm.B * dm.ntiles + 7) / 8) * 8; }
 
 template <class RHS>
 static void launch_eval_rhs(const Dev &dv, hipStream_t s)
