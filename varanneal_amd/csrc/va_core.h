@@ -546,7 +546,7 @@ VA_HD void ls_step(SeedHot &s, const double *ev, const double *dirp, const Opts 
     begin_linesearch(s);
 }
 
-// K4: Gram update + two-loop recursion carried out in coefficient space.
+// K4: Gram update + L-BFGS direction in coefficient space (compact two-loop).
 // up[] = update-kernel dot products (UP_* layout, old slots in order[0..nold)).
 // Produces d = cg*g + sum_j cY[slot]*Y[slot] + cS[slot]*S[slot].
 // Works on a view so that the device can run it on LDS copies (k_coeffs) and the
@@ -582,27 +582,34 @@ VA_HD void direction_coeffs_view(const CoefView &s, const double *up)
         s.b[j] = up[UP_OLD + 4 * j + 1];                         // Y_j . g
     }
     if (hist) { s.a[col - 1] = up[UP_SGT]; s.b[col - 1] = up[UP_YGT]; }
+    // The two-loop recursion in its compact form (Byrd, Nocedal & Schnabel 1994): with
+    // R_ij = S_i.Y_j (i <= j, oldest first), D = diag(R), a = S^T g, b = Y^T g,
+    //     p = R^{-1} a,   q = (D + gamma Y^T Y) p - gamma b,   u = R^{-T} q,
+    //     d = -H g = -gamma g - S u + gamma Y p.
+    // Both triangular solves are written column-oriented (solve one unknown, then update the
+    // remaining right-hand sides): that is the form k_coeffs runs with one lane per pair.
     const double gamma = 1.0 / *s.theta;
-    double *c = s.c, *e = s.e, *al = s.al;
-    for (int j = 0; j < col; ++j) { c[j] = 0.0; e[j] = 0.0; }
-    for (int i = col - 1; i >= 0; --i) {                         // newest -> oldest
+    double *p = s.c, *q = s.e, *rhs = s.al;
+    for (int j = 0; j < col; ++j) rhs[j] = s.a[j];
+    for (int i = col - 1; i >= 0; --i) {                         // back substitution, R upper
         const int si = s.order[i];
-        double sq = s.a[i];
-        for (int j = i + 1; j < col; ++j) sq += c[j] * s.SY[si * M + s.order[j]];
-        al[i] = sq / s.SY[si * M + si];
-        c[i] = -al[i];
+        p[i] = rhs[i] * (1.0 / s.SY[si * M + si]);
+        for (int j = 0; j < i; ++j) rhs[j] -= s.SY[s.order[j] * M + si] * p[i];
     }
-    for (int i = 0; i < col; ++i) {                              // oldest -> newest
+    for (int i = 0; i < col; ++i) {
         const int si = s.order[i];
-        double yr = s.b[i];
-        for (int j = 0; j < col; ++j) yr += c[j] * s.YY[si * M + s.order[j]];
-        yr *= gamma;
-        for (int j = 0; j < i; ++j) yr += e[j] * s.SY[s.order[j] * M + si];
-        e[i] = al[i] - yr / s.SY[si * M + si];
+        double acc = 0.0;
+        for (int k = 0; k < col; ++k) acc += s.YY[si * M + s.order[k]] * p[k];
+        q[i] = s.SY[si * M + si] * p[i] + gamma * acc - gamma * s.b[i];
+    }
+    for (int i = 0; i < col; ++i) {                              // forward substitution, R^T lower
+        const int si = s.order[i];
+        q[i] = q[i] * (1.0 / s.SY[si * M + si]);                 // u_i
+        for (int j = i + 1; j < col; ++j) q[j] -= s.SY[si * M + s.order[j]] * q[i];
     }
     *s.cg = -gamma;
     for (int j = 0; j < MAX_M; ++j) { s.cY[j] = 0.0; s.cS[j] = 0.0; }
-    for (int j = 0; j < col; ++j) { s.cY[s.order[j]] = -gamma * c[j]; s.cS[s.order[j]] = -e[j]; }
+    for (int j = 0; j < col; ++j) { s.cY[s.order[j]] = gamma * p[j]; s.cS[s.order[j]] = -q[j]; }
 }
 
 VA_HD void direction_coeffs(SeedState &s, const double *up, const Opts &o)

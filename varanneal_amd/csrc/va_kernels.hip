@@ -643,28 +643,39 @@ void launch_update(const Dev &dv, hipStream_t s)
 }
 
 // ------------------------------------------------------------------ K4: direction coefficients
-// One wave per seed: Gram update + two-loop recursion in coefficient space
-// (va_core.h: direction_coeffs_view -- the code the CPU emulator also runs).  Everything it
-// touches is staged in LDS by the whole wave first, so the O(m^2) scalar recursion runs on
-// LDS operands instead of a chain of dependent global loads; results go back coalesced.
+// wave-uniform broadcast of lane i's double through SGPRs (v_readlane), i uniform
+__device__ __forceinline__ double bcast_lane(double x, int i)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), i);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), i);
+    return __hiloint2double(hi, lo);
+}
+
+// One wave per seed, lane j <-> j-th oldest history pair: Gram update, then the compact
+// form of the two-loop recursion (va_core.h: direction_coeffs_view, which the CPU emulator
+// runs serially):  p = R^-1 a,  q = (D + gamma Y'Y) p - gamma b,  u = R^-T q,
+// d = -gamma g - S u + gamma Y p.  Both triangular solves are column-oriented, so a step is
+// one SGPR broadcast + one fused update per lane -- no cross-lane reductions and no serial
+// O(m^2) loop (the serial form took 17-40 us per cycle; this one is latency of 2m short steps).
 __global__ __launch_bounds__(64) void k_coeffs(const Dev dv)
 {
     __shared__ double up[UP_N];
     __shared__ double sSY[MAX_M * MAX_M], sYY[MAX_M * MAX_M];
-    __shared__ double wk[7 * MAX_M];                      // a, b, cY, cS, c, e, al
-    __shared__ int sorder[MAX_M];
-    __shared__ double sc[2];                              // theta, cg
+    __shared__ double sp[MAX_M], cYs[MAX_M], cSs[MAX_M];
     const int b = blockIdx.x, lane = threadIdx.x;
     SeedState &s = dv.st[b];
     if (!s.dir) return;
     const Dims &dm = dv.dm;
     const int M = MAX_M, m = dm.m;
-    const int nold = s.nold;
+    const int nold = s.nold, col = s.col, sn = s.slot;
+    const bool hist = (s.upd & UPD_HIST) != 0;
+    const double dr = s.dr;
+    double theta = s.theta;
     const int K = UP_OLD + 4 * nold;
     for (int k = lane; k < K; k += 64)
         up[k] = col_reduce(dv.upp + (size_t)b * dm.nchunks * dv.ups + k, dm.nchunks, dv.ups, 0, 1, false);
-    if (lane < M) sorder[lane] = s.order[lane];
-    {   // the m x m blocks of the Gram matrices: two independent loads per lane per pass
+    const int myslot = lane < col ? s.order[lane] : 0;
+    {   // the m x m blocks of the Gram matrices: independent loads first, LDS stores after
         double t0[4], t1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -684,23 +695,57 @@ __global__ __launch_bounds__(64) void k_coeffs(const Dev dv)
             sSY[i * M + j] = s.SY[i * M + j]; sYY[i * M + j] = s.YY[i * M + j];
         }
     }
-    if (lane == 0) { sc[0] = s.theta; sc[1] = s.cg; }
+    if (lane < M) { cYs[lane] = 0.0; cSs[lane] = 0.0; }
     __syncthreads();
-    if (lane == 0) {
-        CoefView v;
-        v.upd = s.upd; v.slot = s.slot; v.nold = nold; v.col = s.col; v.order = sorder; v.dr = s.dr;
-        v.theta = &sc[0]; v.cg = &sc[1]; v.SY = sSY; v.YY = sYY;
-        v.a = wk; v.b = wk + M; v.cY = wk + 2 * M; v.cS = wk + 3 * M;
-        v.c = wk + 4 * M; v.e = wk + 5 * M; v.al = wk + 6 * M;
-        direction_coeffs_view(v, up);
+    if (hist) {
+        // new column/row of the Gram matrices (LDS copy and the persistent one)
+        if (lane < nold) {
+            const double sjy = up[UP_OLD + 4 * lane + 2], yjy = up[UP_OLD + 4 * lane + 3];
+            sSY[myslot * M + sn] = sjy; sYY[myslot * M + sn] = yjy; sYY[sn * M + myslot] = yjy;
+            s.SY[myslot * M + sn] = sjy; s.YY[myslot * M + sn] = yjy; s.YY[sn * M + myslot] = yjy;
+        }
+        if (lane == 0) {
+            sSY[sn * M + sn] = dr; sYY[sn * M + sn] = up[UP_YY];   // s.y as the line search saw it
+            s.SY[sn * M + sn] = dr; s.YY[sn * M + sn] = up[UP_YY];
+        }
+        theta = up[UP_YY] / dr;
     }
     __syncthreads();
-    for (int e = lane; e < m * m; e += 64) {
-        const int i = e / m, j = e - i * m;
-        s.SY[i * M + j] = sSY[i * M + j]; s.YY[i * M + j] = sYY[i * M + j];
+    double aj = 0.0, bj = 0.0;
+    if (lane < nold) { aj = up[UP_OLD + 4 * lane + 0]; bj = up[UP_OLD + 4 * lane + 1]; }
+    if (hist && lane == col - 1) { aj = up[UP_SGT]; bj = up[UP_YGT]; }
+    const double gamma = 1.0 / theta;
+    const double rjj = lane < col ? sSY[myslot * M + myslot] : 1.0;
+    const double rinv = 1.0 / rjj;
+    // p = R^-1 a  (R_ji = S_j . Y_i for j <= i)
+    double pj = 0.0;
+    for (int i = col - 1; i >= 0; --i) {
+        const int si = __builtin_amdgcn_readlane(myslot, i);
+        const double pi = bcast_lane(aj * rinv, i);
+        if (lane == i) pj = pi;
+        if (lane < i) aj -= sSY[myslot * M + si] * pi;
     }
-    if (lane < M) { s.cY[lane] = wk[2 * M + lane]; s.cS[lane] = wk[3 * M + lane]; }
-    if (lane == 0) { s.theta = sc[0]; s.cg = sc[1]; }
+    if (lane < M) sp[lane] = pj;
+    __syncthreads();
+    // q = (D + gamma Y'Y) p - gamma b
+    double qj = 0.0;
+    if (lane < col) {
+        double acc = 0.0;
+        for (int k = 0; k < col; ++k) acc += sYY[myslot * M + __builtin_amdgcn_readlane(myslot, k)] * sp[k];
+        qj = rjj * pj + gamma * acc - gamma * bj;
+    }
+    // u = R^-T q  ((R^T)_ji = R_ij = S_i . Y_j for i <= j)
+    double uj = 0.0;
+    for (int i = 0; i < col; ++i) {
+        const int si = __builtin_amdgcn_readlane(myslot, i);
+        const double ui = bcast_lane(qj * rinv, i);
+        if (lane == i) uj = ui;
+        if (lane > i && lane < col) qj -= sSY[si * M + myslot] * ui;
+    }
+    if (lane < col) { cYs[myslot] = gamma * pj; cSs[myslot] = -uj; }
+    __syncthreads();
+    if (lane < M) { s.cY[lane] = cYs[lane]; s.cS[lane] = cSs[lane]; }
+    if (lane == 0) { s.cg = -gamma; s.theta = theta; }
 }
 void launch_coeffs(const Dev &dv, hipStream_t s)
 {
