@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VA_ABI_VERSION 1
+#define VA_ABI_VERSION 2
 
 enum { VA_OK = 0, VA_EINVAL = -1, VA_ENOMEM = -2, VA_EHIP = -3, VA_EUNSUPPORTED = -4,
        VA_ESTATE = -5 };
@@ -40,9 +40,12 @@ enum { VA_OK = 0, VA_EINVAL = -1, VA_ENOMEM = -2, VA_EHIP = -3, VA_EUNSUPPORTED 
 enum { VA_DISC_EULER = 0, VA_DISC_TRAPEZOID = 1, VA_DISC_SIMPSON_HERMITE = 2,
        VA_DISC_FORWARDMAP = 3 };
 
-/* built-in right-hand sides (the user `f(t,x,p)` of set_model, va_ode.py:56-67).
- * LORENZ96: examples/Lorenz96_D20/Lorenz96_anneal.py:15-16, NP = 1 (forcing k). */
-enum { VA_RHS_LORENZ96 = 0 };
+/* right-hand sides (the user `f(t,x,p)` of set_model, va_ode.py:56-67).
+ * LORENZ96: built in; examples/Lorenz96_D20/Lorenz96_anneal.py:15-16, NP = 1 (forcing k).
+ * ids >= VA_RHS_USER_BASE: generated-code modules registered with va_rhs_load_module
+ * (varanneal_amd/codegen.py traces the user's Python callable, emits f, J^T v and
+ * (df/dp)^T v as HIP and compiles them for gfx950). */
+enum { VA_RHS_LORENZ96 = 0, VA_RHS_USER_BASE = 1000 };
 
 enum { VA_MEM_HOST = 0, VA_MEM_DEVICE = 1 };
 
@@ -77,7 +80,10 @@ typedef struct va_problem_desc {
     int32_t max_beta;         /* longest ladder va_anneal will be asked for (>=1)    */
     int32_t keep_paths;       /* 1: keep every beta step's path on device (minpaths) */
     int32_t tile_rows;        /* 0 = auto; time rows per workgroup                   */
-    int32_t eval_kernel;      /* 0 = auto; 1 = flat-mapped, 2 = column-mapped tile kernel */
+    int32_t eval_kernel;      /* 0 = auto; 1 = flat-mapped, 2 = column-mapped, 3 = column-run tile kernel */
+    const double *t_model;    /* NULL or [N_model]: times passed to a non-autonomous RHS (va_ode.py:553,558) */
+    const double *stim;       /* NULL or [N_model*n_stim]: external stimulus rows, f(t,x,(p,stim)) (va_ode.py:345-375) */
+    int32_t n_stim;
     void *stream;             /* hipStream_t to run on; NULL = library-owned stream  */
 } va_problem_desc;
 
@@ -94,6 +100,10 @@ typedef struct va_lbfgs_opts {
 int32_t va_abi_version(void);
 const char *va_last_error(void);
 int va_device_count(int32_t *count);
+
+/* Register a compiled right-hand-side module (a shared object built from
+ * varanneal_amd/csrc/va_user_rhs.hip + a generated header); returns its rhs id. */
+int va_rhs_load_module(const char *path, int32_t *rhs_id);
 
 int va_problem_create(const va_problem_desc *desc, va_handle *out);
 void va_problem_destroy(va_handle h);

@@ -144,6 +144,73 @@ def ladder_case(va, name, Y, t, Lidx, N, disc, nbeta, seed_index, D=20):
     return rec
 
 
+def nakl_cases(va):
+    """g5: the tutorial's NaKL neuron model (D=4, 18 parameters, external stimulus,
+    per-component RF0; VarAnneal_tutorial.ipynb "NaKL") on windows of the reference's own
+    data/stimulus files -- single evaluations with complex-step gradients, and one short
+    bounded ladder through the reference's anneal() + SciPy (gradient: complex-step)."""
+    import adolc
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from models.nakl import PB, STATE_BOUNDS, nakl
+    base = os.path.join(_refload.REF_ROOT, "examples", "jupyter-tutorial", "NaKL", "data")
+    data = np.load(os.path.join(base, "NaKL_Vdata_dt0p02_N6001_sm1p0.npy"))
+    stimf = np.load(os.path.join(base, "NaKL_stim_dt0p02_N6001.npy"))
+    out = {}
+
+    def setup(N, n0=1000):
+        t = data[n0:n0 + N, 0]
+        Y = data[n0:n0 + N, 1:][:, [0]]
+        st = stimf[n0:n0 + N, 1]
+        a = va.Annealer()
+        a.set_model(nakl, 4)
+        a.set_data(Y, stim=st, t=t)
+        return a, t, Y, st
+
+    rng = np.random.RandomState(77)
+    for disc, N, nb in (("SimpsonHermite", 301, 41), ("trapezoid", 300, 81)):
+        a, t, Y, st = setup(N)
+        X0 = 0.2 * rng.rand(N, 4) + 0.4
+        P0 = np.array([b[0] + (b[1] - b[0]) * rng.rand() for b in PB])
+        with quiet():
+            a.anneal_init(X0, P0.copy(), 1.1, np.arange(nb), 1.0, [1.0e-8, 1.0e-4, 1.0e-4, 1.0e-4], [0],
+                          list(range(18)), dt_model=None, init_to_data=True, disc=disc)
+        for rfs in (1.0, 1.1 ** (nb - 1)):
+            a.RF = a.RF0 * rfs
+            XP = a.minpaths[0].copy()
+            rec = dict(XP=XP, Y=Y, t=t, stim=st, D=4, N_model=N, dt_model=float(a.dt_model), disc=disc,
+                       RM=1.0, RF0=np.array([1.0e-8, 1.0e-4, 1.0e-4, 1.0e-4]), rf_scale=float(rfs),
+                       A=float(a.A(XP)), me=float(a.me_gaussian(XP[:N * 4])), fe=float(a.fe_gaussian(XP)),
+                       grad=_refload.complex_step_grad(a.A, XP))
+            name = "g5_nakl_%s_rf%.0e" % (disc, rfs)
+            out[name] = rec
+            print("%-32s A=%.16e fe=%.6e |g|max=%.3e" % (name, rec["A"], rec["fe"], np.abs(rec["grad"]).max()))
+
+    # bounded ladder (tutorial flow, shortened): N=101, 8 steps of alpha=1.5 from beta=20
+    N, nb = 101, 8
+    betas = np.arange(20, 20 + 2 * nb, 2)
+    a, t, Y, st = setup(N)
+    X0 = 0.2 * rng.rand(N, 4) + 0.4
+    P0 = np.array([b[0] + (b[1] - b[0]) * rng.rand() for b in PB])
+    bounds = [list(b) for b in STATE_BOUNDS] + [list(b) for b in PB]
+    adolc.function = lambda _id, XP: a.A(XP)
+    adolc.gradient = lambda _id, XP: _refload.complex_step_grad(a.A, np.asarray(XP, dtype=np.float64))
+    opts = {'gtol': 1.0e-8, 'ftol': 1.0e-8, 'maxfun': 1000000, 'maxiter': 1000000}
+    X0in = X0.copy()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        a.anneal(X0, P0.copy(), 1.5, betas, 1.0, [1.0e-8, 1.0e-4, 1.0e-4, 1.0e-4], [0],
+                 list(range(18)), dt_model=None, init_to_data=True, disc="SimpsonHermite",
+                 method='L-BFGS-B', opt_args=opts, adolcID=0, bounds=bounds)
+    nit = [int(l.split("=")[1]) for l in buf.getvalue().splitlines() if l.startswith("Iterations")]
+    out["g5_nakl_ladder_SH_N101"] = dict(
+        Y=Y, t=t, stim=st, X0=X0in, P0=P0, alpha=1.5, beta=betas, N=N, D=4,
+        RF0=np.array([1.0e-8, 1.0e-4, 1.0e-4, 1.0e-4]), bounds=np.array(bounds),
+        A_array=a.A_array.copy(), me_array=a.me_array.copy(), fe_array=a.fe_array.copy(),
+        params=a.minpaths[:, N * 4:].copy(), final_path=a.minpaths[-1, :N * 4].copy(), nit=np.array(nit))
+    print("g5_nakl_ladder_SH_N101  A=%s nit=%s" % (a.A_array, nit))
+    return out
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     va = _refload.load_reference("va_ode")
@@ -167,6 +234,12 @@ def main():
         for k, v in rec.items():
             flat["%s/%s" % (cname, k)] = v
     np.savez_compressed(os.path.join(GOLD, "ladders.npz"), **flat)
+
+    flat = {}
+    for cname, rec in nakl_cases(va).items():
+        for k, v in rec.items():
+            flat["%s/%s" % (cname, k)] = v
+    np.savez_compressed(os.path.join(GOLD, "nakl.npz"), **flat)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 

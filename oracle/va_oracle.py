@@ -200,6 +200,50 @@ class Problem(object):
         return me + fe, me, fe
 
 
+def numpy_action_generic(f, XP, D, N, Y, Lidx, dt, RM, RF, NP, Pidx, P, disc, t_model=None, stim=None,
+                         nskip=1):
+    """The reference's action (va_ode.py:130-234, 341-454) for an arbitrary user `f`, array op
+    for array op, including the stimulus tuple convention (:345-375).  Type-polymorphic, so a
+    complex XP gives complex-step derivatives.  RM: scalar or (N_data,L); RF: scalar or (N-1,D)."""
+    x = np.reshape(XP[:N * D], (N, D))
+    p = np.array(P, dtype=XP.dtype)
+    p[list(Pidx)] = XP[N * D:]
+    t = np.zeros(N) if t_model is None else np.asarray(t_model)
+    diff = x[::nskip, list(Lidx)] - Y
+    me = (np.sum(RM * diff * diff) if isinstance(RM, np.ndarray) else RM * np.sum(diff * diff)) / (len(Lidx) * Y.shape[0])
+    arg = (lambda sl: p) if stim is None else (lambda sl: (p, stim[sl]))
+    arr = isinstance(RF, np.ndarray)
+    if disc == "SimpsonHermite":
+        a, m_, b = slice(None, -2, 2), slice(1, -1, 2), slice(2, None, 2)
+        fn, fmid, fnp1 = f(t[a], x[a], arg(a)), f(t[m_], x[m_], arg(m_)), f(t[b], x[b], arg(b))
+        v1 = (fn + 4.0 * fmid + fnp1) * (2.0 * dt) / 6.0
+        v2 = (x[a] + x[b]) / 2.0 + (fn - fnp1) * (2.0 * dt) / 8.0
+        d1 = x[2::2] - x[:-2:2] - v1
+        d2 = x[1::2] - v2
+        fe = (np.sum(RF[::2] * d1 * d1) + np.sum(RF[1::2] * d2 * d2)) if arr else RF * np.sum(d1 * d1 + d2 * d2)
+    else:
+        a, b = slice(None, -1), slice(1, None)
+        if disc == "trapezoid":
+            d = x[1:] - x[:-1] - dt * (f(t[a], x[a], arg(a)) + f(t[b], x[b], arg(b))) / 2.0
+        elif disc == "euler":
+            d = x[1:] - x[:-1] - dt * f(t[a], x[a], arg(a))
+        else:
+            d = x[1:] - f(t[a], x[a], arg(a))
+        fe = np.sum(RF * d * d) if arr else RF * np.sum(d * d)
+    fe = fe / (D * (N - 1))
+    return me + fe, me, fe
+
+
+def complex_step_grad(fun, XP, h=1e-30):
+    z = np.asarray(XP, dtype=np.complex128).copy()
+    g = np.empty(len(z))
+    for i in range(len(z)):
+        z[i] = complex(XP[i], h)
+        g[i] = fun(z)[0].imag / h
+        z[i] = XP[i]
+    return g
+
+
 def scipy_ladder(pb, XP0, alpha, beta_array, opt_args):
     """Reference control flow (va_ode.py:707-789 + _autodiffmin.py:85-86) with
     the C oracle as A_gradA_taped and SciPy's own L-BFGS-B as the minimiser."""

@@ -13,6 +13,9 @@
 #include "../../varanneal_amd/csrc/va_core.h"
 #include "../../varanneal_amd/csrc/va_tile2.h"
 #include "../../varanneal_amd/csrc/va_tile3.h"
+#ifdef VA_USER_RHS_HEADER
+#include VA_USER_RHS_HEADER      // generated RhsUser (varanneal_amd/codegen.py)
+#endif
 
 using namespace va;
 
@@ -22,7 +25,7 @@ struct Emul {
     Dims dm;
     ProblemPtrs pp;
     std::vector<int> lmap, pidx;
-    std::vector<double> Y, rm, rf0, P;
+    std::vector<double> Y, rm, rf0, P, tm, stim;
     int rhs;
 };
 
@@ -65,6 +68,11 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     E.pp.rm_arr = d->rm_kind ? E.rm.data() : nullptr;
     E.pp.rf0_arr = d->rf_kind ? E.rf0.data() : nullptr;
     E.pp.Pidx = E.pidx.data(); E.pp.Pfull = E.P.data();
+    if (d->t_model) E.tm.assign(d->t_model, d->t_model + m.N);
+    if (d->n_stim > 0) E.stim.assign(d->stim, d->stim + (size_t)m.N * d->n_stim);
+    E.pp.tmodel = d->t_model ? E.tm.data() : nullptr;
+    E.pp.stim = d->n_stim > 0 ? E.stim.data() : nullptr; E.pp.nstim = d->n_stim;
+    if (d->rhs >= VA_RHS_USER_BASE) m.emode = 1;
     E.rhs = d->rhs;
     if (m.disc == DISC_SH && (m.N % 2) == 0) return VA_EINVAL;
     return VA_OK;
@@ -86,6 +94,7 @@ void eval_seed(const Emul &E, int b, const double *x, const double *d, int use_d
         c.n0 = tile * dm.T; c.R = R; c.use_d = use_d; c.stp = stp; c.c = 2.0 * rf_scale * dm.cfe;
         c.xs = xs.data(); c.fs = fs.data(); c.qs = qs.data();
         c.xg = x; c.dg = d; c.gtg = gt;
+        c.tmodel = E.pp.tmodel; c.stim = E.pp.stim; c.nstim = E.pp.nstim;
         tile_params<RHS>(dm, E.pp, b, c);
         std::vector<ThreadAcc> acc(NT);
         for (auto &a : acc) a.clear();
@@ -205,6 +214,9 @@ template <int DISC>
 void eval_seed_rhs(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
                    double rf_scale, double *gt, double *ev)
 {
+#ifdef VA_USER_RHS_HEADER
+    if (E.rhs >= VA_RHS_USER_BASE) { eval_seed<RhsUser, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev); return; }
+#endif
     if (E.dm.emode == 3) {
         if (E.dm.maxr == 4) eval_seed3<RhsL96g, DISC, 4>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
         else if (E.dm.maxr == 6) eval_seed3<RhsL96g, DISC, 6>(E, b, x, d, use_d, stp, rf_scale, gt, ev);

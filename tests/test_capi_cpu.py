@@ -31,7 +31,22 @@ def test_every_declared_symbol_is_exported(capi):
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(capi.EXPORTS) == names
-    assert lib.va_abi_version() == 1
+    assert lib.va_abi_version() == 2
+
+
+def test_rhs_module_loader_rejects_bad_paths(capi, tmp_path):
+    lib = capi.lib()
+    rid = C.c_int(-7)
+    assert lib.va_rhs_load_module(None, C.byref(rid)) == -1
+    assert lib.va_rhs_load_module(str(tmp_path / "nope.so").encode(), C.byref(rid)) != 0
+    assert lib.va_last_error()
+    # a shared object without the module entry points is refused, not half-registered
+    src = tmp_path / "e.c"
+    src.write_text("int unrelated(void){return 0;}\n")
+    so = tmp_path / "e.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+    assert lib.va_rhs_load_module(str(so).encode(), C.byref(rid)) != 0
+    assert b"va_user" in lib.va_last_error()
 
 
 def test_struct_layout_matches_header(capi, tmp_path):

@@ -44,7 +44,8 @@ class ProblemDesc(C.Structure):
                 ("NP", C.c_int32), ("NPest", C.c_int32), ("Pidx", c_ip), ("P", c_dp),
                 ("disc", C.c_int32), ("rhs", C.c_int32), ("lbfgs_m", C.c_int32),
                 ("max_beta", C.c_int32), ("keep_paths", C.c_int32), ("tile_rows", C.c_int32),
-                ("eval_kernel", C.c_int32), ("stream", C.c_void_p)]
+                ("eval_kernel", C.c_int32), ("t_model", c_dp), ("stim", c_dp), ("n_stim", C.c_int32),
+                ("stream", C.c_void_p)]
 
 
 class LbfgsOpts(C.Structure):
@@ -66,7 +67,7 @@ def _f64(a):
 
 def make_desc(batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, disc="trapezoid",
               rhs="lorenz96", merr_nskip=1, lbfgs_m=10, max_beta=1, keep_paths=0, tile_rows=0,
-              eval_kernel=0, device=0, stream=None):
+              eval_kernel=0, device=0, stream=None, t_model=None, stim=None):
     """Build a ProblemDesc plus the list of arrays that must outlive it."""
     Y = _f64(Y)
     N_data, L = Y.shape
@@ -103,9 +104,24 @@ def make_desc(batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, disc="trap
     d.Pidx = Pidx.ctypes.data_as(c_ip)
     d.P = P.ctypes.data_as(c_dp)
     d.disc = DISC[disc] if isinstance(disc, str) else int(disc)
-    d.rhs = RHS[rhs] if isinstance(rhs, str) else int(rhs)
+    d.rhs = RHS[rhs] if isinstance(rhs, str) else int(rhs)      # int: a module id from load_rhs_module
     d.lbfgs_m, d.max_beta, d.keep_paths, d.tile_rows = lbfgs_m, max_beta, keep_paths, tile_rows
     d.eval_kernel = eval_kernel
+    if t_model is not None:
+        tm = _f64(t_model)
+        if tm.shape != (N_model,):
+            raise ValueError("t_model must have shape (N_model,)")
+        keep.append(tm)
+        d.t_model = tm.ctypes.data_as(c_dp)
+    else:
+        d.t_model = None
+    if stim is not None:
+        st = _f64(stim)
+        st = st.reshape(N_model, -1)
+        keep.append(st)
+        d.stim, d.n_stim = st.ctypes.data_as(c_dp), st.shape[1]
+    else:
+        d.stim, d.n_stim = None, 0
     d.stream = stream
     return d, keep
 
@@ -130,6 +146,7 @@ def lib():
     L.va_last_error.restype = C.c_char_p
     L.va_device_count.argtypes = [c_ip]
     L.va_problem_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(h)]
+    L.va_rhs_load_module.argtypes = [C.c_char_p, c_ip]
     L.va_problem_destroy.argtypes = [h]
     L.va_problem_destroy.restype = None
     L.va_problem_info.argtypes = [h, c_lp, c_lp, c_ip, c_ip]
@@ -142,7 +159,7 @@ def lib():
     L.va_get_minpath.argtypes = [h, C.c_int32, C.c_int32, c_dp]
     L.va_eval_timed.argtypes = [h, C.c_double, C.c_int32, C.POINTER(C.c_float)]
     L.va_get_counters.argtypes = [h, c_lp, c_lp, c_lp]
-    for fn in ("va_device_count", "va_problem_create", "va_problem_info", "va_action_grad",
+    for fn in ("va_device_count", "va_rhs_load_module", "va_problem_create", "va_problem_info", "va_action_grad",
                "va_minimize_lbfgs", "va_anneal", "va_get_minpath", "va_eval_timed",
                "va_get_counters"):
         getattr(L, fn).restype = C.c_int
@@ -150,7 +167,7 @@ def lib():
     return L
 
 
-EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_problem_create",
+EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_problem_create",
            "va_problem_destroy", "va_problem_info", "va_action_grad", "va_minimize_lbfgs",
            "va_anneal", "va_get_minpath", "va_eval_timed", "va_get_counters"]
 
@@ -158,6 +175,19 @@ EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_problem_cre
 def check(rc):
     if rc != VA_OK:
         raise VaError(rc, lib().va_last_error().decode("utf-8", "replace"))
+
+
+_modules = {}
+
+
+def load_rhs_module(path):
+    """Register a generated right-hand-side module; returns its rhs id (cached per path)."""
+    path = os.path.abspath(path)
+    if path not in _modules:
+        rid = C.c_int32()
+        check(lib().va_rhs_load_module(path.encode(), C.byref(rid)))
+        _modules[path] = rid.value
+    return _modules[path]
 
 
 class Problem(object):

@@ -1,0 +1,264 @@
+"""User right-hand sides on the device: trace -> differentiate -> HIP -> module.
+
+The reference accepts an arbitrary Python callable `f(t, x, p)` (or `f(t, x, (p, stim))`
+with a stimulus) acting on whole time slices (varanneal/va_ode.py:56-67, 345-375) and
+obtains derivatives by replaying an ADOL-C tape of it (_autodiffmin.py:32-58).  The tape
+works because `f` is written with type-polymorphic NumPy operations; the same property
+lets us run `f` ONCE on an object array of symbolic scalars, differentiate symbolically
+(SymPy) and emit the three device functions the tile kernel needs,
+
+    f_i(x, p, t, stim)            (J^T s)_j = sum_i s_i df_i/dx_j
+    acc_k += s_i df_i/dp_k
+
+as a generated header `struct RhsUser`, compiled with hipcc for gfx950 together with
+csrc/va_user_rhs.hip into a shared object that va_rhs_load_module() registers.  No tape,
+no interpreter at evaluation time.
+
+Limits: `f` must be traceable (no data-dependent Python branching on x/p; NumPy ufuncs
+exp/log/tanh/... and arithmetic are fine); NP <= 24.  Before use the generated
+expressions are checked numerically against `f` itself on random inputs.
+"""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+CACHE = os.environ.get("VARANNEAL_AMD_RHS_CACHE", os.path.join(_HERE, "_rhs_cache"))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+MAX_NP = 24
+
+
+def _sympy():
+    import sympy
+    return sympy
+
+
+class Sym(object):
+    """Scalar wrapper so that NumPy ufuncs on object arrays dispatch to SymPy."""
+    def __init__(self, e):
+        self.e = e
+
+    @staticmethod
+    def _u(o):
+        return o.e if isinstance(o, Sym) else o
+
+    # binary operators: with an ndarray on the other side return NotImplemented so that
+    # NumPy broadcasts element by element (each element then comes back here as a scalar)
+    def _bin(self, o, fn):
+        if isinstance(o, np.ndarray):
+            return NotImplemented
+        return Sym(fn(self.e, self._u(o)))
+
+    def __add__(self, o): return self._bin(o, lambda a, b: a + b)
+    def __radd__(self, o): return self._bin(o, lambda a, b: b + a)
+    def __sub__(self, o): return self._bin(o, lambda a, b: a - b)
+    def __rsub__(self, o): return self._bin(o, lambda a, b: b - a)
+    def __mul__(self, o): return self._bin(o, lambda a, b: a * b)
+    def __rmul__(self, o): return self._bin(o, lambda a, b: b * a)
+    def __truediv__(self, o): return self._bin(o, lambda a, b: a / b)
+    def __rtruediv__(self, o): return self._bin(o, lambda a, b: b / a)
+    def __pow__(self, o): return self._bin(o, lambda a, b: a ** b)
+    def __rpow__(self, o): return self._bin(o, lambda a, b: b ** a)
+    def __neg__(self): return Sym(-self.e)
+    def __pos__(self): return self
+
+    def _cmp(self, *a):
+        raise TypeError("the model function branches on the value of a state/parameter; "
+                        "such right-hand sides cannot be traced")
+    __lt__ = __le__ = __gt__ = __ge__ = __bool__ = _cmp
+
+    def __getattr__(self, name):          # np.tanh(obj_array) calls elem.tanh(), etc.
+        sp = _sympy()
+        table = {"exp": sp.exp, "log": sp.log, "sin": sp.sin, "cos": sp.cos, "tan": sp.tan,
+                 "tanh": sp.tanh, "sinh": sp.sinh, "cosh": sp.cosh, "sqrt": sp.sqrt,
+                 "arctan": sp.atan, "arcsin": sp.asin, "arccos": sp.acos,
+                 "arctanh": sp.atanh, "arcsinh": sp.asinh, "log1p": lambda z: sp.log(1 + z),
+                 "expm1": lambda z: sp.exp(z) - 1, "square": lambda z: z * z,
+                 "reciprocal": lambda z: 1 / z}
+        if name in table:
+            return lambda: Sym(table[name](self.e))
+        raise AttributeError(name)
+
+
+def trace(f, D, NP, nstim=0, stim_ndim=1):
+    """Run `f` once on symbols.  Returns (exprs[D], symbols dict)."""
+    sp = _sympy()
+    xs = sp.symbols("x0:%d" % D, real=True)
+    ps = sp.symbols("p0:%d" % max(NP, 1), real=True)[:NP]
+    ss = sp.symbols("st0:%d" % max(nstim, 1), real=True)[:nstim]
+    t = sp.Symbol("t", real=True)
+    X = np.empty((1, D), dtype=object)
+    for j in range(D):
+        X[0, j] = Sym(xs[j])
+    P = np.empty(NP, dtype=object)
+    for k in range(NP):
+        P[k] = Sym(ps[k])
+    T = np.empty(1, dtype=object)
+    T[0] = Sym(t)
+    if nstim:
+        if stim_ndim == 1:
+            S = np.empty(1, dtype=object); S[0] = Sym(ss[0])
+        else:
+            S = np.empty((1, nstim), dtype=object)
+            for k in range(nstim):
+                S[0, k] = Sym(ss[k])
+        out = f(T, X, (P, S))
+    else:
+        out = f(T, X, P)
+    out = np.asarray(out, dtype=object)
+    if out.shape != (1, D):
+        raise ValueError("model function returned shape %s for a (1, %d) state slice" % (out.shape, D))
+    exprs = [sp.sympify(Sym._u(out[0, i])) for i in range(D)]
+    return exprs, dict(x=xs, p=ps, st=ss, t=t)
+
+
+def _printer():
+    sp = _sympy()
+    from sympy.printing.c import C99CodePrinter
+
+    class P(C99CodePrinter):
+        def _print_Pow(self, e):
+            b, ex = e.as_base_exp()
+            if ex.is_Integer and 2 <= int(ex) <= 4:
+                s = self.parenthesize(b, 50)
+                return "(" + "*".join([s] * int(ex)) + ")"
+            if ex.is_Integer and -4 <= int(ex) <= -1:
+                s = self.parenthesize(b, 50)
+                return "(1.0/(" + "*".join([s] * (-int(ex))) + "))"
+            return super()._print_Pow(e)
+
+        def _print_Symbol(self, s):
+            n = s.name
+            for pre, arr in (("x", "x"), ("p", "p"), ("st", "st"), ("sv", "s")):
+                if n.startswith(pre) and n[len(pre):].isdigit():
+                    return "%s[%s]" % (arr, n[len(pre):])
+            return n
+    return P()
+
+
+def _emit_case(pr, expr, ret):
+    """C statements computing `expr` (with CSE temporaries) then `ret % value`."""
+    sp = _sympy()
+    repl, red = sp.cse([expr], symbols=sp.numbered_symbols("c_"), optimizations="basic")
+    lines = ["const double %s = %s;" % (pr.doprint(a), pr.doprint(b)) for a, b in repl]
+    lines.append(ret % pr.doprint(red[0]))
+    return " ".join(lines)
+
+
+def generate_header(exprs, syms, D, NP, nstim, name="user"):
+    sp = _sympy()
+    pr = _printer()
+    sv = sp.symbols("sv0:%d" % D, real=True)
+    out = []
+    out.append("// generated by varanneal_amd.codegen from the model function %r -- do not edit" % name)
+    out.append("// D=%d NP=%d NSTIM=%d" % (D, NP, nstim))
+    out.append("#pragma once")
+    out.append("namespace va {")
+    out.append("struct RhsUser {")
+    out.append("    static constexpr int NP = %d, D = %d, NSTIM = %d;" % (NP, D, nstim))
+    # f
+    out.append("    static VA_HD double f(const double *x, int i, int, const double *p, double t, const double *st)")
+    out.append("    {")
+    out.append("        (void)x; (void)p; (void)t; (void)st;")
+    out.append("        switch (i) {")
+    for i, e in enumerate(exprs):
+        out.append("        case %d: { %s }" % (i, _emit_case(pr, e, "return %s;")))
+    out.append("        default: return 0.0;")
+    out.append("        }")
+    out.append("    }")
+    # vjp
+    out.append("    static VA_HD double vjp(const double *x, const double *s, int j, int, const double *p, double t, const double *st)")
+    out.append("    {")
+    out.append("        (void)x; (void)s; (void)p; (void)t; (void)st;")
+    out.append("        switch (j) {")
+    for j in range(D):
+        tot = sum((sv[i] * sp.diff(exprs[i], syms["x"][j]) for i in range(D)), sp.Integer(0))
+        out.append("        case %d: { %s }" % (j, _emit_case(pr, tot, "return %s;")))
+    out.append("        default: return 0.0;")
+    out.append("        }")
+    out.append("    }")
+    # pgrad
+    out.append("    static VA_HD void pgrad(const double *x, const double *s, int i, int, const double *p, double t, const double *st, double *acc)")
+    out.append("    {")
+    out.append("        (void)x; (void)s; (void)p; (void)t; (void)st; (void)acc;")
+    out.append("        switch (i) {")
+    for i, e in enumerate(exprs):
+        stm = []
+        for k in range(NP):
+            dk = sp.diff(e, syms["p"][k])
+            if dk != 0:
+                stm.append("{ %s }" % _emit_case(pr, sv[i] * dk, "acc[%d] += %%s;" % k))
+        out.append("        case %d: { %s break; }" % (i, " ".join(stm)))
+        out[-1] = out[-1].replace("{  break; }", "{ break; }")
+    out.append("        default: break;")
+    out.append("        }")
+    out.append("    }")
+    out.append("};")
+    out.append("}  // namespace va")
+    return "\n".join(out) + "\n"
+
+
+def check_against(f, exprs, syms, D, NP, nstim, stim_ndim=1, trials=3, rtol=1e-10):
+    """The traced expressions must reproduce `f` on random numeric slices."""
+    sp = _sympy()
+    args = list(syms["x"]) + list(syms["p"]) + list(syms["st"]) + [syms["t"]]
+    fn = sp.lambdify(args, exprs, modules="numpy")
+    rng = np.random.RandomState(20260102)
+    for _ in range(trials):
+        x = rng.rand(5, D) * 0.8 + 0.1
+        p = rng.rand(NP) * 0.8 + 0.6
+        t = rng.rand(5)
+        if nstim:
+            st = rng.randn(5) if stim_ndim == 1 else rng.randn(5, nstim)
+            want = np.asarray(f(t, x, (p, st)), dtype=np.float64)
+        else:
+            st = None
+            want = np.asarray(f(t, x, p), dtype=np.float64)
+        for r in range(5):
+            srow = [] if not nstim else (list(np.atleast_1d(st[r])))
+            got = np.array(fn(*(list(x[r]) + list(p) + srow + [t[r]])), dtype=np.float64)
+            if not np.allclose(got, want[r], rtol=rtol, atol=1e-12):
+                raise ValueError("traced model disagrees with the model function "
+                                 "(does it branch on its inputs?): %s vs %s" % (got, want[r]))
+
+
+def _core_fingerprint():
+    h = hashlib.sha1()
+    for fn in ("va_core.h", "va_device.h", "va_eval_flat.h", "va_tile2.h", "va_tile3.h", "va_user_rhs.hip"):
+        with open(os.path.join(CSRC, fn), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+def build_module(header_text, verbose=False):
+    """Write the header, compile the module for gfx950 (cached by content).  Returns (so, header)."""
+    os.makedirs(CACHE, exist_ok=True)
+    key = hashlib.sha1((header_text + _core_fingerprint()).encode()).hexdigest()[:16]
+    hdr = os.path.join(CACHE, "rhs_%s.h" % key)
+    so = os.path.join(CACHE, "libva_rhs_%s.so" % key)
+    if not os.path.exists(hdr):
+        with open(hdr, "w") as fh:
+            fh.write(header_text)
+    if not os.path.exists(so):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-Wno-unused-function", "-I", CSRC, '-DVA_USER_RHS_HEADER="%s"' % hdr,
+               "-o", so + ".tmp", os.path.join(CSRC, "va_user_rhs.hip")]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        os.replace(so + ".tmp", so)
+    return so, hdr
+
+
+def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False):
+    """trace + check + generate + build.  Returns dict(so=, header=, exprs=)."""
+    if NP > MAX_NP:
+        raise NotImplementedError("right-hand sides with more than %d parameters" % MAX_NP)
+    exprs, syms = trace(f, D, NP, nstim, stim_ndim)
+    check_against(f, exprs, syms, D, NP, nstim, stim_ndim)
+    text = generate_header(exprs, syms, D, NP, nstim, getattr(f, "__name__", "f"))
+    so, hdr = build_module(text, verbose)
+    return dict(so=so, header=hdr, exprs=exprs, text=text)

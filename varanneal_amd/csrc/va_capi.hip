@@ -5,6 +5,7 @@
 //     k_eval -> k_ls -> k_update -> k_coeffs -> k_direction
 // until every seed has climbed its whole RF ladder.  No per-iteration host sync:
 // the host only polls a device counter of unfinished seeds every few cycles.
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -41,11 +42,21 @@ int fail(int code, const char *fmt, ...)
                         #expr, hipGetErrorString(e_), __FILE__, __LINE__);                 \
     } while (0)
 
+// generated right-hand-side modules (va_rhs_load_module); ids are VA_RHS_USER_BASE + index
+struct UserRhs {
+    std::string path;
+    void *dl = nullptr;
+    void (*launch)(const Dev *, void *) = nullptr;
+    int NP = 0, D = 0, NSTIM = 0;
+};
+std::vector<UserRhs> g_user_rhs;
+
 }  // namespace
 
 struct va_problem_s {
     Dev dv;
     int device = 0, rhs = 0, keep_paths = 0;
+    void (*user_launch)(const Dev *, void *) = nullptr;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::vector<void *> allocs;
@@ -69,8 +80,14 @@ struct va_problem_s {
 
 namespace {
 
+void run_eval(va_handle h)
+{
+    if (h->user_launch) h->user_launch(&h->dv, (void *)h->stream);
+    else launch_eval(h->dv, h->rhs, h->stream);
+}
+
 // Tile geometry of the eval kernel: which mapping, rows per workgroup, threads.
-void pick_eval_geometry(const va_problem_desc *d, Dims &dm)
+void pick_eval_geometry(const va_problem_desc *d, Dims &dm, bool user_rhs)
 {
     const int D = d->D, N = d->N_model;
     const bool sh = d->disc == VA_DISC_SIMPSON_HERMITE;
@@ -79,6 +96,7 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm)
     // auto: column-run when a workgroup holds >= 4 lanes per column, row-strided columns for
     // wider states (their short runs would be mostly halo), flat mapping beyond 256 columns
     if (dm.emode < 1 || dm.emode > 3) dm.emode = (D <= 512) ? 3 : 1;
+    if (user_rhs) dm.emode = 1;                           // generated modules instantiate the flat kernel
     if (dm.emode == 2 && D > 256) dm.emode = 1;           // row-strided columns: a row per <=256 lanes
     if (dm.emode == 3 && D > 512) dm.emode = 1;           // column runs: >= 2 lanes per column
     int tmin, tmax;
@@ -198,7 +216,7 @@ int run_ladder(va_handle h, const double *rf_scale, int nbeta)
     int poll = 4;
     for (;;) {
         for (int k = 0; k < poll; ++k) {
-            launch_eval(dv, h->rhs, h->stream);
+            run_eval(h);
             launch_ls(dv, h->stream);
             launch_update(dv, h->stream);
             launch_coeffs(dv, h->stream);
@@ -244,6 +262,32 @@ int va_device_count(int32_t *count)
     return VA_OK;
 }
 
+int va_rhs_load_module(const char *path, int32_t *rhs_id)
+{
+    if (!path || !rhs_id) return fail(VA_EINVAL, "null argument");
+    for (size_t i = 0; i < g_user_rhs.size(); ++i)
+        if (g_user_rhs[i].path == path) { *rhs_id = VA_RHS_USER_BASE + (int32_t)i; return VA_OK; }
+    UserRhs u;
+    u.path = path;
+    u.dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!u.dl) return fail(VA_EINVAL, "dlopen(%s): %s", path, dlerror());
+    typedef void (*info_fn)(int *);
+    info_fn info = (info_fn)dlsym(u.dl, "va_user_rhs_info");
+    u.launch = (void (*)(const Dev *, void *))dlsym(u.dl, "va_user_launch_eval");
+    if (!info || !u.launch) { dlclose(u.dl); return fail(VA_EINVAL, "%s lacks va_user_rhs_info / va_user_launch_eval", path); }
+    int v[5] = {0, 0, 0, 0, 0};
+    info(v);
+    if (v[3] != (int)sizeof(Dev) || v[4] != (int)sizeof(SeedState)) {
+        dlclose(u.dl);
+        return fail(VA_EINVAL, "%s was built against different headers (Dev %d vs %zu bytes): rebuild it", path, v[3], sizeof(Dev));
+    }
+    if (v[0] < 0 || v[0] > RHS_MAX_NP) { dlclose(u.dl); return fail(VA_EUNSUPPORTED, "%s: NP=%d > %d", path, v[0], RHS_MAX_NP); }
+    u.NP = v[0]; u.D = v[1]; u.NSTIM = v[2];
+    g_user_rhs.push_back(u);
+    *rhs_id = VA_RHS_USER_BASE + (int32_t)g_user_rhs.size() - 1;
+    return VA_OK;
+}
+
 int va_problem_create(const va_problem_desc *d, va_handle *out)
 {
     if (!d || !out) return fail(VA_EINVAL, "null argument");
@@ -257,9 +301,17 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     if (d->disc < VA_DISC_EULER || d->disc > VA_DISC_FORWARDMAP) return fail(VA_EINVAL, "unknown disc %d", d->disc);
     if (d->disc == VA_DISC_SIMPSON_HERMITE && (d->N_model % 2) == 0)
         return fail(VA_EINVAL, "SimpsonHermite needs an odd number of time points (N_model=%d)", d->N_model);
-    if (d->rhs != VA_RHS_LORENZ96) return fail(VA_EUNSUPPORTED, "unknown built-in rhs %d", d->rhs);
+    const UserRhs *user = nullptr;
+    if (d->rhs >= VA_RHS_USER_BASE) {
+        if ((size_t)(d->rhs - VA_RHS_USER_BASE) >= g_user_rhs.size()) return fail(VA_EINVAL, "rhs module id %d was never registered", d->rhs);
+        user = &g_user_rhs[d->rhs - VA_RHS_USER_BASE];
+        if (user->NP != d->NP || user->D != d->D || user->NSTIM != d->n_stim)
+            return fail(VA_EINVAL, "rhs module %s was generated for D=%d NP=%d n_stim=%d, problem has D=%d NP=%d n_stim=%d",
+                        user->path.c_str(), user->D, user->NP, user->NSTIM, d->D, d->NP, d->n_stim);
+    } else if (d->rhs != VA_RHS_LORENZ96) return fail(VA_EUNSUPPORTED, "unknown built-in rhs %d", d->rhs);
     if (d->rhs == VA_RHS_LORENZ96 && (d->NP != RhsL96::NP || d->D < 4))
         return fail(VA_EINVAL, "Lorenz-96 needs NP=1 and D>=4 (NP=%d D=%d)", d->NP, d->D);
+    if (d->n_stim < 0 || (d->n_stim > 0 && !d->stim)) return fail(VA_EINVAL, "n_stim=%d without a stimulus array", d->n_stim);
     if (d->NPest < 0 || d->NPest > d->NP || d->NP > RHS_MAX_NP) return fail(VA_EINVAL, "bad NP/NPest (%d/%d)", d->NP, d->NPest);
     if (!d->Y || (d->L > 0 && !d->Lidx) || !d->P || (d->NPest > 0 && !d->Pidx)) return fail(VA_EINVAL, "null array in desc");
     if ((d->rm_kind && !d->rm_array) || (d->rf_kind && !d->rf0_array)) return fail(VA_EINVAL, "rm/rf array kind without array");
@@ -278,6 +330,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
 
     va_handle h = new va_problem_s();
     h->device = d->device; h->rhs = d->rhs; h->keep_paths = d->keep_paths;
+    h->user_launch = user ? user->launch : nullptr;
     if (d->stream) h->stream = (hipStream_t)d->stream;
     else {
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -291,7 +344,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dm.nskip = d->merr_nskip; dm.NP = d->NP; dm.NPest = d->NPest; dm.B = d->batch; dm.m = m;
     dm.disc = d->disc;
     dm.ld = ((dm.ND + dm.NPest + 15) / 16) * 16;
-    pick_eval_geometry(d, dm);
+    pick_eval_geometry(d, dm, user != nullptr);
     dm.nprow = dm.emode == 3 ? dm.ntiles * (dm.NT / 64) : dm.ntiles;
     dm.obsmask = 0ull;
     if (dm.D <= 64) for (int l = 0; l < d->L; ++l) dm.obsmask |= 1ull << d->Lidx[l];
@@ -312,7 +365,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     int rc = VA_OK;
     const size_t B = dm.B, ld = dm.ld;
     int *lmap_d = nullptr, *pidx_d = nullptr;
-    double *Y_d = nullptr, *rm_d = nullptr, *rf_d = nullptr, *P_d = nullptr;
+    double *Y_d = nullptr, *rm_d = nullptr, *rf_d = nullptr, *P_d = nullptr, *t_d = nullptr, *st_d = nullptr;
 #define TRY(x) do { rc = (x); if (rc) { va_problem_destroy(h); return rc; } } while (0)
     TRY(h->alloc(&lmap_d, dm.D));
     TRY(h->alloc(&Y_d, (size_t)dm.N_data * dm.L));
@@ -320,6 +373,8 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     TRY(h->alloc(&P_d, B * dm.NP));
     if (d->rm_kind) TRY(h->alloc(&rm_d, (size_t)dm.N_data * dm.L));
     if (d->rf_kind) TRY(h->alloc(&rf_d, (size_t)(dm.N - 1) * dm.D));
+    if (d->t_model) TRY(h->alloc(&t_d, (size_t)dm.N));
+    if (d->n_stim > 0) TRY(h->alloc(&st_d, (size_t)dm.N * d->n_stim));
     TRY(h->alloc(&dv.x, B * ld)); TRY(h->alloc(&dv.g, B * ld));
     TRY(h->alloc(&dv.gt, B * ld)); TRY(h->alloc(&dv.d, B * ld));
     TRY(h->alloc(&dv.S, B * m * ld)); TRY(h->alloc(&dv.Y, B * m * ld));
@@ -348,8 +403,11 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     H2D(P_d, d->P, B * dm.NP, double);
     if (d->rm_kind) H2D(rm_d, d->rm_array, (size_t)dm.N_data * dm.L, double);
     if (d->rf_kind) H2D(rf_d, d->rf0_array, (size_t)(dm.N - 1) * dm.D, double);
+    if (d->t_model) H2D(t_d, d->t_model, (size_t)dm.N, double);
+    if (d->n_stim > 0) H2D(st_d, d->stim, (size_t)dm.N * d->n_stim, double);
     dv.pp.lmap = lmap_d; dv.pp.Y = Y_d; dv.pp.rm_arr = rm_d; dv.pp.rf0_arr = rf_d;
     dv.pp.Pidx = pidx_d; dv.pp.Pfull = P_d;
+    dv.pp.tmodel = t_d; dv.pp.stim = st_d; dv.pp.nstim = d->n_stim;
 
     hipError_t e = hipHostMalloc((void **)&h->h_nactive, 4 * sizeof(int), hipHostMallocDefault);
     if (e != hipSuccess) { va_problem_destroy(h); return fail(VA_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e)); }
@@ -399,7 +457,7 @@ int va_action_grad(va_handle h, const double *XP, int64_t ld, int32_t mem, doubl
     Dev &dv = h->dv;
     if ((rc = copy_in(h, XP, ld, mem))) return rc;
     launch_init_states(dv, PH_START, rf_scale, h->stream);
-    launch_eval(dv, h->rhs, h->stream);
+    run_eval(h);
     launch_finalize_eval(dv, h->stream);
     const hipMemcpyKind k = mem == VA_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     HIPCHK(hipMemcpyAsync(A, dv.outA, sizeof(double) * dv.dm.B, k, h->stream));
@@ -475,7 +533,7 @@ int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms
     Dev &dv = h->dv;
     launch_init_states(dv, PH_START, rf_scale, h->stream);
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    for (int i = 0; i < iters; ++i) launch_eval(dv, h->rhs, h->stream);
+    for (int i = 0; i < iters; ++i) run_eval(h);
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventSynchronize(h->ev1));
     HIPCHK(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));

@@ -39,7 +39,7 @@ enum { UPD_X = 1, UPD_G = 2, UPD_HIST = 4, UPD_STORE = 8 };
 enum { LS_START = 0, LS_FG = 1, LS_CONV = 2, LS_WARN = 3, LS_ERROR = 4 };
 
 constexpr int MAX_M = 32;        // history pairs
-constexpr int RHS_MAX_NP = 8;    // parameters a built-in RHS may have
+constexpr int RHS_MAX_NP = 24;   // parameters a right-hand side may have (NaKL: 18)
 // eval partial columns
 enum { EP_ME = 0, EP_FE = 1, EP_GTD = 2, EP_GN2 = 3, EP_GMAX = 4, EP_GP = 5 };
 constexpr int EP_N = EP_GP + RHS_MAX_NP;
@@ -66,6 +66,9 @@ struct ProblemPtrs {
     const double *rf0_arr; // NULL or [(N-1)*D]
     const int *Pidx;       // [NPest]
     const double *Pfull;   // [B*NP]
+    const double *tmodel;  // NULL or [N]: model times, for non-autonomous right-hand sides
+    const double *stim;    // NULL or [N*nstim]: external stimulus rows (va_ode.py:345-354)
+    int nstim;
 };
 
 struct LsState {
@@ -103,7 +106,7 @@ struct SeedState : SeedHot {
 // f_i = x_{i-1}(x_{i+1} - x_{i-2}) - x_i + k   (cyclic)
 struct RhsL96 {
     static constexpr int NP = 1;
-    static VA_HD double f(const double *x, int i, int D, const double *p)
+    static VA_HD double f(const double *x, int i, int D, const double *p, double, const double *)
     {
         int im1 = i == 0 ? D - 1 : i - 1;
         int im2 = im1 == 0 ? D - 1 : im1 - 1;
@@ -111,7 +114,7 @@ struct RhsL96 {
         return x[im1] * (x[ip1] - x[im2]) - x[i] + p[0];
     }
     // (J^T s)_j = s_{j+1}(x_{j+2} - x_{j-1}) + s_{j-1} x_{j-2} - s_{j+2} x_{j+1} - s_j
-    static VA_HD double vjp(const double *x, const double *s, int j, int D, const double *)
+    static VA_HD double vjp(const double *x, const double *s, int j, int D, const double *, double, const double *)
     {
         int jm1 = j == 0 ? D - 1 : j - 1;
         int jm2 = jm1 == 0 ? D - 1 : jm1 - 1;
@@ -120,7 +123,7 @@ struct RhsL96 {
         return s[jp1] * (x[jp2] - x[jm1]) + s[jm1] * x[jm2] - s[jp2] * x[jp1] - s[j];
     }
     // acc[k] += s_i * df_i/dp_k
-    static VA_HD void pgrad(const double *, const double *s, int i, int, const double *, double *acc)
+    static VA_HD void pgrad(const double *, const double *s, int i, int, const double *, double, const double *, double *acc)
     {
         acc[0] += s[i];
     }
@@ -138,6 +141,8 @@ struct TileCtx {
     double *xs, *fs, *qs;        // staged rows [R*D] (LDS); fs is re-used for s
     const double *xg, *dg;       // this seed's x (and d) in global memory
     double *gtg;                 // this seed's gradient output
+    const double *tmodel, *stim; // per-row time / stimulus (NULL / unused for autonomous RHS)
+    int nstim;
     double p[RHS_MAX_NP];
 };
 
@@ -191,7 +196,9 @@ VA_HD void tile_f(const Dims &dm, TileCtx &c, int tid, int nt)
     const int dlr = nt / D, di = nt - dlr * D;
     for (int e = tid; e < tot; e += nt) {
         int row = c.n0 - Halo<DISC>::HL + lr;
-        c.fs[e] = (row >= 0 && row < dm.N) ? RHS::f(c.xs + lr * D, i, D, c.p) : 0.0;
+        c.fs[e] = (row >= 0 && row < dm.N)
+                      ? RHS::f(c.xs + lr * D, i, D, c.p, c.tmodel ? c.tmodel[row] : 0.0, c.stim + (size_t)row * c.nstim)
+                      : 0.0;
         lr += dlr; i += di;
         if (i >= D) { i -= D; ++lr; }
     }
@@ -301,8 +308,10 @@ VA_HD void tile_g(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &
             double direct, sdummy;
             disc_direct_s<DISC>(c.qs + lr * D + j, D, m, dm.dt, direct, sdummy);
             const double *xr = c.xs + lr * D, *sr = c.fs + lr * D;
-            double g = direct + RHS::vjp(xr, sr, j, D, c.p);
-            RHS::pgrad(xr, sr, j, D, c.p, acc.v + EP_GP);
+            const double tm = c.tmodel ? c.tmodel[m] : 0.0;
+            const double *st = c.stim + (size_t)m * c.nstim;
+            double g = direct + RHS::vjp(xr, sr, j, D, c.p, tm, st);
+            RHS::pgrad(xr, sr, j, D, c.p, tm, st, acc.v + EP_GP);
             const int l = pp.lmap[j];
             if (l >= 0 && (m % dm.nskip) == 0) {
                 const int nd = m / dm.nskip;

@@ -15,86 +15,9 @@
 // Reference arithmetic: see va_core.h header.  All fp64.  HBM-bound streaming
 // kernels: nothing here is GEMM-shaped, so no MFMA.
 #include "va_device.h"
+#include "va_eval_flat.h"
 
 namespace va {
-
-// ------------------------------------------------------------------ helpers
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-    return v;
-}
-
-// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one):
-// give each XCD a contiguous range of work items so that neighbouring tiles of a
-// seed (which share halo rows) meet in the same L2.  Speed only, never correctness.
-__device__ __forceinline__ int xcd_swizzle(int bid, int nwork)
-{
-    const int per = (nwork + 7) >> 3;
-    return (bid & 7) * per + (bid >> 3);
-}
-
-// ------------------------------------------------------------------ K1: eval
-template <class RHS, int DISC>
-__global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
-{
-    extern __shared__ double smem[];
-    const Dims &dm = dv.dm;
-    const int nwork = dm.B * dm.ntiles;
-    const int w = xcd_swizzle(blockIdx.x, nwork);
-    if (w >= nwork) return;
-    const int b = w / dm.ntiles, tile = w - b * dm.ntiles;
-    const SeedState &st = dv.st[b];
-    const int phase = st.phase;
-    if (phase != PH_START && phase != PH_LS) return;
-
-    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
-    constexpr int K = EP_GP + RHS::NP;            // partial columns in use
-    const int R = dm.T + HL + HR, RD = R * dm.D;
-    TileCtx c;
-    c.n0 = tile * dm.T; c.R = R; c.use_d = (phase == PH_LS);
-    c.stp = st.stp; c.c = 2.0 * st.rf_scale * dm.cfe;
-    c.xs = smem; c.fs = smem + RD; c.qs = smem + 2 * RD;
-    double *red = smem + 3 * RD;
-    c.xg = dv.x + (size_t)b * dm.ld; c.dg = dv.d + (size_t)b * dm.ld;
-    c.gtg = dv.gt + (size_t)b * dm.ld;
-    tile_params<RHS>(dm, dv.pp, b, c);
-
-    const int tid = threadIdx.x, nt = blockDim.x;
-    ThreadAcc acc;
-    acc.clear();
-    tile_load<DISC>(dm, c, tid, nt);
-    __syncthreads();
-    tile_f<RHS, DISC>(dm, c, tid, nt);
-    __syncthreads();
-    tile_q<DISC>(dm, dv.pp, c, acc, tid, nt);
-    __syncthreads();
-    tile_s<DISC>(dm, c, tid, nt);
-    __syncthreads();
-    tile_g<RHS, DISC>(dm, dv.pp, c, acc, tid, nt);
-
-    // wave64 shuffle reduction, then across the workgroup's waves through LDS
-    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        double v = (k == EP_GMAX) ? wave_max(acc.v[k]) : wave_sum(acc.v[k]);
-        if (lane == 0) red[wave * K + k] = v;
-    }
-    __syncthreads();
-    if (tid < K) {
-        double v = red[tid];
-        for (int ww = 1; ww < nw; ++ww)
-            v = (tid == EP_GMAX) ? fmax(v, red[ww * K + tid]) : v + red[ww * K + tid];
-        dv.evp[((size_t)b * dm.ntiles + tile) * EP_N + tid] = v;
-    }
-}
 
 // ------------------------------------------------------------------ K1 (fast path): column-mapped
 template <class RHS, int DISC, int MAXR>
@@ -345,19 +268,6 @@ static void launch_eval3_d(const Dev &dv, hipStream_t s)
 
 int eval_grid(const Dims &dm) { return ((dm.B * dm.ntiles + 7) / 8) * 8; }
 
-template <class RHS>
-static void launch_eval_rhs(const Dev &dv, hipStream_t s)
-{
-    const dim3 grid(eval_grid(dv.dm)), block(EVAL_THREADS);
-    const size_t lds = eval_lds_bytes(dv.dm);
-    switch (dv.dm.disc) {
-    case DISC_EULER: hipLaunchKernelGGL((k_eval<RHS, DISC_EULER>), grid, block, lds, s, dv); break;
-    case DISC_TRAPEZOID: hipLaunchKernelGGL((k_eval<RHS, DISC_TRAPEZOID>), grid, block, lds, s, dv); break;
-    case DISC_SH: hipLaunchKernelGGL((k_eval<RHS, DISC_SH>), grid, block, lds, s, dv); break;
-    default: hipLaunchKernelGGL((k_eval<RHS, DISC_FWDMAP>), grid, block, lds, s, dv); break;
-    }
-}
-
 template <class RHS, int MAXR>
 static void launch_eval2_rhs(const Dev &dv, hipStream_t s)
 {
@@ -406,16 +316,16 @@ __device__ __forceinline__ double col_reduce(const double *p, int nrows, int str
 }
 
 // reduce the eval partial rows of seed b with the whole wave: lane = (row group r, column k),
-// 4 row groups x 16 columns; returns the column totals broadcast into ev[].
+// 2 row groups x 32 columns (EP_N <= 32); returns the column totals broadcast into ev[].
+static_assert(EP_N <= 32, "reduce_eval assumes at most 32 partial columns");
 __device__ __forceinline__ void reduce_eval(const Dev &dv, int b, int lane, double *ev)
 {
-    const int k = lane & 15, r = lane >> 4;
+    const int k = lane & 31, r = lane >> 5;
     double v = 0.0;
-    if (k < EP_N) v = col_reduce(dv.evp + (size_t)b * dv.dm.nprow * EP_N + k, dv.dm.nprow, EP_N, r, 4, k == EP_GMAX);
-    // combine the 4 row groups (lanes k, k+16, k+32, k+48) in a fixed order
-    const double v1 = __shfl(v, k + 16, 64), v2 = __shfl(v, k + 32, 64), v3 = __shfl(v, k + 48, 64);
-    const double v0 = __shfl(v, k, 64);
-    const double tot = (k == EP_GMAX) ? fmax(fmax(v0, v1), fmax(v2, v3)) : ((v0 + v1) + (v2 + v3));
+    if (k < EP_N) v = col_reduce(dv.evp + (size_t)b * dv.dm.nprow * EP_N + k, dv.dm.nprow, EP_N, r, 2, k == EP_GMAX);
+    // combine the 2 row groups (lanes k, k+32) in a fixed order
+    const double v0 = __shfl(v, k, 64), v1 = __shfl(v, k + 32, 64);
+    const double tot = (k == EP_GMAX) ? fmax(v0, v1) : (v0 + v1);
 #pragma unroll
     for (int c = 0; c < EP_N; ++c) ev[c] = __shfl(tot, c, 64);
 }

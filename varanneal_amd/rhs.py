@@ -4,9 +4,10 @@ The reference's `set_model(f, D)` takes an arbitrary Python callable
 `f(t, x, p)` acting on whole time slices (varanneal/va_ode.py:56-67; called at
 :356, :377-378, :430-432, :454).  The device kernels need `f` and `J^T v` as
 HIP code, so a callable is matched against the built-in registry by probing it
-numerically on random rows.  Generic callables (traced -> generated HIP) are the
-next row of SURVEY.md 8(f); until then an unrecognised `f` raises
-NotImplementedError instead of silently running something else.
+numerically on random rows and, when it matches, runs the hand-written kernels
+(column-run tile kernel, compile-time D).  Anything else goes through
+varanneal_amd.codegen: traced, differentiated, emitted as HIP and compiled into a
+module for the flat tile kernel.
 """
 import numpy as np
 

@@ -22,10 +22,14 @@ run unchanged:
     independently on the device.
   * `device=`, `verbose=`, `fused=` keyword-only arguments of anneal()/anneal_init().
 
+A model function that is not one of the hand-written built-ins (varanneal_amd.rhs) is
+traced once, differentiated symbolically and compiled into a device module
+(varanneal_amd.codegen) -- including the reference's `f(t, x, (p, stim))` stimulus
+convention (va_ode.py:345-375).
+
 Not implemented yet (SURVEY.md 8(f) "next" rows; raise NotImplementedError):
-time-dependent parameters (P0.ndim == 2 with 2-D X0), an external stimulus, full
-(L,L)/(D,D) RM/RF matrices, user-defined action callables, a user RHS that is not
-in varanneal_amd.rhs.REGISTRY.
+time-dependent parameters (P0.ndim == 2 with 2-D X0), full (L,L)/(D,D) RM/RF matrices,
+user-defined action callables.
 """
 from __future__ import print_function
 
@@ -126,12 +130,11 @@ class Annealer(object):
             raise NotImplementedError("method='LM' is dead code upstream (_autodiffmin.py:157)")
         self.method = method
         self.verbose = verbose
-        if self.stim is not None:
-            raise NotImplementedError("external stimulus (va_ode.py:345-354) is not on the device path yet")
-        if not hasattr(self, "_rhs_name") or self._rhs_name is None:
-            raise NotImplementedError(
-                "set_model(f, D): f is not one of the built-in device right-hand sides %s; "
-                "generic user RHS code generation is not implemented yet" % sorted(_rhs.REGISTRY))
+        if not hasattr(self, "f"):
+            raise ValueError("set_model() has not been called")
+        # separate dt_data and dt_model are not supported upstream with a stimulus (va_ode.py:544-547)
+        if dt_model is not None and dt_model != self.dt_data and self.stim is not None:
+            raise ValueError("Separate dt_data and dt_model currently not supported with an external stimulus.")
         if action != 'A_gaussian':
             raise NotImplementedError("only action='A_gaussian' is implemented")
         if disc not in _DISCS:
@@ -173,9 +176,21 @@ class Annealer(object):
         self.L = len(self.Lidx)
         if np.shape(self.Y)[1] != self.L:
             raise ValueError("data has %d observed columns but Lidx has %d entries" % (np.shape(self.Y)[1], self.L))
-        impl, NPr, _ = _rhs.REGISTRY[self._rhs_name]
-        if self.NP != NPr:
-            raise ValueError("RHS %r takes %d parameter(s), P0 has %d" % (self._rhs_name, NPr, self.NP))
+        stim = None
+        if self.stim is not None:
+            stim = np.asarray(self.stim, dtype=np.float64)
+        if self._rhs_name is not None and stim is None:
+            impl, NPr, _ = _rhs.REGISTRY[self._rhs_name]
+            if self.NP != NPr:
+                raise ValueError("RHS %r takes %d parameter(s), P0 has %d" % (self._rhs_name, NPr, self.NP))
+            rhs_id = self._rhs_name
+        else:
+            # any other callable: trace it, differentiate it, emit HIP, compile a module
+            from . import codegen
+            nstim = 0 if stim is None else (1 if stim.ndim == 1 else stim.shape[1])
+            mod = codegen.module_for(self.f, self.D, self.NP, nstim, 1 if stim is None else stim.ndim)
+            rhs_id = _capi.load_rhs_module(mod["so"])
+            self._rhs_module = mod
 
         # RM / RF0 broadcasting (va_ode.py:612-640)
         if isinstance(RM, list):
@@ -247,7 +262,8 @@ class Annealer(object):
             self._pb.close()
         self._pb = _capi.Problem(self.B, self.D, self.N_model, np.asarray(self.Y, dtype=np.float64),
                                  self.Lidx, float(self.dt_model), self.RM, self.RF0, self._Pfull,
-                                 self.Pidx, disc=disc, rhs=self._rhs_name, merr_nskip=self.merr_nskip,
+                                 self.Pidx, disc=disc, rhs=rhs_id, merr_nskip=self.merr_nskip,
+                                 t_model=np.asarray(self.t_model, dtype=np.float64), stim=stim,
                                  lbfgs_m=int((opt_args or {}).get("maxcor", 10)),
                                  max_beta=self.Nbeta, keep_paths=1, device=device)
         self.initalized = True                        # sic (va_ode.py:705)
