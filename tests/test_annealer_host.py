@@ -205,3 +205,51 @@ def test_scipy_route_with_bounds(fake_device, golden_ladders):
     assert np.all(a.minpaths[:, -1] >= 6.5 - 1e-12) and np.all(np.abs(a.minpaths[:, :-1]) <= 15.0 + 1e-12)
     assert np.all(a.A_array > 0) and np.allclose(a.A_array, a.me_array + a.fe_array, rtol=1e-12)
     assert np.all(a.exitflags == 0)
+
+
+class EmulBackedProblem(object):
+    """Test double for _capi.Problem on a GENERATED right-hand side: single evaluations by the
+    CPU emulator compiled with the generated header (same tile phases as the device module)."""
+    headers = {}
+
+    def __init__(self, batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, disc="trapezoid",
+                 rhs=0, merr_nskip=1, t_model=None, stim=None, **kw):
+        from cpu_emul import emul
+        self.emul, self.B = emul, batch
+        self.header = self.headers[rhs]
+        self.desc, self.keep = _capi.make_desc(batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, disc=disc,
+                                               rhs=1000, merr_nskip=merr_nskip, t_model=t_model, stim=stim)
+
+    def close(self):
+        pass
+
+    def action_grad(self, XP, rf_scale=1.0, want_grad=True):
+        A, me, fe, g = self.emul.action_grad(self.desc, 16, np.asarray(XP), rf_scale, user_header=self.header)
+        return A, me, fe, (g if want_grad else None)
+
+
+def test_nakl_bounded_ladder_host_flow(monkeypatch):
+    """Stimulus + bounds + generated RHS through the Annealer (tutorial NaKL flow,
+    va_ode.py:582-605 bounds expansion, :356 f(t, x, (p, stim))) against the ladder the
+    reference produced (tests/golden/nakl.npz)."""
+    from _util import load_npz_cases
+    from models.nakl import nakl
+    c = load_npz_cases("nakl.npz")["g5_nakl_ladder_SH_N101"]
+
+    def fake_load(path):
+        d, b = os.path.split(path)                          # libva_rhs_<key>.so -> rhs_<key>.h
+        EmulBackedProblem.headers[1000 + len(EmulBackedProblem.headers)] = os.path.join(d, b[6:-3] + ".h")
+        return 1000 + len(EmulBackedProblem.headers) - 1
+    monkeypatch.setattr(_capi, "load_rhs_module", fake_load)
+    monkeypatch.setattr(_capi, "Problem", EmulBackedProblem)
+    a = va_ode.Annealer()
+    a.set_model(nakl, 4)
+    a.set_data(c["Y"], stim=c["stim"], t=c["t"])
+    a.anneal(c["X0"].copy(), c["P0"].copy(), float(c["alpha"]), c["beta"], 1.0, list(c["RF0"]), [0],
+             list(range(18)), dt_model=None, init_to_data=True, disc="SimpsonHermite", method='L-BFGS-B',
+             bounds=[tuple(b) for b in c["bounds"]], opt_args=OPTS, adolcID=0, verbose=False)
+    assert list(a.nit_array[:4]) == list(c["nit"][:4])
+    assert np.all(np.abs(a.A_array[:7] - c["A_array"][:7]) <= 1e-5 * c["A_array"][:7])
+    assert np.all(np.abs(a.A_array - c["A_array"]) <= 2e-2 * c["A_array"])
+    lo, hi = c["bounds"][4:, 0], c["bounds"][4:, 1]
+    assert np.all(a.P >= lo - 1e-12) and np.all(a.P <= hi + 1e-12)

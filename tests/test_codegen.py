@@ -95,3 +95,33 @@ def test_module_cross_compiles_for_gfx950(nakl_module):
     L.va_user_rhs_info(v)
     assert list(v)[:3] == [18, 4, 1]
     assert hasattr(L, "va_user_launch_eval")
+
+
+def _golden_nakl():
+    from _util import load_npz_cases
+    return load_npz_cases("nakl.npz")
+
+
+@pytest.mark.parametrize("name", ["g5_nakl_SimpsonHermite_rf1e+00", "g5_nakl_SimpsonHermite_rf5e+01",
+                                  "g5_nakl_trapezoid_rf1e+00", "g5_nakl_trapezoid_rf2e+03"])
+def test_generated_nakl_matches_reference_golden(nakl_module, name):
+    """A, measurement/model split and gradient the reference itself produced for the tutorial's
+    NaKL model (oracle/gen_golden.py:nakl_cases) -- pins both the NumPy restatement for generic
+    f and the generated code run through the emulator."""
+    c = _golden_nakl()[name]
+    D, N = int(c["D"]), int(c["N_model"])
+    RF0 = np.resize(c["RF0"], (N - 1, D))
+    XP = c["XP"]
+    P = XP[N * D:]
+    Pidx = list(range(18))
+    rf = float(c["rf_scale"])
+    A0, me0, fe0 = va_oracle.numpy_action_generic(nakl, XP, D, N, c["Y"], [0], float(c["dt_model"]), float(c["RM"]),
+                                                  RF0 * rf, 18, Pidx, P, str(c["disc"]), t_model=c["t"],
+                                                  stim=c["stim"])
+    assert abs(A0 - c["A"]) <= 1e-12 * c["A"] and abs(me0 - c["me"]) <= 1e-12 * c["A"]
+    desc, keep = _capi.make_desc(1, D, N, c["Y"], [0], float(c["dt_model"]), float(c["RM"]), RF0, P[None, :], Pidx,
+                                 disc=str(c["disc"]), rhs=1000, t_model=c["t"], stim=c["stim"])
+    A, me, fe, g = emul.action_grad(desc, 16, XP[None, :], rf, user_header=nakl_module["header"])
+    assert abs(A[0] - c["A"]) <= 1e-12 * c["A"]
+    assert abs(me[0] - c["me"]) <= 1e-12 * c["A"] and abs(fe[0] - c["fe"]) <= 1e-12 * c["A"]
+    assert np.abs(g[0] - c["grad"]).max() <= 1e-10 * np.abs(c["grad"]).max()
