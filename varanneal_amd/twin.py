@@ -65,3 +65,79 @@ def initial_guess(N, D, seed_index, Y=None, Lidx=None, nskip=1):
     if Y is not None:
         X0[::nskip, Lidx] = Y
     return X0, P0
+
+
+# ---------------------------------------------------------------------------------------
+# Feed-forward "twin" network data (examples/nnet_twin).  The reference ships the two
+# generator scripts (data/gen_params.py, data/gen_io_pairs.py) but none of their output, so
+# the BASELINE C5 config needs a generator of our own following the same recipe: weights
+# U(-1,1)/fan_in, zero biases, sigmoid layers, inputs standardised N(0,1) draws, Gaussian
+# noise of width sigma on input and output, output clipped to (1e-4, 1-1e-4).
+NNET_SIGMA = 0.005      # "sm0p005" (nnet_twin_anneal.py:11, gen_io_pairs.py:20)
+
+
+def sigmoid(x, W, b):
+    """examples/nnet_twin/nnet_twin_anneal.py:20-22"""
+    return 1.0 / (1.0 + np.exp(-(np.dot(W, x) + b)))
+
+
+def nnet_structure(N=20, D_in=10, D_out=10, D_hidden=10):
+    s = np.full(N, D_hidden, dtype=int)
+    s[0], s[-1] = D_in, D_out
+    return s
+
+
+def nnet_param_layout(structure):
+    """(woff, boff, NP): offsets of W_n (s[n+1] x s[n], row-major) and b_n in the flat
+    parameter vector (va_nnet.py:194-207)."""
+    woff, boff, o = [], [], 0
+    for n in range(len(structure) - 1):
+        woff.append(o); o += int(structure[n + 1]) * int(structure[n])
+        boff.append(o); o += int(structure[n + 1])
+    return woff, boff, o
+
+
+def make_nnet_twin(structure, M, sigma=NNET_SIGMA, seed=GEN_SEED):
+    """Returns (data_in (M, s0), data_out (M, s_last), P_true (NP,))."""
+    structure = np.asarray(structure, dtype=int)
+    rng = np.random.RandomState(seed + 7)
+    woff, boff, NP = nnet_param_layout(structure)
+    P = np.zeros(NP)
+    for n in range(len(structure) - 1):
+        nw = structure[n + 1] * structure[n]
+        P[woff[n]:woff[n] + nw] = (2.0 * rng.rand(nw) - 1.0) / float(structure[n])
+    din = np.empty((M, structure[0])); dout = np.empty((M, structure[-1]))
+    for m in range(M):
+        y = rng.randn(structure[0])
+        y = (y - np.average(y)) / np.std(y)
+        x = y
+        for n in range(len(structure) - 1):
+            W = P[woff[n]:boff[n]].reshape(structure[n + 1], structure[n])
+            x = sigmoid(x, W, P[boff[n]:boff[n] + structure[n + 1]])
+        din[m] = y + sigma * rng.randn(structure[0])
+        dout[m] = np.clip(x + sigma * rng.randn(structure[-1]), 0.0001, 0.9999)
+    return din, dout, P
+
+
+def nnet_initial_guess(structure, M, seed_index, weights_only=True):
+    """Initial states/parameters drawn as nnet_twin_anneal.py:67-119 draws them (inputs
+    standardised N(0,1), other layers U(0.4,0.6), weights U(-1,1)/fan_in, biases 0) from
+    RandomState(1000+seed_index).  Returns (X0 (M*NDnet,), P0 (NP,), Pidx)."""
+    structure = np.asarray(structure, dtype=int)
+    rng = np.random.RandomState(1000 + int(seed_index))
+    X0 = []
+    for m in range(M):
+        xin = rng.randn(structure[0])
+        X0.append((xin - np.average(xin)) / np.std(xin))
+        for n in range(1, len(structure)):
+            X0.append(0.2 * rng.rand(structure[n]) + 0.4)
+    X0 = np.concatenate(X0)
+    woff, boff, NP = nnet_param_layout(structure)
+    P0 = np.zeros(NP); Pidx = []
+    for n in range(len(structure) - 1):
+        nw = structure[n + 1] * structure[n]
+        P0[woff[n]:woff[n] + nw] = (2.0 * rng.rand(nw) - 1.0) / float(structure[n])
+        Pidx += list(range(woff[n], woff[n] + nw))
+        if not weights_only:
+            Pidx += list(range(boff[n], boff[n] + int(structure[n + 1])))
+    return X0, P0, Pidx
