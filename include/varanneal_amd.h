@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VA_ABI_VERSION 2
+#define VA_ABI_VERSION 3
 
 enum { VA_OK = 0, VA_EINVAL = -1, VA_ENOMEM = -2, VA_EHIP = -3, VA_EUNSUPPORTED = -4,
        VA_ESTATE = -5 };
@@ -152,6 +152,46 @@ int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms
 /* Cumulative counters since create: batched eval launches, seed-evaluations,
  * L-BFGS cycles. */
 int va_get_counters(va_handle h, int64_t *eval_launches, int64_t *seed_evals, int64_t *cycles);
+
+/* ---- feed-forward-network action (reference: varanneal/va_nnet.py) -------------------
+ * va_nnet.Annealer estimates the neuron states of M training examples and (a subset of)
+ * the weights/biases of an all-to-all layered network; the "model error" is the mismatch
+ * x_{n+1} - f(W_n x_n + b_n) of every layer transition (va_nnet.py:175-255), the
+ * measurement error acts on observed input/output neurons (va_nnet.py:117-173).
+ * A handle made here is used with the SAME S1/S2/S3 entry points above; its path vector is
+ *     XP[b] = [ X[b]: M examples x NDnet states, example-major | p_est (NPest) ]   (va_nnet.py:440)
+ * with NDnet = sum(structure); the flat parameter vector is W_0 (structure[1] x structure[0],
+ * row-major), b_0, W_1, b_1, ... (va_nnet.py:194-207).  minpaths rows returned by va_anneal
+ * for such a handle are [X | p_est] (n_var wide); the caller scatters p_est into P. */
+enum { VA_ACT_SIGMOID = 0,   /* 1/(1+exp(-(W x + b))): examples/nnet_twin/nnet_twin_anneal.py:20-22 */
+       VA_ACT_TANH = 1, VA_ACT_LINEAR = 2 };
+
+typedef struct va_nnet_desc {
+    int32_t struct_size;      /* = sizeof(va_nnet_desc)                                  */
+    int32_t device;
+    int32_t batch;            /* B independent initial guesses ("seeds")                  */
+    int32_t n_layers;         /* len(structure), >= 2 (set_structure, va_nnet.py:59-69)   */
+    const int32_t *structure; /* [n_layers] neurons per layer                             */
+    int32_t M;                /* training examples (set_input_data, va_nnet.py:78-91)     */
+    int32_t L_in, L_out;      /* observed input / output neurons (va_nnet.py:324-332)     */
+    const int32_t *Lidx_in;   /* [L_in]  indices into the input layer                     */
+    const int32_t *Lidx_out;  /* [L_out] indices into the output layer                    */
+    const double *data_in;    /* [M][L_in]                                                */
+    const double *data_out;   /* [M][L_out]                                               */
+    double rm_in, rm_out;     /* RM scalar -> both equal; RM = [a, b] -> (a, b) (va_nnet.py:132-147) */
+    double rf0;               /* RF = rf0 * rf_scale                                      */
+    int32_t NP, NPest;        /* all parameters / estimated ones                          */
+    const int32_t *Pidx;      /* [NPest] indices into the flat parameter vector           */
+    const double *P;          /* [batch][NP] initial/fixed values                         */
+    int32_t activation;       /* VA_ACT_*                                                 */
+    int32_t lbfgs_m;          /* history pairs kept on the device (0 -> 10)               */
+    int32_t max_beta;         /* longest ladder va_anneal will be given                   */
+    int32_t keep_paths;       /* store every step's minimiser                             */
+    void *stream;             /* hipStream_t to use, or NULL for a private one            */
+} va_nnet_desc;
+
+/* Everything va_nnet.Annealer.anneal_init() freezes (va_nnet.py:288-450). */
+int va_nnet_problem_create(const va_nnet_desc *desc, va_handle *out);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,19 @@ class ProblemDesc(C.Structure):
                 ("stream", C.c_void_p)]
 
 
+class NnetDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("batch", C.c_int32),
+                ("n_layers", C.c_int32), ("structure", c_ip), ("M", C.c_int32),
+                ("L_in", C.c_int32), ("L_out", C.c_int32), ("Lidx_in", c_ip), ("Lidx_out", c_ip),
+                ("data_in", c_dp), ("data_out", c_dp), ("rm_in", C.c_double), ("rm_out", C.c_double),
+                ("rf0", C.c_double), ("NP", C.c_int32), ("NPest", C.c_int32), ("Pidx", c_ip), ("P", c_dp),
+                ("activation", C.c_int32), ("lbfgs_m", C.c_int32), ("max_beta", C.c_int32),
+                ("keep_paths", C.c_int32), ("stream", C.c_void_p)]
+
+
+ACTIVATION = {"sigmoid": 0, "tanh": 1, "linear": 2}
+
+
 class LbfgsOpts(C.Structure):
     _fields_ = [("maxcor", C.c_int32), ("ftol", C.c_double), ("gtol", C.c_double),
                 ("maxiter", C.c_int32), ("maxfun", C.c_int64), ("maxls", C.c_int32)]
@@ -146,6 +159,7 @@ def lib():
     L.va_last_error.restype = C.c_char_p
     L.va_device_count.argtypes = [c_ip]
     L.va_problem_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(h)]
+    L.va_nnet_problem_create.argtypes = [C.POINTER(NnetDesc), C.POINTER(h)]
     L.va_rhs_load_module.argtypes = [C.c_char_p, c_ip]
     L.va_problem_destroy.argtypes = [h]
     L.va_problem_destroy.restype = None
@@ -159,7 +173,8 @@ def lib():
     L.va_get_minpath.argtypes = [h, C.c_int32, C.c_int32, c_dp]
     L.va_eval_timed.argtypes = [h, C.c_double, C.c_int32, C.POINTER(C.c_float)]
     L.va_get_counters.argtypes = [h, c_lp, c_lp, c_lp]
-    for fn in ("va_device_count", "va_rhs_load_module", "va_problem_create", "va_problem_info", "va_action_grad",
+    for fn in ("va_device_count", "va_rhs_load_module", "va_problem_create", "va_nnet_problem_create",
+               "va_problem_info", "va_action_grad",
                "va_minimize_lbfgs", "va_anneal", "va_get_minpath", "va_eval_timed",
                "va_get_counters"):
         getattr(L, fn).restype = C.c_int
@@ -169,7 +184,7 @@ def lib():
 
 EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_problem_create",
            "va_problem_destroy", "va_problem_info", "va_action_grad", "va_minimize_lbfgs",
-           "va_anneal", "va_get_minpath", "va_eval_timed", "va_get_counters"]
+           "va_anneal", "va_get_minpath", "va_eval_timed", "va_get_counters", "va_nnet_problem_create"]
 
 
 def check(rc):
@@ -282,3 +297,60 @@ class Problem(object):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         check(self._L.va_get_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(eval_launches=a.value, seed_evals=b.value, cycles=c.value)
+
+
+def make_nnet_desc(batch, structure, data_in, data_out, Lidx, RM, RF0, P, Pidx, act="sigmoid",
+                   lbfgs_m=10, max_beta=1, keep_paths=0, device=0, stream=None):
+    """Fill a va_nnet_desc from what va_nnet.Annealer.anneal_init holds (va_nnet.py:288-450)."""
+    st = np.ascontiguousarray(structure, dtype=np.int32)
+    din = _f64(np.atleast_2d(data_in)); dout = _f64(np.atleast_2d(data_out))
+    M = din.shape[0]
+    lin = np.ascontiguousarray(Lidx[0], dtype=np.int32); lout = np.ascontiguousarray(Lidx[1], dtype=np.int32)
+    if din.shape != (M, lin.size) or dout.shape != (M, lout.size):
+        raise ValueError("data_in/data_out must have shapes (M, len(Lidx[0])) / (M, len(Lidx[1])), got %s / %s"
+                         % (din.shape, dout.shape))
+    if isinstance(RM, (list, tuple, np.ndarray)) and np.ndim(RM) > 0:
+        RM = np.asarray(RM, dtype=np.float64)
+        if RM.shape != (2,):
+            raise NotImplementedError("RM must be a scalar or [RM_in, RM_out]; matrix RM (va_nnet.py:136-139) "
+                                      "is not supported")
+        rm_in, rm_out = float(RM[0]), float(RM[1])
+    else:
+        rm_in = rm_out = float(RM)
+    if act not in ACTIVATION:
+        raise NotImplementedError("activation %r is not built in (have %s)" % (act, sorted(ACTIVATION)))
+    P = _f64(P)
+    if P.ndim == 1:
+        P = np.tile(P, (batch, 1))
+    pidx = np.ascontiguousarray(Pidx, dtype=np.int32)
+    d = NnetDesc()
+    d.struct_size = C.sizeof(NnetDesc); d.device = device; d.batch = batch
+    d.n_layers = st.size; d.structure = st.ctypes.data_as(c_ip); d.M = M
+    d.L_in, d.L_out = lin.size, lout.size
+    d.Lidx_in = lin.ctypes.data_as(c_ip); d.Lidx_out = lout.ctypes.data_as(c_ip)
+    d.data_in = din.ctypes.data_as(c_dp); d.data_out = dout.ctypes.data_as(c_dp)
+    d.rm_in, d.rm_out, d.rf0 = rm_in, rm_out, float(RF0)
+    d.NP, d.NPest = P.shape[1], pidx.size
+    d.Pidx = pidx.ctypes.data_as(c_ip); d.P = P.ctypes.data_as(c_dp)
+    d.activation = ACTIVATION[act]; d.lbfgs_m = lbfgs_m; d.max_beta = max_beta; d.keep_paths = keep_paths
+    d.stream = stream
+    return d, (st, din, dout, lin, lout, P, pidx)
+
+
+class NnetProblem(Problem):
+    """va_handle of a feed-forward-network action; same S1/S2/S3 methods as Problem.  The
+    path vector is [X (M*NDnet) | p_est]; `minpaths` rows from anneal() have that width."""
+
+    def __init__(self, batch, structure, data_in, data_out, Lidx, RM, RF0, P, Pidx, **kw):
+        self._L = lib()
+        self.desc, self._keep = make_nnet_desc(batch, structure, data_in, data_out, Lidx, RM, RF0, P, Pidx, **kw)
+        self.B = batch
+        self.M, self.NDnet = self.desc.M, int(np.sum(structure))
+        self.NDens = self.M * self.NDnet
+        self.NP_net, self.NPest_net = self.desc.NP, self.desc.NPest
+        self.n_var = self.NDens + self.NPest_net
+        # to the shared solver the vector has no separate parameter tail
+        self.N, self.D, self.NP, self.NPest = 1, self.n_var, 0, 0
+        self.max_beta = self.desc.max_beta
+        self._h = C.c_void_p()
+        check(self._L.va_nnet_problem_create(C.byref(self.desc), C.byref(self._h)))

@@ -16,6 +16,7 @@
 
 #include "../../include/varanneal_amd.h"
 #include "va_device.h"
+#include "va_nnet.h"
 
 using namespace va;
 
@@ -57,6 +58,8 @@ struct va_problem_s {
     Dev dv;
     int device = 0, rhs = 0, keep_paths = 0;
     void (*user_launch)(const Dev *, void *) = nullptr;
+    bool is_nnet = false;              // feed-forward-network action (va_nnet.hip) instead of an ODE path
+    NnetDev nn;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::vector<void *> allocs;
@@ -82,7 +85,8 @@ namespace {
 
 void run_eval(va_handle h)
 {
-    if (h->user_launch) h->user_launch(&h->dv, (void *)h->stream);
+    if (h->is_nnet) launch_nnet_eval(h->dv, h->nn, h->stream);
+    else if (h->user_launch) h->user_launch(&h->dv, (void *)h->stream);
     else launch_eval(h->dv, h->rhs, h->stream);
 }
 
@@ -154,6 +158,50 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, bool user_rhs)
     if (T < 2) T = 2;
     dm.T = T;
     dm.ntiles = (N + T - 1) / T;
+}
+
+// per-seed vectors, L-BFGS history, partial tables and result tables: the part of the device
+// image that does not depend on which action is being minimised
+int alloc_solver_state(va_handle h, int max_beta, int keep_paths)
+{
+    Dev &dv = h->dv;
+    const Dims &dm = dv.dm;
+    const size_t B = dm.B, ld = dm.ld, m = dm.m;
+    int rc;
+#define TRYA(x) do { rc = (x); if (rc) return rc; } while (0)
+    TRYA(h->alloc(&dv.x, B * ld)); TRYA(h->alloc(&dv.g, B * ld));
+    TRYA(h->alloc(&dv.gt, B * ld)); TRYA(h->alloc(&dv.d, B * ld));
+    TRYA(h->alloc(&dv.S, B * m * ld)); TRYA(h->alloc(&dv.Y, B * m * ld));
+    TRYA(h->alloc(&dv.st, B));
+    TRYA(h->alloc(&dv.evp, B * dm.nprow * EP_N));
+    TRYA(h->alloc(&dv.upp, B * dm.nchunks * dv.ups));
+    TRYA(h->alloc(&dv.dpp, B * dm.nchunks * DP_N));
+    TRYA(h->alloc(&h->d_rf, (size_t)max_beta));
+    TRYA(h->alloc(&dv.ame, B * max_beta * 3));
+    TRYA(h->alloc(&dv.pest, B * max_beta * (dm.NPest ? dm.NPest : 1)));
+    TRYA(h->alloc(&dv.status, B * max_beta)); TRYA(h->alloc(&dv.nit, B * max_beta));
+    TRYA(h->alloc(&dv.nfev, B * max_beta));
+    if (keep_paths) TRYA(h->alloc(&dv.minpaths, B * max_beta * (size_t)(dm.ND + dm.NP), false));
+    TRYA(h->alloc(&dv.n_active, 1));
+    TRYA(h->alloc(&dv.n_evals, 1));
+    TRYA(h->alloc(&dv.outA, B)); TRYA(h->alloc(&dv.outme, B)); TRYA(h->alloc(&dv.outfe, B));
+#undef TRYA
+    dv.rf_ladder = h->d_rf;
+    return VA_OK;
+}
+
+// pinned poll word, timing events, initial seed states
+int finish_create(va_handle h)
+{
+    hipError_t e = hipHostMalloc((void **)&h->h_nactive, 4 * sizeof(int), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(VA_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e));
+    e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e != hipSuccess) return fail(VA_EHIP, "hipEventCreate: %s", hipGetErrorString(e));
+    e = hipStreamSynchronize(h->stream);     // host staging buffers must be consumed before we return
+    if (e != hipSuccess) return fail(VA_EHIP, "create sync: %s", hipGetErrorString(e));
+    launch_init_states(h->dv, PH_IDLE, 1.0, h->stream);
+    return VA_OK;
 }
 
 int copy_in(va_handle h, const double *XP, int64_t ld, int32_t mem)
@@ -363,7 +411,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     }
 
     int rc = VA_OK;
-    const size_t B = dm.B, ld = dm.ld;
+    const size_t B = dm.B;
     int *lmap_d = nullptr, *pidx_d = nullptr;
     double *Y_d = nullptr, *rm_d = nullptr, *rf_d = nullptr, *P_d = nullptr, *t_d = nullptr, *st_d = nullptr;
 #define TRY(x) do { rc = (x); if (rc) { va_problem_destroy(h); return rc; } } while (0)
@@ -375,23 +423,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     if (d->rf_kind) TRY(h->alloc(&rf_d, (size_t)(dm.N - 1) * dm.D));
     if (d->t_model) TRY(h->alloc(&t_d, (size_t)dm.N));
     if (d->n_stim > 0) TRY(h->alloc(&st_d, (size_t)dm.N * d->n_stim));
-    TRY(h->alloc(&dv.x, B * ld)); TRY(h->alloc(&dv.g, B * ld));
-    TRY(h->alloc(&dv.gt, B * ld)); TRY(h->alloc(&dv.d, B * ld));
-    TRY(h->alloc(&dv.S, B * m * ld)); TRY(h->alloc(&dv.Y, B * m * ld));
-    TRY(h->alloc(&dv.st, B));
-    TRY(h->alloc(&dv.evp, B * dm.nprow * EP_N));
-    TRY(h->alloc(&dv.upp, B * dm.nchunks * dv.ups));
-    TRY(h->alloc(&dv.dpp, B * dm.nchunks * DP_N));
-    TRY(h->alloc(&h->d_rf, (size_t)max_beta));
-    TRY(h->alloc(&dv.ame, B * max_beta * 3));
-    TRY(h->alloc(&dv.pest, B * max_beta * (dm.NPest ? dm.NPest : 1)));
-    TRY(h->alloc(&dv.status, B * max_beta)); TRY(h->alloc(&dv.nit, B * max_beta));
-    TRY(h->alloc(&dv.nfev, B * max_beta));
-    if (d->keep_paths) TRY(h->alloc(&dv.minpaths, B * max_beta * (size_t)(dm.ND + dm.NP), false));
-    TRY(h->alloc(&dv.n_active, 1));
-    TRY(h->alloc(&dv.n_evals, 1));
-    TRY(h->alloc(&dv.outA, B)); TRY(h->alloc(&dv.outme, B)); TRY(h->alloc(&dv.outfe, B));
-    dv.rf_ladder = h->d_rf;
+    TRY(alloc_solver_state(h, max_beta, d->keep_paths));
 
     std::vector<int> lmap(dm.D, -1);
     for (int l = 0; l < dm.L; ++l) lmap[d->Lidx[l]] = l;
@@ -409,14 +441,131 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dv.pp.Pidx = pidx_d; dv.pp.Pfull = P_d;
     dv.pp.tmodel = t_d; dv.pp.stim = st_d; dv.pp.nstim = d->n_stim;
 
-    hipError_t e = hipHostMalloc((void **)&h->h_nactive, 4 * sizeof(int), hipHostMallocDefault);
-    if (e != hipSuccess) { va_problem_destroy(h); return fail(VA_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e)); }
-    e = hipEventCreate(&h->ev0);
-    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
-    if (e != hipSuccess) { va_problem_destroy(h); return fail(VA_EHIP, "hipEventCreate: %s", hipGetErrorString(e)); }
-    e = hipStreamSynchronize(h->stream);     // lmap (stack vector) must be consumed before we return
-    if (e != hipSuccess) { va_problem_destroy(h); return fail(VA_EHIP, "create sync: %s", hipGetErrorString(e)); }
-    launch_init_states(dv, PH_IDLE, 1.0, h->stream);
+    TRY(finish_create(h));
+#undef TRY
+#undef H2D
+    *out = h;
+    return VA_OK;
+}
+
+int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
+{
+    if (!d || !out) return fail(VA_EINVAL, "null argument");
+    *out = nullptr;
+    if (d->struct_size != (int32_t)sizeof(va_nnet_desc)) return fail(VA_EINVAL, "struct_size %d != %zu", d->struct_size, sizeof(va_nnet_desc));
+    if (d->batch < 1 || d->n_layers < 2 || d->M < 1 || !d->structure) return fail(VA_EINVAL, "bad sizes (batch=%d n_layers=%d M=%d)", d->batch, d->n_layers, d->M);
+    if (d->activation < VA_ACT_SIGMOID || d->activation > VA_ACT_LINEAR) return fail(VA_EUNSUPPORTED, "unknown activation %d", d->activation);
+    const int NL = d->n_layers;
+    std::vector<int> s(d->structure, d->structure + NL), off(NL + 1, 0), woff(NL - 1), boff(NL - 1);
+    long long np = 0;
+    for (int n = 0; n < NL; ++n) {
+        if (s[n] < 1) return fail(VA_EINVAL, "structure[%d]=%d", n, s[n]);
+        off[n + 1] = off[n] + s[n];
+    }
+    for (int n = 0; n < NL - 1; ++n) { woff[n] = (int)np; np += (long long)s[n + 1] * s[n]; boff[n] = (int)np; np += s[n + 1]; }
+    if (np != d->NP) return fail(VA_EINVAL, "NP=%d but the structure holds %lld weights and biases (va_nnet.py:194-207)", d->NP, np);
+    if (d->NPest < 0 || d->NPest > d->NP || !d->P || (d->NPest > 0 && !d->Pidx)) return fail(VA_EINVAL, "bad NPest/P/Pidx");
+    if (d->L_in < 0 || d->L_out < 0 || (d->L_in > 0 && (!d->Lidx_in || !d->data_in)) || (d->L_out > 0 && (!d->Lidx_out || !d->data_out)))
+        return fail(VA_EINVAL, "observed-neuron arrays missing");
+    if (d->L_in + d->L_out < 1) return fail(VA_EINVAL, "no observed neurons: the measurement error divides by Ltot*M (va_nnet.py:173)");
+    const int NDnet = off[NL];
+    const long long nvar = (long long)NDnet * d->M + d->NPest;
+    if (nvar > 2000000000LL) return fail(VA_EUNSUPPORTED, "n_var=%lld does not fit 32-bit indexing", nvar);
+    std::vector<int> lin(s[0], -1), lout(s[NL - 1], -1), pmap(d->NP, -1);
+    for (int l = 0; l < d->L_in; ++l) {
+        if (d->Lidx_in[l] < 0 || d->Lidx_in[l] >= s[0]) return fail(VA_EINVAL, "Lidx_in[%d]=%d outside the input layer", l, d->Lidx_in[l]);
+        lin[d->Lidx_in[l]] = l;
+    }
+    for (int l = 0; l < d->L_out; ++l) {
+        if (d->Lidx_out[l] < 0 || d->Lidx_out[l] >= s[NL - 1]) return fail(VA_EINVAL, "Lidx_out[%d]=%d outside the output layer", l, d->Lidx_out[l]);
+        lout[d->Lidx_out[l]] = l;
+    }
+    for (int k = 0; k < d->NPest; ++k) {
+        if (d->Pidx[k] < 0 || d->Pidx[k] >= d->NP) return fail(VA_EINVAL, "Pidx[%d]=%d outside [0,NP)", k, d->Pidx[k]);
+        if (pmap[d->Pidx[k]] >= 0) return fail(VA_EINVAL, "Pidx[%d]=%d listed twice", k, d->Pidx[k]);
+        pmap[d->Pidx[k]] = k;
+    }
+    const int m = d->lbfgs_m > 0 ? d->lbfgs_m : 10;
+    if (m > MAX_M) return fail(VA_EINVAL, "lbfgs_m=%d > %d", m, MAX_M);
+    const int max_beta = d->max_beta > 0 ? d->max_beta : 1;
+
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (d->device < 0 || d->device >= ndev) return fail(VA_EINVAL, "device %d of %d", d->device, ndev);
+    HIPCHK(hipSetDevice(d->device));
+
+    va_handle h = new va_problem_s();
+    h->device = d->device; h->rhs = -1; h->keep_paths = d->keep_paths; h->is_nnet = true;
+    if (d->stream) h->stream = (hipStream_t)d->stream;
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete h; return fail(VA_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        h->own_stream = true;
+    }
+    Dev &dv = h->dv;
+    memset(&dv, 0, sizeof dv);
+    NnetDev &nn = h->nn;
+    memset(&nn, 0, sizeof nn);
+    Dims &dm = dv.dm;
+    // to the L-BFGS kernels the unknown vector is one flat run of ND doubles with no tail
+    dm.D = NDnet; dm.N = d->M; dm.ND = (int)nvar; dm.NP = 0; dm.NPest = 0; dm.B = d->batch; dm.m = m;
+    dm.L = d->L_in + d->L_out; dm.N_data = d->M; dm.nskip = 1; dm.disc = VA_DISC_FORWARDMAP;
+    dm.ld = ((dm.ND + 15) / 16) * 16;
+    dm.chunk = VEC_CHUNK; dm.nchunks = (dm.ld + VEC_CHUNK - 1) / VEC_CHUNK;
+    dm.cme = 1.0 / ((double)(d->L_in + d->L_out) * d->M);                 /* va_nnet.py:173 */
+    dm.cfe = d->rf0 / ((double)(NDnet - s[0]) * d->M);                    /* va_nnet.py:255 */
+    dm.rm = d->rm_in; dm.rf0 = d->rf0;
+    dv.ups = UP_OLD + 4 * m; dv.max_beta = max_beta; dv.nbeta = 1;
+    dv.o.m = m; dv.o.maxiter = 15000; dv.o.maxls = 20; dv.o.maxfun = 15000; dv.o.ftol = 2.2204460492503131e-09; dv.o.gtol = 1e-5;
+
+    nn.NL = NL; nn.M = d->M; nn.NDnet = NDnet; nn.NDens = NDnet * d->M; nn.NP = d->NP; nn.NPest = d->NPest;
+    nn.act = d->activation; nn.Lin = d->L_in; nn.Lout = d->L_out; nn.rm_in = d->rm_in; nn.rm_out = d->rm_out;
+    // job tables: one entry per 32x32 output tile
+    std::vector<NnetTile> t1, t2, t3;
+    nn.mch = d->M <= 256 ? ((d->M + NN_KC - 1) / NN_KC) * NN_KC : 256;
+    nn.nmch = (d->M + nn.mch - 1) / nn.mch;
+    for (int n = 0; n < NL - 1; ++n)
+        for (int m0 = 0; m0 < d->M; m0 += NN_TILE)
+            for (int i0 = 0; i0 < s[n + 1]; i0 += NN_TILE) t1.push_back(NnetTile{n, m0, i0, 0});
+    for (int n = 0; n < NL; ++n)
+        for (int m0 = 0; m0 < d->M; m0 += NN_TILE)
+            for (int j0 = 0; j0 < s[n]; j0 += NN_TILE) t2.push_back(NnetTile{n, m0, j0, 0});
+    for (int n = 0; n < NL - 1; ++n)
+        for (int c = 0; c < nn.nmch; ++c)
+            for (int i0 = 0; i0 < s[n + 1]; i0 += NN_TILE)
+                for (int j0 = 0; j0 < s[n]; j0 += NN_TILE) t3.push_back(NnetTile{n, i0, j0, c});
+    nn.n1 = (int)t1.size(); nn.n2 = (int)t2.size(); nn.n3 = (int)t3.size();
+    nn.n4 = (d->NP + NN_THREADS - 1) / NN_THREADS;
+    dm.nprow = nn.n1 + nn.n2 + nn.n4;
+    dm.ntiles = dm.nprow; dm.T = NN_TILE; dm.emode = 0;
+
+    int rc = VA_OK;
+    const size_t B = dm.B;
+    int *s_d = nullptr, *off_d = nullptr, *woff_d = nullptr, *boff_d = nullptr, *lin_d = nullptr, *lout_d = nullptr, *pmap_d = nullptr;
+    double *din_d = nullptr, *dout_d = nullptr, *P_d = nullptr;
+    NnetTile *t1_d = nullptr, *t2_d = nullptr, *t3_d = nullptr;
+#define TRY(x) do { rc = (x); if (rc) { va_problem_destroy(h); return rc; } } while (0)
+#define H2D(dst, src, n, T) do { hipError_t e_ = hipMemcpyAsync(dst, src, sizeof(T) * (n), hipMemcpyHostToDevice, h->stream); \
+        if (e_ != hipSuccess) { va_problem_destroy(h); return fail(VA_EHIP, "H2D %s: %s", #dst, hipGetErrorString(e_)); } } while (0)
+    TRY(h->alloc(&s_d, NL)); TRY(h->alloc(&off_d, NL + 1)); TRY(h->alloc(&woff_d, NL - 1)); TRY(h->alloc(&boff_d, NL - 1));
+    TRY(h->alloc(&lin_d, s[0])); TRY(h->alloc(&lout_d, s[NL - 1])); TRY(h->alloc(&pmap_d, d->NP));
+    TRY(h->alloc(&din_d, (size_t)d->M * d->L_in)); TRY(h->alloc(&dout_d, (size_t)d->M * d->L_out));
+    TRY(h->alloc(&P_d, B * d->NP)); TRY(h->alloc(&nn.Pw, B * d->NP));
+    TRY(h->alloc(&nn.delta, B * dm.ld));
+    TRY(h->alloc(&nn.gpart, B * nn.nmch * (size_t)d->NP));
+    TRY(h->alloc(&t1_d, t1.size())); TRY(h->alloc(&t2_d, t2.size())); TRY(h->alloc(&t3_d, t3.size()));
+    TRY(alloc_solver_state(h, max_beta, d->keep_paths));
+    H2D(s_d, s.data(), NL, int); H2D(off_d, off.data(), NL + 1, int);
+    H2D(woff_d, woff.data(), NL - 1, int); H2D(boff_d, boff.data(), NL - 1, int);
+    H2D(lin_d, lin.data(), s[0], int); H2D(lout_d, lout.data(), s[NL - 1], int); H2D(pmap_d, pmap.data(), d->NP, int);
+    if (d->L_in) H2D(din_d, d->data_in, (size_t)d->M * d->L_in, double);
+    if (d->L_out) H2D(dout_d, d->data_out, (size_t)d->M * d->L_out, double);
+    H2D(P_d, d->P, B * d->NP, double);
+    H2D(t1_d, t1.data(), t1.size(), NnetTile); H2D(t2_d, t2.data(), t2.size(), NnetTile);
+    if (!t3.empty()) H2D(t3_d, t3.data(), t3.size(), NnetTile);
+    nn.s = s_d; nn.off = off_d; nn.woff = woff_d; nn.boff = boff_d; nn.lmap_in = lin_d; nn.lmap_out = lout_d;
+    nn.pmap = pmap_d; nn.din = din_d; nn.dout = dout_d; nn.Pfix = P_d; nn.t1 = t1_d; nn.t2 = t2_d; nn.t3 = t3_d;
+    TRY(finish_create(h));
 #undef TRY
 #undef H2D
     *out = h;

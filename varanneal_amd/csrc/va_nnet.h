@@ -1,0 +1,40 @@
+// va_nnet.h -- device image of the feed-forward-network action (reference:
+// varanneal/va_nnet.py:111-255).  The unknown vector of one seed is
+//     [ X: M examples x NDnet neuron states (example-major, layers in order) | estimated params ]
+// (va_nnet.py:440) and rides in the same x/g/gt/d/S/Y arrays and the same L-BFGS kernels as
+// the ODE path (Dims.ND = M*NDnet + NPest, Dims.NPest = 0); only the evaluator differs.
+#pragma once
+#include "va_device.h"
+
+namespace va {
+
+enum { NNET_SIGMOID = 0, NNET_TANH = 1, NNET_LINEAR = 2 };
+
+constexpr int NN_TILE = 32;      // workgroup output tile (2 x 2 waves of one 16x16 MFMA block each)
+constexpr int NN_KC = 32;        // K elements staged in LDS per step
+constexpr int NN_THREADS = 256;
+
+// one workgroup's job: rows [r0, r0+32) x columns [c0, c0+32) of a layer's product
+struct NnetTile { int layer, r0, c0, chunk; };
+
+struct NnetDev {
+    int NL, M, NDnet, NDens, NP, NPest, act;
+    int Lin, Lout;
+    double rm_in, rm_out;          // measurement weights (va_nnet.py:132-147)
+    const int *s, *off;            // [NL] layer widths, [NL+1] offsets inside one example
+    const int *woff, *boff;        // [NL-1] offsets of W_n (s[n+1] x s[n], row-major) and b_n in P
+    const int *lmap_in, *lmap_out; // [s[0]], [s[NL-1]] -> observed index or -1
+    const double *din, *dout;      // [M][Lin], [M][Lout]
+    const int *pmap;               // [NP] -> index among the estimated parameters or -1
+    const double *Pfix;            // [B][NP] fixed values (entries of estimated parameters unused)
+    double *Pw;                    // [B][NP] full parameter vector at the trial point
+    double *delta;                 // [B][ld]  dA/dz, indexed like X (layer-0 slots unused)
+    double *gpart;                 // [B][nmch][NP] parameter-gradient partials per example chunk
+    const NnetTile *t1, *t2, *t3;  // job tables of the three product kernels
+    int n1, n2, n3, n4;            // workgroups per seed (n4: parameter reduce)
+    int mch, nmch;                 // examples per chunk of the weight-gradient product, chunks
+};
+
+void launch_nnet_eval(const Dev &dv, const NnetDev &nn, hipStream_t s);
+
+}  // namespace va

@@ -1,0 +1,368 @@
+// va_nnet.hip -- action + gradient of the feed-forward-network model error
+// (reference: varanneal/va_nnet.py:111-255; activation examples/nnet_twin/nnet_twin_anneal.py:20-22).
+//
+// In the variational formulation every layer state of every training example is an unknown,
+// so the N-1 layer transitions are independent given X: there is no sequential forward pass.
+// With Z_n = X_n W_n^T + b_n (examples x neurons), a = act(Z_n), r = X_{n+1} - a,
+// q = 2 RF c r, delta = -q act'(Z_n):
+//     dA/dX_{n+1} += q                       (direct)
+//     dA/dX_n     += delta W_n               (product 2)
+//     dA/dW_n      = delta^T X_n,  dA/db_n = sum_m delta        (product 3)
+// Three float64 products per layer, all on v_mfma_f64_16x16x4_f64:
+//   k_nnet_fwd    Z tile -> residual, delta, q              (writes delta, q into gt, fe partial)
+//   k_nnet_bwd_x  delta W + q + measurement term -> gt       (me, g.d, g.g, max|g| partials)
+//   k_nnet_bwd_w  delta^T X per chunk of examples -> gpart   (no atomics: fixed-order reduce in
+//   k_nnet_pred   sum over chunks, scatter to the estimated-parameter tail of gt)
+// A workgroup owns a 32x32 output tile (4 waves, one 16x16 accumulator block each); K is
+// staged through LDS 32 at a time with the next step's global loads already in flight.
+// Operand tiles that are contiguous along K in memory are stored [row][k] (pitch 36), tiles
+// contiguous along the row/column index are stored [k][row] (pitch 48): both pitches make the
+// 16x4 MFMA fragment read hit 32 distinct 8-byte banks per half-wave.
+#include "va_nnet.h"
+#include "va_eval_flat.h"
+
+namespace va {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int PRK = NN_KC + 4;     // [row][k] pitch: 36 = 4 (mod 32)
+constexpr int PKR = NN_TILE + 16;  // [k][row] pitch: 48 = 16 (mod 32)
+
+template <int ACT> __device__ __forceinline__ double act_f(double z)
+{
+    if (ACT == NNET_SIGMOID) return 1.0 / (1.0 + exp(-z));
+    if (ACT == NNET_TANH) return tanh(z);
+    return z;
+}
+template <int ACT> __device__ __forceinline__ double act_d(double a)
+{
+    if (ACT == NNET_SIGMOID) return a * (1.0 - a);
+    if (ACT == NNET_TANH) return 1.0 - a * a;
+    return 1.0;
+}
+
+// ---- global -> register -> LDS tile movers (256 threads, 4 elements each) -------------------
+// element (r, k) at base[r*rs + k]; lanes run along k (32 contiguous doubles per half-wave)
+template <bool TRIAL>
+__device__ __forceinline__ void load_rk(const double *base, const double *dbase, size_t rs, int nr, int nk,
+                                        double stp, int t, double v[4])
+{
+    const int k = t & 31;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = (t >> 5) + 8 * u;
+        double x = 0.0;
+        if (r < nr && k < nk) {
+            x = base[(size_t)r * rs + k];
+            if (TRIAL) x = trial(x, stp, dbase[(size_t)r * rs + k]);
+        }
+        v[u] = x;
+    }
+}
+__device__ __forceinline__ void store_rk(double *L, int t, const double v[4])
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) L[((t >> 5) + 8 * u) * PRK + (t & 31)] = v[u];
+}
+// element (k, r) at base[k*ks + r]; lanes run along r
+template <bool TRIAL>
+__device__ __forceinline__ void load_kr(const double *base, const double *dbase, size_t ks, int nr, int nk,
+                                        double stp, int t, double v[4])
+{
+    const int r = t & 31;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = (t >> 5) + 8 * u;
+        double x = 0.0;
+        if (r < nr && k < nk) {
+            x = base[(size_t)k * ks + r];
+            if (TRIAL) x = trial(x, stp, dbase[(size_t)k * ks + r]);
+        }
+        v[u] = x;
+    }
+}
+__device__ __forceinline__ void store_kr(double *L, int t, const double v[4])
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) L[((t >> 5) + 8 * u) * PKR + (t & 31)] = v[u];
+}
+
+// ---- one K step of 32 on the matrix cores: acc[16x16] += A[16 x 32] B[32 x 16] ---------------
+// fragment layout of v_mfma_f64_16x16x4_f64: lane l feeds A[row = l&15][k = l>>4] and
+// B[k = l>>4][col = l&15]; result register i of lane l is C[row = (l>>4) + 4i][col = l&15].
+template <bool A_RK, bool B_RK>
+__device__ __forceinline__ d4 mma_step(const double *As, const double *Bs, int wr, int wc, int lane, d4 acc)
+{
+    const int lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < NN_KC / 4; ++kk) {
+        const int k = 4 * kk + hi;
+        const double a = A_RK ? As[(wr * 16 + lo) * PRK + k] : As[k * PKR + wr * 16 + lo];
+        const double b = B_RK ? Bs[(wc * 16 + lo) * PRK + k] : Bs[k * PKR + wc * 16 + lo];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ bool seed_live(const Dev &dv, int b, int &use_d, double &stp, double &rf)
+{
+    const SeedState &st = dv.st[b];
+    const int phase = st.phase;
+    use_d = (phase == PH_LS);
+    stp = use_d ? st.stp : 0.0;        // fma(0, d, x) == x: one code path for both cases
+    rf = st.rf_scale;
+    return phase == PH_START || phase == PH_LS;
+}
+
+// workgroup reduction of up to 4 values (k == 3 is a max), thread 0 gets the totals
+__device__ __forceinline__ void wg_reduce4(double v[4], double *red, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double w = (k == 3) ? wave_max(v[k]) : wave_sum(v[k]);
+        if (lane == 0) red[wave * 4 + k] = w;
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double w = red[k];
+            for (int ww = 1; ww < NN_THREADS / 64; ++ww) w = (k == 3) ? fmax(w, red[ww * 4 + k]) : w + red[ww * 4 + k];
+            v[k] = w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K0: full parameter vector
+__global__ __launch_bounds__(NN_THREADS) void k_nnet_pack(const Dev dv, const NnetDev nn)
+{
+    const int b = blockIdx.y, j = blockIdx.x * NN_THREADS + threadIdx.x;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf) || j >= nn.NP) return;
+    const int k = nn.pmap[j];
+    double v;
+    if (k >= 0) {
+        const size_t i = (size_t)b * dv.dm.ld + nn.NDens + k;
+        v = trial(dv.x[i], stp, dv.d[i]);
+    } else v = nn.Pfix[(size_t)b * nn.NP + j];
+    nn.Pw[(size_t)b * nn.NP + j] = v;
+}
+
+// ------------------------------------------------------------------ K1: Z, residual, delta
+template <int ACT>
+__global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const NnetDev nn)
+{
+    __shared__ double As[NN_TILE * PRK], Bs[NN_TILE * PRK], red[16];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    const NnetTile tl = nn.t1[blockIdx.x];
+    const int n = tl.layer, m0 = tl.r0, i0 = tl.c0;
+    const int sn = nn.s[n], sn1 = nn.s[n + 1], K = sn;
+    const size_t vo = (size_t)b * dv.dm.ld;
+    const size_t xo = vo + (size_t)m0 * nn.NDnet + nn.off[n];
+    const double *W = nn.Pw + (size_t)b * nn.NP + nn.woff[n] + (size_t)i0 * sn;
+    const int nra = min(NN_TILE, nn.M - m0), nrb = min(NN_TILE, sn1 - i0);
+    const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    double va[4], vb[4];
+    load_rk<true>(dv.x + xo, dv.d + xo, nn.NDnet, nra, K, stp, tid, va);
+    load_rk<false>(W, nullptr, sn, nrb, K, 0.0, tid, vb);
+    for (int k0 = 0; k0 < K; k0 += NN_KC) {
+        store_rk(As, tid, va); store_rk(Bs, tid, vb);
+        __syncthreads();
+        if (k0 + NN_KC < K) {
+            load_rk<true>(dv.x + xo + k0 + NN_KC, dv.d + xo + k0 + NN_KC, nn.NDnet, nra, K - k0 - NN_KC, stp, tid, va);
+            load_rk<false>(W + k0 + NN_KC, nullptr, sn, nrb, K - k0 - NN_KC, 0.0, tid, vb);
+        }
+        acc = mma_step<true, true>(As, Bs, wr, wc, lane, acc);
+        __syncthreads();
+    }
+    // epilogue: lane holds Z[m][i] for i = column (16 consecutive neurons per 16 lanes)
+    const int i = i0 + wc * 16 + (lane & 15);
+    const double cq = 2.0 * rf * dv.dm.cfe;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (i < sn1) {
+        const double bias = nn.Pw[(size_t)b * nn.NP + nn.boff[n] + i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wr * 16 + (lane >> 4) + 4 * r;
+            if (m >= nn.M) continue;
+            const size_t idx = vo + (size_t)m * nn.NDnet + nn.off[n + 1] + i;
+            const double a = act_f<ACT>(acc[r] + bias);
+            const double res = trial(dv.x[idx], stp, dv.d[idx]) - a;
+            const double q = cq * res;
+            v[1] += res * res;
+            nn.delta[idx] = -q * act_d<ACT>(a);
+            dv.gt[idx] = q;
+        }
+    }
+    wg_reduce4(v, red, tid);
+    if (tid == 0) {
+        double *row = dv.evp + ((size_t)b * dv.dm.nprow + blockIdx.x) * EP_N;
+        row[EP_ME] = 0.0; row[EP_FE] = v[1]; row[EP_GTD] = 0.0; row[EP_GN2] = 0.0; row[EP_GMAX] = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------ K2: dA/dX
+__global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_x(const Dev dv, const NnetDev nn)
+{
+    __shared__ double As[NN_TILE * PRK], Bs[NN_KC * PKR], red[16];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    const NnetTile tl = nn.t2[blockIdx.x];
+    const int n = tl.layer, m0 = tl.r0, j0 = tl.c0;
+    const int sn = nn.s[n];
+    const int K = (n < nn.NL - 1) ? nn.s[n + 1] : 0;
+    const size_t vo = (size_t)b * dv.dm.ld;
+    const int nra = min(NN_TILE, nn.M - m0), nrb = min(NN_TILE, sn - j0);
+    const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    if (K > 0) {
+        const double *Dl = nn.delta + vo + (size_t)m0 * nn.NDnet + nn.off[n + 1];
+        const double *W = nn.Pw + (size_t)b * nn.NP + nn.woff[n] + j0;
+        double va[4], vb[4];
+        load_rk<false>(Dl, nullptr, nn.NDnet, nra, K, 0.0, tid, va);
+        load_kr<false>(W, nullptr, sn, nrb, K, 0.0, tid, vb);
+        for (int k0 = 0; k0 < K; k0 += NN_KC) {
+            store_rk(As, tid, va); store_kr(Bs, tid, vb);
+            __syncthreads();
+            if (k0 + NN_KC < K) {
+                load_rk<false>(Dl + k0 + NN_KC, nullptr, nn.NDnet, nra, K - k0 - NN_KC, 0.0, tid, va);
+                load_kr<false>(W + (size_t)(k0 + NN_KC) * sn, nullptr, sn, nrb, K - k0 - NN_KC, 0.0, tid, vb);
+            }
+            acc = mma_step<true, false>(As, Bs, wr, wc, lane, acc);
+            __syncthreads();
+        }
+    }
+    const int j = j0 + wc * 16 + (lane & 15);
+    double v[4] = {0.0, 0.0, 0.0, 0.0};          // me, g.d, g.g, max|g|
+    if (j < sn) {
+        int l = -1; double rm = 0.0; const double *dat = nullptr; int L = 0;
+        if (n == 0) { l = nn.lmap_in[j]; rm = nn.rm_in; dat = nn.din; L = nn.Lin; }
+        else if (n == nn.NL - 1) { l = nn.lmap_out[j]; rm = nn.rm_out; dat = nn.dout; L = nn.Lout; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wr * 16 + (lane >> 4) + 4 * r;
+            if (m >= nn.M) continue;
+            const size_t idx = vo + (size_t)m * nn.NDnet + nn.off[n] + j;
+            double g = acc[r];
+            if (n > 0) g += dv.gt[idx];                       // q left by k_nnet_fwd
+            const double dd = dv.d[idx];
+            if (l >= 0) {
+                const double diff = trial(dv.x[idx], stp, dd) - dat[(size_t)m * L + l];
+                v[0] += rm * diff * diff;
+                g += 2.0 * dv.dm.cme * rm * diff;
+            }
+            dv.gt[idx] = g;
+            if (use_d) v[1] += g * dd;
+            v[2] += g * g;
+            v[3] = fmax(v[3], fabs(g));
+        }
+    }
+    wg_reduce4(v, red, tid);
+    if (tid == 0) {
+        double *row = dv.evp + ((size_t)b * dv.dm.nprow + nn.n1 + blockIdx.x) * EP_N;
+        row[EP_ME] = v[0]; row[EP_FE] = 0.0; row[EP_GTD] = v[1]; row[EP_GN2] = v[2]; row[EP_GMAX] = v[3];
+    }
+}
+
+// ------------------------------------------------------------------ K3: dA/dW, dA/db per chunk
+__global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_w(const Dev dv, const NnetDev nn)
+{
+    __shared__ double As[NN_KC * PKR], Bs[NN_KC * PKR];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    const NnetTile tl = nn.t3[blockIdx.x];
+    const int n = tl.layer, i0 = tl.r0, j0 = tl.c0;
+    const int sn = nn.s[n], sn1 = nn.s[n + 1];
+    const int mb = tl.chunk * nn.mch;
+    const int K = min(nn.mch, nn.M - mb);                       // examples in this chunk
+    const size_t vo = (size_t)b * dv.dm.ld;
+    const size_t ao = vo + (size_t)mb * nn.NDnet + nn.off[n + 1] + i0;
+    const size_t bo = vo + (size_t)mb * nn.NDnet + nn.off[n] + j0;
+    const int nra = min(NN_TILE, sn1 - i0), nrb = min(NN_TILE, sn - j0);
+    const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    double va[4], vb[4], bsum = 0.0;
+    load_kr<false>(nn.delta + ao, nullptr, nn.NDnet, nra, K, 0.0, tid, va);
+    load_kr<true>(dv.x + bo, dv.d + bo, nn.NDnet, nrb, K, stp, tid, vb);
+    for (int k0 = 0; k0 < K; k0 += NN_KC) {
+        store_kr(As, tid, va); store_kr(Bs, tid, vb);
+        __syncthreads();
+        if (k0 + NN_KC < K) {
+            const size_t sh = (size_t)(k0 + NN_KC) * nn.NDnet;
+            load_kr<false>(nn.delta + ao + sh, nullptr, nn.NDnet, nra, K - k0 - NN_KC, 0.0, tid, va);
+            load_kr<true>(dv.x + bo + sh, dv.d + bo + sh, nn.NDnet, nrb, K - k0 - NN_KC, stp, tid, vb);
+        }
+        acc = mma_step<false, false>(As, Bs, wr, wc, lane, acc);
+        if (j0 == 0 && tid < NN_TILE) {                         // bias gradient: column sums of delta
+#pragma unroll 8
+            for (int k = 0; k < NN_KC; ++k) bsum += As[k * PKR + tid];
+        }
+        __syncthreads();
+    }
+    double *gp = nn.gpart + ((size_t)b * nn.nmch + tl.chunk) * nn.NP;
+    const int j = j0 + wc * 16 + (lane & 15);
+    if (j < sn) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + wr * 16 + (lane >> 4) + 4 * r;
+            if (i < sn1) gp[nn.woff[n] + (size_t)i * sn + j] = acc[r];
+        }
+    }
+    if (j0 == 0 && tid < NN_TILE && i0 + tid < sn1) gp[nn.boff[n] + i0 + tid] = bsum;
+}
+
+// ------------------------------------------------------------------ K4: parameter tail of grad A
+__global__ __launch_bounds__(NN_THREADS) void k_nnet_pred(const Dev dv, const NnetDev nn)
+{
+    __shared__ double red[16];
+    const int b = blockIdx.y, tid = threadIdx.x, j = blockIdx.x * NN_THREADS + tid;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (j < nn.NP) {
+        const int k = nn.pmap[j];
+        if (k >= 0) {
+            const double *gp = nn.gpart + (size_t)b * nn.nmch * nn.NP + j;
+            double g = 0.0;
+            for (int c = 0; c < nn.nmch; ++c) g += gp[(size_t)c * nn.NP];
+            const size_t i = (size_t)b * dv.dm.ld + nn.NDens + k;
+            dv.gt[i] = g;
+            if (use_d) v[1] = g * dv.d[i];
+            v[2] = g * g;
+            v[3] = fabs(g);
+        }
+    }
+    wg_reduce4(v, red, tid);
+    if (tid == 0) {
+        double *row = dv.evp + ((size_t)b * dv.dm.nprow + nn.n1 + nn.n2 + blockIdx.x) * EP_N;
+        row[EP_ME] = 0.0; row[EP_FE] = 0.0; row[EP_GTD] = v[1]; row[EP_GN2] = v[2]; row[EP_GMAX] = v[3];
+    }
+}
+
+void launch_nnet_eval(const Dev &dv, const NnetDev &nn, hipStream_t s)
+{
+    const int B = dv.dm.B;
+    const dim3 blk(NN_THREADS);
+    hipLaunchKernelGGL(k_nnet_pack, dim3(nn.n4, B), blk, 0, s, dv, nn);
+    switch (nn.act) {
+    case NNET_SIGMOID: hipLaunchKernelGGL(k_nnet_fwd<NNET_SIGMOID>, dim3(nn.n1, B), blk, 0, s, dv, nn); break;
+    case NNET_TANH: hipLaunchKernelGGL(k_nnet_fwd<NNET_TANH>, dim3(nn.n1, B), blk, 0, s, dv, nn); break;
+    default: hipLaunchKernelGGL(k_nnet_fwd<NNET_LINEAR>, dim3(nn.n1, B), blk, 0, s, dv, nn); break;
+    }
+    hipLaunchKernelGGL(k_nnet_bwd_x, dim3(nn.n2, B), blk, 0, s, dv, nn);
+    if (nn.NPest > 0) {
+        hipLaunchKernelGGL(k_nnet_bwd_w, dim3(nn.n3, B), blk, 0, s, dv, nn);
+        hipLaunchKernelGGL(k_nnet_pred, dim3(nn.n4, B), blk, 0, s, dv, nn);
+    }
+}
+
+}  // namespace va
