@@ -14,6 +14,9 @@ Workloads (BASELINE.json configs):
   c3 (default)  Lorenz-96 D=20,  N=1000, L=7,  B=64 seeds per GPU, trapezoid
   c4            Lorenz-96 D=200, N=5000, L=80, B=64 seeds per GPU, trapezoid
   c2            Lorenz-96 D=20,  N=1000, L=7,  B=1  (parity config; launch-bound)
+  c5            va_nnet twin: structure [10]*20, M=2 examples, 1900 weights estimated, B=64 seeds
+  c5x           the same action scaled to where the layer products fill the matrix cores:
+                structure [128]*8, M=2048 examples, B=16 seeds (roofline bound: f64 MFMA)
 """
 import argparse
 import json
@@ -35,6 +38,12 @@ WORKLOADS = {
     "c3x16": dict(D=20, N=1000, B=1024, name="lorenz96_D20_N1000_L7_B1024_trapezoid"),
     "c3x64": dict(D=20, N=1000, B=4096, name="lorenz96_D20_N1000_L7_B4096_trapezoid"),
 }
+NNET_WORKLOADS = {
+    "c5": dict(structure=[10] * 20, M=2, B=64, name="nnet_twin_10x20_M2_B64_sigmoid"),
+    "c5x": dict(structure=[128] * 8, M=2048, B=16, name="nnet_128x8_M2048_B16_sigmoid"),
+}
+F64_MFMA_PEAK_TFLOPS = 78.6    # MI355X FP64 matrix = FP64 vector rate (half the 157.3 TF FP32 rows of
+                               # MI355X_MICROARCH.md; v_mfma_f64_16x16x4_f64: 2048 flop / 64 cycles / SIMD)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 RF_SCALE = 1.5 ** 15           # mid-ladder RF (value does not change the work)
 
@@ -86,6 +95,81 @@ def cpu_baseline(D, N, Y, Lidx, XP, P, budget_s=10.0):
                       % (n, D, N, dt, os.cpu_count() or 0)}
 
 
+def nnet_main(args, rank, local_rank, world, dist, torch):
+    """C5: (A, grad A) of the feed-forward-network action; one step = one batched evaluation
+    (k_nnet_pack, k_nnet_fwd, k_nnet_bwd_x, k_nnet_bwd_w, k_nnet_pred) of B seeds."""
+    from varanneal_amd import _capi, twin
+    w = NNET_WORKLOADS[args.workload]
+    s, M, B = np.array(w["structure"]), w["M"], w["B"]
+    din, dout, _ = twin.make_nnet_twin(s, M)
+    Lidx = [np.arange(s[0]), np.arange(s[-1])]
+    RM = 1.0 / 0.005 ** 2
+    RF0 = 1.0e-8 * RM * float(np.sum(s) - s[0]) / float(s[0] + s[-1])       # nnet_twin_anneal.py:45
+    g = [twin.nnet_initial_guess(s, M, rank * B + b) for b in range(B)]
+    Pidx = g[0][2]
+    P = np.array([x[1] for x in g])
+    XP = np.array([np.append(x[0], x[1][Pidx]) for x in g])
+    pb = _capi.NnetProblem(B, s, din, dout, Lidx, RM, RF0, P, Pidx, device=local_rank)
+    rf = 1.1 ** 100
+    A, me, fe, gr = pb.action_grad(XP, rf)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    pb.eval_timed(rf, max(args.warmup, 1))
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = pb.eval_timed(rf, args.steps)
+    if dist is not None:
+        mine = torch.from_numpy(A).cuda()
+        allA = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allA, mine)
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall, kernel_ms = float(tmax[0]), float(tmax[1])
+    if rank != 0:
+        return
+    # three products per layer transition: Z = X W^T, dX = delta W, dW = delta^T X
+    flops = B * M * float(np.sum(3 * 2 * s[1:] * s[:-1]))
+    balg = 8 * (B * (2 * (M * int(np.sum(s)) + len(Pidx)) + 3) + din.size + dout.size)
+    ks = kernel_ms * 1e-3 / args.steps
+    out = {
+        "metric": "action+grad evals/sec, va_nnet %s M=%d" % ("x".join(str(v) for v in (s[0], len(s))), M),
+        "value": world * B * args.steps / wall, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic (sigmoid twin network, sigma=0.005, seeded)",
+        "config": {"workload": w["name"], "seeds_per_gpu": B, "structure": [int(v) for v in s], "M": M,
+                   "n_var": int(XP.shape[1]), "parallelism": "seeds sharded, %d per GPU" % B},
+        "roofline": {"bound": "mfma", "achieved": flops / ks / 1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flops / ks / 1e12 / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "kernel": "k_nnet_fwd + k_nnet_bwd_x + k_nnet_bwd_w (+ pack, pred): one evaluation",
+                     "kernel_us": ks * 1e6, "flops_alg_per_launch": flops, "bytes_alg_per_launch": balg,
+                     "hbm_frac_of_8TBs": balg / ks / 1e9 / HBM_PEAK_GBS},
+        "cpu_baseline": None,
+    }
+    if world == 1 and not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import va_nnet_oracle as vno
+        from threadpoolctl import threadpool_limits
+        pbo = vno.NnetProblem(s, din, dout, Lidx, RM, RF0, P[0], Pidx)
+        with threadpool_limits(limits=1):
+            pbo.action_grad(XP[0], rf)
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 10.0:
+                pbo.action_grad(XP[n % B], rf); n += 1
+            dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
+                               "sample": "%d (A,gradA) evaluations by oracle/va_nnet_oracle.py (NumPy, BLAS limited "
+                                         "to 1 thread) in %.1f s on 1 of %d host cores" % (n, dt, os.cpu_count() or 0)}
+    print(json.dumps(out), flush=True)
+    pb.close()
+
+
 def ladder_mode(args, pb0, XP, P, D, N, B, Y, Lidx, device):
     """Whole ladder (alpha=1.5, beta=0..nbeta-1, SciPy-equal stopping rules) for B seeds;
     reports end-to-end seed-evaluations/s including every L-BFGS vector kernel."""
@@ -117,7 +201,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS) + sorted(NNET_WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--mode", default="eval", choices=["eval", "ladder"],
@@ -139,6 +223,11 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
 
+    if args.workload in NNET_WORKLOADS:
+        nnet_main(args, rank, local_rank, world, dist, torch)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     from varanneal_amd import _capi, twin
     w = WORKLOADS[args.workload]
     D, N, B = w["D"], w["N"], w["B"]

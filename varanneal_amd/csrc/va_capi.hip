@@ -536,7 +536,10 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
                 for (int j0 = 0; j0 < s[n]; j0 += NN_TILE) t3.push_back(NnetTile{n, i0, j0, c});
     nn.n1 = (int)t1.size(); nn.n2 = (int)t2.size(); nn.n3 = (int)t3.size();
     nn.n4 = (d->NP + NN_THREADS - 1) / NN_THREADS;
-    dm.nprow = nn.n1 + nn.n2 + nn.n4;
+    nn.n0 = (nn.NDens + d->NP + NN_THREADS - 1) / NN_THREADS;
+    nn.nraw = nn.n1 + nn.n2 + nn.n4;
+    const bool fold_rows = nn.nraw > NN_ROWS_DIRECT;      // k_ls sums the rows with one wave: keep them few
+    dm.nprow = fold_rows ? NN_RED_ROWS : nn.nraw;
     dm.ntiles = dm.nprow; dm.T = NN_TILE; dm.emode = 0;
 
     int rc = VA_OK;
@@ -552,6 +555,8 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
     TRY(h->alloc(&din_d, (size_t)d->M * d->L_in)); TRY(h->alloc(&dout_d, (size_t)d->M * d->L_out));
     TRY(h->alloc(&P_d, B * d->NP)); TRY(h->alloc(&nn.Pw, B * d->NP));
     TRY(h->alloc(&nn.delta, B * dm.ld));
+    TRY(h->alloc(&nn.Xw, B * dm.ld));
+    if (fold_rows) TRY(h->alloc(&nn.raw, B * nn.nraw * EP_GP));
     TRY(h->alloc(&nn.gpart, B * nn.nmch * (size_t)d->NP));
     TRY(h->alloc(&t1_d, t1.size())); TRY(h->alloc(&t2_d, t2.size())); TRY(h->alloc(&t3_d, t3.size()));
     TRY(alloc_solver_state(h, max_beta, d->keep_paths));

@@ -10,11 +10,13 @@ namespace va {
 
 enum { NNET_SIGMOID = 0, NNET_TANH = 1, NNET_LINEAR = 2 };
 
-constexpr int NN_TILE = 32;      // workgroup output tile (2 x 2 waves of one 16x16 MFMA block each)
+constexpr int NN_TILE = 64;      // workgroup output tile: 2 x 2 waves, each 2 x 2 MFMA blocks of 16x16
 constexpr int NN_KC = 32;        // K elements staged in LDS per step
 constexpr int NN_THREADS = 256;
 
-// one workgroup's job: rows [r0, r0+32) x columns [c0, c0+32) of a layer's product
+constexpr int NN_ROWS_DIRECT = 64;   // partial rows per seed the line-search kernel reduces itself
+constexpr int NN_RED_ROWS = 32;      // rows left by k_nnet_rows when there are more
+// one workgroup's job: rows [r0, r0+64) x columns [c0, c0+64) of a layer's product
 struct NnetTile { int layer, r0, c0, chunk; };
 
 struct NnetDev {
@@ -28,11 +30,15 @@ struct NnetDev {
     const int *pmap;               // [NP] -> index among the estimated parameters or -1
     const double *Pfix;            // [B][NP] fixed values (entries of estimated parameters unused)
     double *Pw;                    // [B][NP] full parameter vector at the trial point
+    double *Xw;                    // [B][ld] neuron states at the trial point x + stp*d
     double *delta;                 // [B][ld]  dA/dz, indexed like X (layer-0 slots unused)
     double *gpart;                 // [B][nmch][NP] parameter-gradient partials per example chunk
     const NnetTile *t1, *t2, *t3;  // job tables of the three product kernels
     int n1, n2, n3, n4;            // workgroups per seed (n4: parameter reduce)
     int mch, nmch;                 // examples per chunk of the weight-gradient product, chunks
+    int n0;                        // workgroups per seed of the pack kernel
+    int nraw;                      // partial rows per seed written by the kernels (n1 + n2 + n4)
+    double *raw;                   // NULL (rows go straight to Dev::evp) or [B][nraw][EP_GP]
 };
 
 void launch_nnet_eval(const Dev &dv, const NnetDev &nn, hipStream_t s);

@@ -9,15 +9,19 @@
 //     dA/dX_n     += delta W_n               (product 2)
 //     dA/dW_n      = delta^T X_n,  dA/db_n = sum_m delta        (product 3)
 // Three float64 products per layer, all on v_mfma_f64_16x16x4_f64:
+//   k_nnet_pack   trial point: Xw = x + stp d, Pw = fixed | x + stp d   (read once, not per tile)
 //   k_nnet_fwd    Z tile -> residual, delta, q              (writes delta, q into gt, fe partial)
 //   k_nnet_bwd_x  delta W + q + measurement term -> gt       (me, g.d, g.g, max|g| partials)
 //   k_nnet_bwd_w  delta^T X per chunk of examples -> gpart   (no atomics: fixed-order reduce in
 //   k_nnet_pred   sum over chunks, scatter to the estimated-parameter tail of gt)
-// A workgroup owns a 32x32 output tile (4 waves, one 16x16 accumulator block each); K is
-// staged through LDS 32 at a time with the next step's global loads already in flight.
-// Operand tiles that are contiguous along K in memory are stored [row][k] (pitch 36), tiles
-// contiguous along the row/column index are stored [k][row] (pitch 48): both pitches make the
-// 16x4 MFMA fragment read hit 32 distinct 8-byte banks per half-wave.
+//   k_nnet_rows   (large problems only) folds the per-workgroup partial rows to 32 per seed
+// A workgroup owns a 64x64 output tile: 2 x 2 waves, each wave 2 x 2 MFMA blocks (32 x 32, four
+// accumulators) so every LDS fragment read feeds two matrix instructions.  K is staged through
+// LDS 32 at a time with the next step's global loads already in flight.  Operand tiles that
+// are contiguous along K in memory are stored [row][k] (pitch 36), tiles contiguous along the
+// row/column index are stored [k][row] (pitch 80): both pitches make the 16x4 MFMA fragment
+// read hit 32 distinct 8-byte banks per half-wave.  MFMA blocks that lie wholly outside the
+// matrix (narrow layers, few examples) are skipped wave-uniformly.
 #include "va_nnet.h"
 #include "va_eval_flat.h"
 
@@ -26,7 +30,8 @@ namespace va {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int PRK = NN_KC + 4;     // [row][k] pitch: 36 = 4 (mod 32)
-constexpr int PKR = NN_TILE + 16;  // [k][row] pitch: 48 = 16 (mod 32)
+constexpr int PKR = NN_TILE + 16;  // [k][row] pitch: 80 = 16 (mod 32)
+constexpr int NLD = NN_TILE * NN_KC / NN_THREADS;   // elements per thread per operand tile (8)
 
 template <int ACT> __device__ __forceinline__ double act_f(double z)
 {
@@ -41,67 +46,75 @@ template <int ACT> __device__ __forceinline__ double act_d(double a)
     return 1.0;
 }
 
-// ---- global -> register -> LDS tile movers (256 threads, 4 elements each) -------------------
-// element (r, k) at base[r*rs + k]; lanes run along k (32 contiguous doubles per half-wave)
-template <bool TRIAL>
-__device__ __forceinline__ void load_rk(const double *base, const double *dbase, size_t rs, int nr, int nk,
-                                        double stp, int t, double v[4])
+// ---- global -> register -> LDS tile movers (256 threads, 8 elements each) -------------------
+// element (r, k) at base[r*rs + k], 64 rows x 32 k; lanes run along k
+__device__ __forceinline__ void load_rk(const double *base, size_t rs, int nr, int nk, int t, double v[NLD])
 {
     const int k = t & 31;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NLD; ++u) {
         const int r = (t >> 5) + 8 * u;
-        double x = 0.0;
-        if (r < nr && k < nk) {
-            x = base[(size_t)r * rs + k];
-            if (TRIAL) x = trial(x, stp, dbase[(size_t)r * rs + k]);
-        }
-        v[u] = x;
+        v[u] = (r < nr && k < nk) ? base[(size_t)r * rs + k] : 0.0;
     }
 }
-__device__ __forceinline__ void store_rk(double *L, int t, const double v[4])
+__device__ __forceinline__ void store_rk(double *L, int t, const double v[NLD])
 {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) L[((t >> 5) + 8 * u) * PRK + (t & 31)] = v[u];
+    for (int u = 0; u < NLD; ++u) L[((t >> 5) + 8 * u) * PRK + (t & 31)] = v[u];
 }
-// element (k, r) at base[k*ks + r]; lanes run along r
-template <bool TRIAL>
-__device__ __forceinline__ void load_kr(const double *base, const double *dbase, size_t ks, int nr, int nk,
-                                        double stp, int t, double v[4])
+// element (k, r) at base[k*ks + r], 32 k x 64 r; lanes run along r
+__device__ __forceinline__ void load_kr(const double *base, size_t ks, int nr, int nk, int t, double v[NLD])
 {
-    const int r = t & 31;
+    const int r = t & 63;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int k = (t >> 5) + 8 * u;
-        double x = 0.0;
-        if (r < nr && k < nk) {
-            x = base[(size_t)k * ks + r];
-            if (TRIAL) x = trial(x, stp, dbase[(size_t)k * ks + r]);
-        }
-        v[u] = x;
+    for (int u = 0; u < NLD; ++u) {
+        const int k = (t >> 6) + 4 * u;
+        v[u] = (r < nr && k < nk) ? base[(size_t)k * ks + r] : 0.0;
     }
 }
-__device__ __forceinline__ void store_kr(double *L, int t, const double v[4])
+__device__ __forceinline__ void store_kr(double *L, int t, const double v[NLD])
 {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) L[((t >> 5) + 8 * u) * PKR + (t & 31)] = v[u];
+    for (int u = 0; u < NLD; ++u) L[((t >> 6) + 4 * u) * PKR + (t & 63)] = v[u];
 }
 
-// ---- one K step of 32 on the matrix cores: acc[16x16] += A[16 x 32] B[32 x 16] ---------------
+// ---- one K step of 32 on the matrix cores: acc[2][2] (32x32) += A[32 x 32] B[32 x 32] -------
 // fragment layout of v_mfma_f64_16x16x4_f64: lane l feeds A[row = l&15][k = l>>4] and
 // B[k = l>>4][col = l&15]; result register i of lane l is C[row = (l>>4) + 4i][col = l&15].
+// live: bit (2*bi + bj) set <=> block (bi, bj) of this wave intersects the matrix.
 template <bool A_RK, bool B_RK>
-__device__ __forceinline__ d4 mma_step(const double *As, const double *Bs, int wr, int wc, int lane, d4 acc)
+__device__ __forceinline__ void mma_step(const double *As, const double *Bs, int wr, int wc, int lane, int live,
+                                         d4 acc[2][2])
 {
     const int lo = lane & 15, hi = lane >> 4;
+    if (!live) return;
 #pragma unroll
     for (int kk = 0; kk < NN_KC / 4; ++kk) {
         const int k = 4 * kk + hi;
-        const double a = A_RK ? As[(wr * 16 + lo) * PRK + k] : As[k * PKR + wr * 16 + lo];
-        const double b = B_RK ? Bs[(wc * 16 + lo) * PRK + k] : Bs[k * PKR + wc * 16 + lo];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        double a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = wr * 32 + i * 16 + lo, c = wc * 32 + i * 16 + lo;
+            a[i] = A_RK ? As[r * PRK + k] : As[k * PKR + r];
+            b[i] = B_RK ? Bs[c * PRK + k] : Bs[k * PKR + c];
+        }
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 2; ++bj)
+                if (live & (1 << (2 * bi + bj)))
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bi], b[bj], acc[bi][bj], 0, 0, 0);
     }
-    return acc;
+}
+__device__ __forceinline__ int live_mask(int wr, int wc, int nra, int nrb)
+{
+    int m = 0;
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+            if (wr * 32 + bi * 16 < nra && wc * 32 + bj * 16 < nrb) m |= 1 << (2 * bi + bj);
+    return m;
 }
 
 __device__ __forceinline__ bool seed_live(const Dev &dv, int b, int &use_d, double &stp, double &rf)
@@ -109,12 +122,12 @@ __device__ __forceinline__ bool seed_live(const Dev &dv, int b, int &use_d, doub
     const SeedState &st = dv.st[b];
     const int phase = st.phase;
     use_d = (phase == PH_LS);
-    stp = use_d ? st.stp : 0.0;        // fma(0, d, x) == x: one code path for both cases
+    stp = use_d ? st.stp : 0.0;
     rf = st.rf_scale;
     return phase == PH_START || phase == PH_LS;
 }
 
-// workgroup reduction of up to 4 values (k == 3 is a max), thread 0 gets the totals
+// workgroup reduction of 4 values (k == 3 is a max), thread 0 gets the totals
 __device__ __forceinline__ void wg_reduce4(double v[4], double *red, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
@@ -133,20 +146,37 @@ __device__ __forceinline__ void wg_reduce4(double v[4], double *red, int tid)
         }
     }
 }
+// partial row r of seed b: straight into the table the line-search kernel reads, or into the
+// raw table k_nnet_rows folds
+__device__ __forceinline__ void put_row(const Dev &dv, const NnetDev &nn, int b, int r, double me, double fe,
+                                        double gtd, double gn2, double gmax)
+{
+    double *row = nn.raw ? nn.raw + ((size_t)b * nn.nraw + r) * EP_GP
+                         : dv.evp + ((size_t)b * dv.dm.nprow + r) * EP_N;
+    row[EP_ME] = me; row[EP_FE] = fe; row[EP_GTD] = gtd; row[EP_GN2] = gn2; row[EP_GMAX] = gmax;
+}
 
-// ------------------------------------------------------------------ K0: full parameter vector
+// ------------------------------------------------------------------ K0: trial point
 __global__ __launch_bounds__(NN_THREADS) void k_nnet_pack(const Dev dv, const NnetDev nn)
 {
-    const int b = blockIdx.y, j = blockIdx.x * NN_THREADS + threadIdx.x;
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * NN_THREADS + threadIdx.x;
     int use_d; double stp, rf;
-    if (!seed_live(dv, b, use_d, stp, rf) || j >= nn.NP) return;
-    const int k = nn.pmap[j];
-    double v;
-    if (k >= 0) {
-        const size_t i = (size_t)b * dv.dm.ld + nn.NDens + k;
-        v = trial(dv.x[i], stp, dv.d[i]);
-    } else v = nn.Pfix[(size_t)b * nn.NP + j];
-    nn.Pw[(size_t)b * nn.NP + j] = v;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    const size_t vo = (size_t)b * dv.dm.ld;
+    if (i < nn.NDens) {
+        double v = dv.x[vo + i];
+        if (use_d) v = trial(v, stp, dv.d[vo + i]);
+        nn.Xw[vo + i] = v;
+    } else if (i < nn.NDens + nn.NP) {
+        const int j = i - nn.NDens, k = nn.pmap[j];
+        double v;
+        if (k >= 0) {
+            v = dv.x[vo + nn.NDens + k];
+            if (use_d) v = trial(v, stp, dv.d[vo + nn.NDens + k]);
+        } else v = nn.Pfix[(size_t)b * nn.NP + j];
+        nn.Pw[(size_t)b * nn.NP + j] = v;
+    }
 }
 
 // ------------------------------------------------------------------ K1: Z, residual, delta
@@ -161,49 +191,51 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const Nne
     const int n = tl.layer, m0 = tl.r0, i0 = tl.c0;
     const int sn = nn.s[n], sn1 = nn.s[n + 1], K = sn;
     const size_t vo = (size_t)b * dv.dm.ld;
-    const size_t xo = vo + (size_t)m0 * nn.NDnet + nn.off[n];
+    const double *X = nn.Xw + vo + (size_t)m0 * nn.NDnet + nn.off[n];
     const double *W = nn.Pw + (size_t)b * nn.NP + nn.woff[n] + (size_t)i0 * sn;
     const int nra = min(NN_TILE, nn.M - m0), nrb = min(NN_TILE, sn1 - i0);
     const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int live = live_mask(wr, wc, nra, nrb);
 
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
-    double va[4], vb[4];
-    load_rk<true>(dv.x + xo, dv.d + xo, nn.NDnet, nra, K, stp, tid, va);
-    load_rk<false>(W, nullptr, sn, nrb, K, 0.0, tid, vb);
+    d4 acc[2][2] = {};
+    double va[NLD], vb[NLD];
+    load_rk(X, nn.NDnet, nra, K, tid, va);
+    load_rk(W, sn, nrb, K, tid, vb);
     for (int k0 = 0; k0 < K; k0 += NN_KC) {
         store_rk(As, tid, va); store_rk(Bs, tid, vb);
         __syncthreads();
         if (k0 + NN_KC < K) {
-            load_rk<true>(dv.x + xo + k0 + NN_KC, dv.d + xo + k0 + NN_KC, nn.NDnet, nra, K - k0 - NN_KC, stp, tid, va);
-            load_rk<false>(W + k0 + NN_KC, nullptr, sn, nrb, K - k0 - NN_KC, 0.0, tid, vb);
+            load_rk(X + k0 + NN_KC, nn.NDnet, nra, K - k0 - NN_KC, tid, va);
+            load_rk(W + k0 + NN_KC, sn, nrb, K - k0 - NN_KC, tid, vb);
         }
-        acc = mma_step<true, true>(As, Bs, wr, wc, lane, acc);
+        mma_step<true, true>(As, Bs, wr, wc, lane, live, acc);
         __syncthreads();
     }
-    // epilogue: lane holds Z[m][i] for i = column (16 consecutive neurons per 16 lanes)
-    const int i = i0 + wc * 16 + (lane & 15);
+    // epilogue: lane holds Z[m][i], 16 consecutive neurons i per 16 lanes
     const double cq = 2.0 * rf * dv.dm.cfe;
     double v[4] = {0.0, 0.0, 0.0, 0.0};
-    if (i < sn1) {
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+        const int i = i0 + wc * 32 + bj * 16 + (lane & 15);
+        if (i >= sn1) continue;
         const double bias = nn.Pw[(size_t)b * nn.NP + nn.boff[n] + i];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wr * 16 + (lane >> 4) + 4 * r;
-            if (m >= nn.M) continue;
-            const size_t idx = vo + (size_t)m * nn.NDnet + nn.off[n + 1] + i;
-            const double a = act_f<ACT>(acc[r] + bias);
-            const double res = trial(dv.x[idx], stp, dv.d[idx]) - a;
-            const double q = cq * res;
-            v[1] += res * res;
-            nn.delta[idx] = -q * act_d<ACT>(a);
-            dv.gt[idx] = q;
-        }
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
+                if (m >= nn.M) continue;
+                const size_t idx = vo + (size_t)m * nn.NDnet + nn.off[n + 1] + i;
+                const double a = act_f<ACT>(acc[bi][bj][r] + bias);
+                const double res = nn.Xw[idx] - a;
+                const double q = cq * res;
+                v[1] += res * res;
+                nn.delta[idx] = -q * act_d<ACT>(a);
+                dv.gt[idx] = q;
+            }
     }
     wg_reduce4(v, red, tid);
-    if (tid == 0) {
-        double *row = dv.evp + ((size_t)b * dv.dm.nprow + blockIdx.x) * EP_N;
-        row[EP_ME] = 0.0; row[EP_FE] = v[1]; row[EP_GTD] = 0.0; row[EP_GN2] = 0.0; row[EP_GMAX] = 0.0;
-    }
+    if (tid == 0) put_row(dv, nn, b, blockIdx.x, 0.0, v[1], 0.0, 0.0, 0.0);
 }
 
 // ------------------------------------------------------------------ K2: dA/dX
@@ -220,55 +252,56 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_x(const Dev dv, const N
     const size_t vo = (size_t)b * dv.dm.ld;
     const int nra = min(NN_TILE, nn.M - m0), nrb = min(NN_TILE, sn - j0);
     const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int live = live_mask(wr, wc, nra, nrb);
 
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    d4 acc[2][2] = {};
     if (K > 0) {
         const double *Dl = nn.delta + vo + (size_t)m0 * nn.NDnet + nn.off[n + 1];
         const double *W = nn.Pw + (size_t)b * nn.NP + nn.woff[n] + j0;
-        double va[4], vb[4];
-        load_rk<false>(Dl, nullptr, nn.NDnet, nra, K, 0.0, tid, va);
-        load_kr<false>(W, nullptr, sn, nrb, K, 0.0, tid, vb);
+        double va[NLD], vb[NLD];
+        load_rk(Dl, nn.NDnet, nra, K, tid, va);
+        load_kr(W, sn, nrb, K, tid, vb);
         for (int k0 = 0; k0 < K; k0 += NN_KC) {
             store_rk(As, tid, va); store_kr(Bs, tid, vb);
             __syncthreads();
             if (k0 + NN_KC < K) {
-                load_rk<false>(Dl + k0 + NN_KC, nullptr, nn.NDnet, nra, K - k0 - NN_KC, 0.0, tid, va);
-                load_kr<false>(W + (size_t)(k0 + NN_KC) * sn, nullptr, sn, nrb, K - k0 - NN_KC, 0.0, tid, vb);
+                load_rk(Dl + k0 + NN_KC, nn.NDnet, nra, K - k0 - NN_KC, tid, va);
+                load_kr(W + (size_t)(k0 + NN_KC) * sn, sn, nrb, K - k0 - NN_KC, tid, vb);
             }
-            acc = mma_step<true, false>(As, Bs, wr, wc, lane, acc);
+            mma_step<true, false>(As, Bs, wr, wc, lane, live, acc);
             __syncthreads();
         }
     }
-    const int j = j0 + wc * 16 + (lane & 15);
     double v[4] = {0.0, 0.0, 0.0, 0.0};          // me, g.d, g.g, max|g|
-    if (j < sn) {
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+        const int j = j0 + wc * 32 + bj * 16 + (lane & 15);
+        if (j >= sn) continue;
         int l = -1; double rm = 0.0; const double *dat = nullptr; int L = 0;
         if (n == 0) { l = nn.lmap_in[j]; rm = nn.rm_in; dat = nn.din; L = nn.Lin; }
         else if (n == nn.NL - 1) { l = nn.lmap_out[j]; rm = nn.rm_out; dat = nn.dout; L = nn.Lout; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wr * 16 + (lane >> 4) + 4 * r;
-            if (m >= nn.M) continue;
-            const size_t idx = vo + (size_t)m * nn.NDnet + nn.off[n] + j;
-            double g = acc[r];
-            if (n > 0) g += dv.gt[idx];                       // q left by k_nnet_fwd
-            const double dd = dv.d[idx];
-            if (l >= 0) {
-                const double diff = trial(dv.x[idx], stp, dd) - dat[(size_t)m * L + l];
-                v[0] += rm * diff * diff;
-                g += 2.0 * dv.dm.cme * rm * diff;
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
+                if (m >= nn.M) continue;
+                const size_t idx = vo + (size_t)m * nn.NDnet + nn.off[n] + j;
+                double g = acc[bi][bj][r];
+                if (n > 0) g += dv.gt[idx];                       // q left by k_nnet_fwd
+                if (l >= 0) {
+                    const double diff = nn.Xw[idx] - dat[(size_t)m * L + l];
+                    v[0] += rm * diff * diff;
+                    g += 2.0 * dv.dm.cme * rm * diff;
+                }
+                dv.gt[idx] = g;
+                if (use_d) v[1] += g * dv.d[idx];
+                v[2] += g * g;
+                v[3] = fmax(v[3], fabs(g));
             }
-            dv.gt[idx] = g;
-            if (use_d) v[1] += g * dd;
-            v[2] += g * g;
-            v[3] = fmax(v[3], fabs(g));
-        }
     }
     wg_reduce4(v, red, tid);
-    if (tid == 0) {
-        double *row = dv.evp + ((size_t)b * dv.dm.nprow + nn.n1 + blockIdx.x) * EP_N;
-        row[EP_ME] = v[0]; row[EP_FE] = 0.0; row[EP_GTD] = v[1]; row[EP_GN2] = v[2]; row[EP_GMAX] = v[3];
-    }
+    if (tid == 0) put_row(dv, nn, b, nn.n1 + blockIdx.x, v[0], 0.0, v[1], v[2], v[3]);
 }
 
 // ------------------------------------------------------------------ K3: dA/dW, dA/db per chunk
@@ -284,24 +317,25 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_w(const Dev dv, const N
     const int mb = tl.chunk * nn.mch;
     const int K = min(nn.mch, nn.M - mb);                       // examples in this chunk
     const size_t vo = (size_t)b * dv.dm.ld;
-    const size_t ao = vo + (size_t)mb * nn.NDnet + nn.off[n + 1] + i0;
-    const size_t bo = vo + (size_t)mb * nn.NDnet + nn.off[n] + j0;
+    const double *Dl = nn.delta + vo + (size_t)mb * nn.NDnet + nn.off[n + 1] + i0;
+    const double *X = nn.Xw + vo + (size_t)mb * nn.NDnet + nn.off[n] + j0;
     const int nra = min(NN_TILE, sn1 - i0), nrb = min(NN_TILE, sn - j0);
     const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int live = live_mask(wr, wc, nra, nrb);
 
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
-    double va[4], vb[4], bsum = 0.0;
-    load_kr<false>(nn.delta + ao, nullptr, nn.NDnet, nra, K, 0.0, tid, va);
-    load_kr<true>(dv.x + bo, dv.d + bo, nn.NDnet, nrb, K, stp, tid, vb);
+    d4 acc[2][2] = {};
+    double va[NLD], vb[NLD], bsum = 0.0;
+    load_kr(Dl, nn.NDnet, nra, K, tid, va);
+    load_kr(X, nn.NDnet, nrb, K, tid, vb);
     for (int k0 = 0; k0 < K; k0 += NN_KC) {
         store_kr(As, tid, va); store_kr(Bs, tid, vb);
         __syncthreads();
         if (k0 + NN_KC < K) {
             const size_t sh = (size_t)(k0 + NN_KC) * nn.NDnet;
-            load_kr<false>(nn.delta + ao + sh, nullptr, nn.NDnet, nra, K - k0 - NN_KC, 0.0, tid, va);
-            load_kr<true>(dv.x + bo + sh, dv.d + bo + sh, nn.NDnet, nrb, K - k0 - NN_KC, stp, tid, vb);
+            load_kr(Dl + sh, nn.NDnet, nra, K - k0 - NN_KC, tid, va);
+            load_kr(X + sh, nn.NDnet, nrb, K - k0 - NN_KC, tid, vb);
         }
-        acc = mma_step<false, false>(As, Bs, wr, wc, lane, acc);
+        mma_step<false, false>(As, Bs, wr, wc, lane, live, acc);
         if (j0 == 0 && tid < NN_TILE) {                         // bias gradient: column sums of delta
 #pragma unroll 8
             for (int k = 0; k < NN_KC; ++k) bsum += As[k * PKR + tid];
@@ -309,13 +343,17 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_w(const Dev dv, const N
         __syncthreads();
     }
     double *gp = nn.gpart + ((size_t)b * nn.nmch + tl.chunk) * nn.NP;
-    const int j = j0 + wc * 16 + (lane & 15);
-    if (j < sn) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = i0 + wr * 16 + (lane >> 4) + 4 * r;
-            if (i < sn1) gp[nn.woff[n] + (size_t)i * sn + j] = acc[r];
-        }
+    for (int bj = 0; bj < 2; ++bj) {
+        const int j = j0 + wc * 32 + bj * 16 + (lane & 15);
+        if (j >= sn) continue;
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
+                if (i < sn1) gp[nn.woff[n] + (size_t)i * sn + j] = acc[bi][bj][r];
+            }
     }
     if (j0 == 0 && tid < NN_TILE && i0 + tid < sn1) gp[nn.boff[n] + i0 + tid] = bsum;
 }
@@ -342,17 +380,38 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_pred(const Dev dv, const Nn
         }
     }
     wg_reduce4(v, red, tid);
-    if (tid == 0) {
-        double *row = dv.evp + ((size_t)b * dv.dm.nprow + nn.n1 + nn.n2 + blockIdx.x) * EP_N;
-        row[EP_ME] = 0.0; row[EP_FE] = 0.0; row[EP_GTD] = v[1]; row[EP_GN2] = v[2]; row[EP_GMAX] = v[3];
+    if (tid == 0) put_row(dv, nn, b, nn.n1 + nn.n2 + blockIdx.x, 0.0, 0.0, v[1], v[2], v[3]);
+}
+
+// ------------------------------------------------------------------ K5: fold the partial rows
+// NN_RED_ROWS workgroups of one wave per seed: workgroup w sums raw rows w, w+32, ... in a
+// fixed order (lane = (row phase, column)), so k_ls / k_finalize_eval see 32 rows per seed.
+__global__ __launch_bounds__(64) void k_nnet_rows(const Dev dv, const NnetDev nn)
+{
+    const int b = blockIdx.y, w = blockIdx.x, lane = threadIdx.x;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    const int c = lane & 7, ph = lane >> 3;                      // 8 columns (5 used) x 8 row phases
+    const double *raw = nn.raw + (size_t)b * nn.nraw * EP_GP;
+    double v = 0.0;
+    if (c < EP_GP)
+        for (int r = w + NN_RED_ROWS * ph; r < nn.nraw; r += NN_RED_ROWS * 8) {
+            const double x = raw[(size_t)r * EP_GP + c];
+            v = (c == EP_GMAX) ? fmax(v, x) : v + x;
+        }
+#pragma unroll
+    for (int o = 32; o >= 8; o >>= 1) {
+        const double x = __shfl_down(v, o, 64);
+        v = (c == EP_GMAX) ? fmax(v, x) : v + x;
     }
+    if (lane < EP_GP) dv.evp[((size_t)b * dv.dm.nprow + w) * EP_N + lane] = v;
 }
 
 void launch_nnet_eval(const Dev &dv, const NnetDev &nn, hipStream_t s)
 {
     const int B = dv.dm.B;
     const dim3 blk(NN_THREADS);
-    hipLaunchKernelGGL(k_nnet_pack, dim3(nn.n4, B), blk, 0, s, dv, nn);
+    hipLaunchKernelGGL(k_nnet_pack, dim3(nn.n0, B), blk, 0, s, dv, nn);
     switch (nn.act) {
     case NNET_SIGMOID: hipLaunchKernelGGL(k_nnet_fwd<NNET_SIGMOID>, dim3(nn.n1, B), blk, 0, s, dv, nn); break;
     case NNET_TANH: hipLaunchKernelGGL(k_nnet_fwd<NNET_TANH>, dim3(nn.n1, B), blk, 0, s, dv, nn); break;
@@ -363,6 +422,7 @@ void launch_nnet_eval(const Dev &dv, const NnetDev &nn, hipStream_t s)
         hipLaunchKernelGGL(k_nnet_bwd_w, dim3(nn.n3, B), blk, 0, s, dv, nn);
         hipLaunchKernelGGL(k_nnet_pred, dim3(nn.n4, B), blk, 0, s, dv, nn);
     }
+    if (nn.raw) hipLaunchKernelGGL(k_nnet_rows, dim3(NN_RED_ROWS, B), dim3(64), 0, s, dv, nn);
 }
 
 }  // namespace va
