@@ -524,20 +524,36 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
     std::vector<NnetTile> t1, t2, t3;
     nn.mch = d->M <= 256 ? ((d->M + NN_KC - 1) / NN_KC) * NN_KC : 256;
     nn.nmch = (d->M + nn.mch - 1) / nn.mch;
+    auto tile = [&](int n, int r0, int c0, int c) {
+        NnetTile t;
+        memset(&t, 0, sizeof t);
+        t.layer = n; t.r0 = r0; t.c0 = c0; t.chunk = c; t.sn = s[n]; t.offn = off[n];
+        if (n < NL - 1) { t.sn1 = s[n + 1]; t.offn1 = off[n + 1]; t.woff = woff[n]; t.boff = boff[n]; }
+        return t;
+    };
     for (int n = 0; n < NL - 1; ++n)
         for (int m0 = 0; m0 < d->M; m0 += NN_TILE)
-            for (int i0 = 0; i0 < s[n + 1]; i0 += NN_TILE) t1.push_back(NnetTile{n, m0, i0, 0});
+            for (int i0 = 0; i0 < s[n + 1]; i0 += NN_TILE) t1.push_back(tile(n, m0, i0, 0));
     for (int n = 0; n < NL; ++n)
         for (int m0 = 0; m0 < d->M; m0 += NN_TILE)
-            for (int j0 = 0; j0 < s[n]; j0 += NN_TILE) t2.push_back(NnetTile{n, m0, j0, 0});
+            for (int j0 = 0; j0 < s[n]; j0 += NN_TILE) t2.push_back(tile(n, m0, j0, 0));
     for (int n = 0; n < NL - 1; ++n)
         for (int c = 0; c < nn.nmch; ++c)
             for (int i0 = 0; i0 < s[n + 1]; i0 += NN_TILE)
-                for (int j0 = 0; j0 < s[n]; j0 += NN_TILE) t3.push_back(NnetTile{n, i0, j0, c});
+                for (int j0 = 0; j0 < s[n]; j0 += NN_TILE) t3.push_back(tile(n, i0, j0, c));
     nn.n1 = (int)t1.size(); nn.n2 = (int)t2.size(); nn.n3 = (int)t3.size();
     nn.n4 = (d->NP + NN_THREADS - 1) / NN_THREADS;
     nn.n0 = (nn.NDens + d->NP + NN_THREADS - 1) / NN_THREADS;
     nn.nraw = nn.n1 + nn.n2 + nn.n4;
+    // small networks: one workgroup per layer does the whole evaluation (k_nnet_small)
+    {
+        int widest = d->M;
+        for (int n = 0; n < NL; ++n) widest = s[n] > widest ? s[n] : widest;
+        nn.small = (widest <= NN_SMALL && NL <= NN_ROWS_DIRECT) ? (widest <= 16 ? 16 : 32) : 0;
+        const char *e = getenv("VA_NNET_SMALL");                      // tests: force the tiled path
+        if (e && atoi(e) == 0) nn.small = 0;
+    }
+    if (nn.small) nn.nraw = NL;
     const bool fold_rows = nn.nraw > NN_ROWS_DIRECT;      // k_ls sums the rows with one wave: keep them few
     dm.nprow = fold_rows ? NN_RED_ROWS : nn.nraw;
     dm.ntiles = dm.nprow; dm.T = NN_TILE; dm.emode = 0;

@@ -14,10 +14,12 @@ constexpr int NN_TILE = 64;      // workgroup output tile: 2 x 2 waves, each 2 x
 constexpr int NN_KC = 32;        // K elements staged in LDS per step
 constexpr int NN_THREADS = 256;
 
+constexpr int NN_SMALL = 32;         // widest layer / most examples the single-kernel path handles
 constexpr int NN_ROWS_DIRECT = 64;   // partial rows per seed the line-search kernel reduces itself
 constexpr int NN_RED_ROWS = 32;      // rows left by k_nnet_rows when there are more
 // one workgroup's job: rows [r0, r0+64) x columns [c0, c0+64) of a layer's product
-struct NnetTile { int layer, r0, c0, chunk; };
+// (layer metadata rides in the entry so a workgroup needs ONE dependent load before its data)
+struct NnetTile { int layer, r0, c0, chunk, sn, sn1, offn, offn1, woff, boff, pad0, pad1; };
 
 struct NnetDev {
     int NL, M, NDnet, NDens, NP, NPest, act;
@@ -36,6 +38,8 @@ struct NnetDev {
     const NnetTile *t1, *t2, *t3;  // job tables of the three product kernels
     int n1, n2, n3, n4;            // workgroups per seed (n4: parameter reduce)
     int mch, nmch;                 // examples per chunk of the weight-gradient product, chunks
+    int small;                     // 0, or rows staged per operand (16 / 32) when every layer and M fit one
+                                   // 32x32 tile and k_nnet_small does the whole evaluation
     int n0;                        // workgroups per seed of the pack kernel
     int nraw;                      // partial rows per seed written by the kernels (n1 + n2 + n4)
     double *raw;                   // NULL (rows go straight to Dev::evp) or [B][nraw][EP_GP]

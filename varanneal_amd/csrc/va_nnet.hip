@@ -188,11 +188,11 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const Nne
     int use_d; double stp, rf;
     if (!seed_live(dv, b, use_d, stp, rf)) return;
     const NnetTile tl = nn.t1[blockIdx.x];
-    const int n = tl.layer, m0 = tl.r0, i0 = tl.c0;
-    const int sn = nn.s[n], sn1 = nn.s[n + 1], K = sn;
+    const int m0 = tl.r0, i0 = tl.c0;
+    const int sn = tl.sn, sn1 = tl.sn1, K = sn;
     const size_t vo = (size_t)b * dv.dm.ld;
-    const double *X = nn.Xw + vo + (size_t)m0 * nn.NDnet + nn.off[n];
-    const double *W = nn.Pw + (size_t)b * nn.NP + nn.woff[n] + (size_t)i0 * sn;
+    const double *X = nn.Xw + vo + (size_t)m0 * nn.NDnet + tl.offn;
+    const double *W = nn.Pw + (size_t)b * nn.NP + tl.woff + (size_t)i0 * sn;
     const int nra = min(NN_TILE, nn.M - m0), nrb = min(NN_TILE, sn1 - i0);
     const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int live = live_mask(wr, wc, nra, nrb);
@@ -201,6 +201,20 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const Nne
     double va[NLD], vb[NLD];
     load_rk(X, nn.NDnet, nra, K, tid, va);
     load_rk(W, sn, nrb, K, tid, vb);
+    // epilogue operands (bias, x_{n+1}) are requested now so they arrive under the K loop
+    double bias[2], xn1[2][2][4];
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+        const int i = i0 + wc * 32 + bj * 16 + (lane & 15);
+        bias[bj] = (i < sn1) ? nn.Pw[(size_t)b * nn.NP + tl.boff + i] : 0.0;
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
+                xn1[bi][bj][r] = (i < sn1 && m < nn.M) ? nn.Xw[vo + (size_t)m * nn.NDnet + tl.offn1 + i] : 0.0;
+            }
+    }
     for (int k0 = 0; k0 < K; k0 += NN_KC) {
         store_rk(As, tid, va); store_rk(Bs, tid, vb);
         __syncthreads();
@@ -218,16 +232,15 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const Nne
     for (int bj = 0; bj < 2; ++bj) {
         const int i = i0 + wc * 32 + bj * 16 + (lane & 15);
         if (i >= sn1) continue;
-        const double bias = nn.Pw[(size_t)b * nn.NP + nn.boff[n] + i];
 #pragma unroll
         for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
                 if (m >= nn.M) continue;
-                const size_t idx = vo + (size_t)m * nn.NDnet + nn.off[n + 1] + i;
-                const double a = act_f<ACT>(acc[bi][bj][r] + bias);
-                const double res = nn.Xw[idx] - a;
+                const size_t idx = vo + (size_t)m * nn.NDnet + tl.offn1 + i;
+                const double a = act_f<ACT>(acc[bi][bj][r] + bias[bj]);
+                const double res = xn1[bi][bj][r] - a;
                 const double q = cq * res;
                 v[1] += res * res;
                 nn.delta[idx] = -q * act_d<ACT>(a);
@@ -247,17 +260,30 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_x(const Dev dv, const N
     if (!seed_live(dv, b, use_d, stp, rf)) return;
     const NnetTile tl = nn.t2[blockIdx.x];
     const int n = tl.layer, m0 = tl.r0, j0 = tl.c0;
-    const int sn = nn.s[n];
-    const int K = (n < nn.NL - 1) ? nn.s[n + 1] : 0;
+    const int sn = tl.sn;
+    const int K = tl.sn1;                                  // 0 for the output layer: no product
     const size_t vo = (size_t)b * dv.dm.ld;
     const int nra = min(NN_TILE, nn.M - m0), nrb = min(NN_TILE, sn - j0);
     const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int live = live_mask(wr, wc, nra, nrb);
 
     d4 acc[2][2] = {};
+    // q left by k_nnet_fwd in gt: requested now, consumed in the epilogue
+    double q0[2][2][4];
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+        const int j = j0 + wc * 32 + bj * 16 + (lane & 15);
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
+                q0[bi][bj][r] = (n > 0 && j < sn && m < nn.M) ? dv.gt[vo + (size_t)m * nn.NDnet + tl.offn + j] : 0.0;
+            }
+    }
     if (K > 0) {
-        const double *Dl = nn.delta + vo + (size_t)m0 * nn.NDnet + nn.off[n + 1];
-        const double *W = nn.Pw + (size_t)b * nn.NP + nn.woff[n] + j0;
+        const double *Dl = nn.delta + vo + (size_t)m0 * nn.NDnet + tl.offn1;
+        const double *W = nn.Pw + (size_t)b * nn.NP + tl.woff + j0;
         double va[NLD], vb[NLD];
         load_rk(Dl, nn.NDnet, nra, K, tid, va);
         load_kr(W, sn, nrb, K, tid, vb);
@@ -286,9 +312,8 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_x(const Dev dv, const N
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
                 if (m >= nn.M) continue;
-                const size_t idx = vo + (size_t)m * nn.NDnet + nn.off[n] + j;
-                double g = acc[bi][bj][r];
-                if (n > 0) g += dv.gt[idx];                       // q left by k_nnet_fwd
+                const size_t idx = vo + (size_t)m * nn.NDnet + tl.offn + j;
+                double g = acc[bi][bj][r] + q0[bi][bj][r];
                 if (l >= 0) {
                     const double diff = nn.Xw[idx] - dat[(size_t)m * L + l];
                     v[0] += rm * diff * diff;
@@ -312,13 +337,13 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_w(const Dev dv, const N
     int use_d; double stp, rf;
     if (!seed_live(dv, b, use_d, stp, rf)) return;
     const NnetTile tl = nn.t3[blockIdx.x];
-    const int n = tl.layer, i0 = tl.r0, j0 = tl.c0;
-    const int sn = nn.s[n], sn1 = nn.s[n + 1];
+    const int i0 = tl.r0, j0 = tl.c0;
+    const int sn = tl.sn, sn1 = tl.sn1;
     const int mb = tl.chunk * nn.mch;
     const int K = min(nn.mch, nn.M - mb);                       // examples in this chunk
     const size_t vo = (size_t)b * dv.dm.ld;
-    const double *Dl = nn.delta + vo + (size_t)mb * nn.NDnet + nn.off[n + 1] + i0;
-    const double *X = nn.Xw + vo + (size_t)mb * nn.NDnet + nn.off[n] + j0;
+    const double *Dl = nn.delta + vo + (size_t)mb * nn.NDnet + tl.offn1 + i0;
+    const double *X = nn.Xw + vo + (size_t)mb * nn.NDnet + tl.offn + j0;
     const int nra = min(NN_TILE, sn1 - i0), nrb = min(NN_TILE, sn - j0);
     const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int live = live_mask(wr, wc, nra, nrb);
@@ -352,10 +377,10 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_w(const Dev dv, const N
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = i0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
-                if (i < sn1) gp[nn.woff[n] + (size_t)i * sn + j] = acc[bi][bj][r];
+                if (i < sn1) gp[tl.woff + (size_t)i * sn + j] = acc[bi][bj][r];
             }
     }
-    if (j0 == 0 && tid < NN_TILE && i0 + tid < sn1) gp[nn.boff[n] + i0 + tid] = bsum;
+    if (j0 == 0 && tid < NN_TILE && i0 + tid < sn1) gp[tl.boff + i0 + tid] = bsum;
 }
 
 // ------------------------------------------------------------------ K4: parameter tail of grad A
@@ -407,10 +432,191 @@ __global__ __launch_bounds__(64) void k_nnet_rows(const Dev dv, const NnetDev nn
     if (lane < EP_GP) dv.evp[((size_t)b * dv.dm.nprow + w) * EP_N + lane] = v;
 }
 
+// ------------------------------------------------------------------ small networks: one kernel
+// When every layer is at most 32 wide and there are at most 32 examples (the reference's twin
+// example: 20 x 10 neurons, M = 2), the six launches above are pure launch latency.  Here one
+// workgroup OWNS layer n of one seed and produces everything indexed by n:
+//     q_n     = 2 RF c (x_n - act(x_{n-1} W_{n-1}^T + b_{n-1}))      (transition n-1, recomputed)
+//     delta_n = -q_{n+1} act'(...) from transition n                 (its residual feeds fe)
+//     dA/dx_n = q_n + delta_n W_n + measurement term
+//     dA/dW_n = delta_n^T x_n,  dA/db_n = sum_m delta_n  -> scattered through pmap
+// so no workgroup waits for another, nothing round-trips through HBM, and the trial point is
+// formed on load.  Each transition's forward product is computed twice (by the owners of its two
+// ends): 4 instead of 3 tiny products per layer.  Waves = the 2 x 2 MFMA blocks of the 32x32 tile.
+constexpr int PS = NN_SMALL + 4;   // LDS pitch 36
+
+// acc[16x16 block (br, bc)] = A[. x K] B[K x .], K <= 4*nk; *_T: operand stored transposed in LDS
+template <bool A_T, bool B_T>
+__device__ __forceinline__ d4 mma32(const double *As, const double *Bs, int br, int bc, int lane, int nk)
+{
+    const int lo = lane & 15, hi = lane >> 4;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk < nk; ++kk) {
+        const int k = 4 * kk + hi, r = br * 16 + lo, c = bc * 16 + lo;
+        const double a = A_T ? As[k * PS + r] : As[r * PS + k];
+        const double b = B_T ? Bs[c * PS + k] : Bs[k * PS + c];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// LDS: five operand arrays of R rows (R = 16 or 32: the largest of M and the layer widths rounded
+// up to the MFMA block) x pitch 36, two bias rows, reduction scratch
+inline size_t nnet_small_lds(int R) { return sizeof(double) * ((size_t)5 * R * PS + 2 * NN_SMALL + 20); }
+
+template <int ACT>
+__global__ __launch_bounds__(NN_THREADS) void k_nnet_small(const Dev dv, const NnetDev nn)
+{
+    extern __shared__ double sm[];
+    const int R = nn.small;                       // rows staged per array
+    double *Xp = sm, *Xc = sm + R * PS, *Wp = sm + 2 * R * PS, *Wc = sm + 3 * R * PS, *Dl = sm + 4 * R * PS;
+    double *bp = sm + 5 * R * PS, *bc = bp + NN_SMALL, *red = bc + NN_SMALL;
+    const int b = blockIdx.y, n = blockIdx.x, tid = threadIdx.x;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    const int NL = nn.NL, M = nn.M;
+    const bool has_prev = n > 0, has_next = n < NL - 1;
+    const int sn = nn.s[n], sp = has_prev ? nn.s[n - 1] : 0, sx = has_next ? nn.s[n + 1] : 0;
+    const int offc = nn.off[n], offp = has_prev ? nn.off[n - 1] : 0, offx = has_next ? nn.off[n + 1] : 0;
+    const int wofp = has_prev ? nn.woff[n - 1] : 0, bofp = has_prev ? nn.boff[n - 1] : 0;
+    const int wofc = has_next ? nn.woff[n] : 0, bofc = has_next ? nn.boff[n] : 0;
+    const size_t vo = (size_t)b * dv.dm.ld;
+    const double *x = dv.x + vo, *d = dv.d + vo;
+    const double *Pf = nn.Pfix + (size_t)b * nn.NP;
+    const int lane = tid & 63, wave = tid >> 6, br = wave >> 1, bcol = wave & 1;
+
+    auto xval = [&](int idx) { double v = x[idx]; if (use_d) v = trial(v, stp, d[idx]); return v; };
+    auto pval = [&](int j) {
+        const int k = nn.pmap[j];
+        return k >= 0 ? xval(nn.NDens + k) : Pf[j];
+    };
+    // ---- stage the operands (zero padded to 32 x 32): 4 elements per thread per array
+    for (int e = tid; e < R * 32; e += NN_THREADS) {
+        const int r = e >> 5, k = e & 31;
+        Xc[r * PS + k] = (r < M && k < sn) ? xval(r * nn.NDnet + offc + k) : 0.0;
+        Xp[r * PS + k] = (has_prev && r < M && k < sp) ? xval(r * nn.NDnet + offp + k) : 0.0;
+        Wp[r * PS + k] = (has_prev && r < sn && k < sp) ? pval(wofp + r * sp + k) : 0.0;     // W_{n-1}[i][k]
+        Wc[r * PS + k] = (has_next && r < sx && k < sn) ? pval(wofc + r * sn + k) : 0.0;     // W_n[i][k]
+    }
+    if (tid < NN_SMALL) {
+        bp[tid] = (has_prev && tid < sn) ? pval(bofp + tid) : 0.0;
+        bc[tid] = (has_next && tid < sx) ? pval(bofc + tid) : 0.0;
+    }
+    // x_{n+1} is only needed element-wise, in the accumulator layout of this wave's block
+    const int col = bcol * 16 + (lane & 15);
+    double xn1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = br * 16 + (lane >> 4) + 4 * r;
+        xn1[r] = (has_next && m < M && col < sx) ? xval(m * nn.NDnet + offx + col) : 0.0;
+    }
+    __syncthreads();
+
+    const double cq = 2.0 * rf * dv.dm.cfe;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};          // me (+ fe in vfe), g.d, g.g, max|g|
+    double vfe = 0.0;
+    // ---- transition n-1 -> q_n in this wave's block of [m][j of layer n]
+    double q[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool rows_m = br * 16 < M;              // this wave's block rows hold examples
+    if (has_prev && rows_m && bcol * 16 < sn) {
+        const d4 z = mma32<false, true>(Xp, Wp, br, bcol, lane, (sp + 3) >> 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = br * 16 + (lane >> 4) + 4 * r;
+            if (m < M && col < sn) q[r] = cq * (Xc[m * PS + col] - act_f<ACT>(z[r] + bp[col]));
+        }
+    }
+    // ---- transition n -> delta_n in LDS, fe
+    if (has_next && br * 16 < R) {
+        d4 z = {0.0, 0.0, 0.0, 0.0};
+        if (rows_m && bcol * 16 < sx) z = mma32<false, true>(Xc, Wc, br, bcol, lane, (sn + 3) >> 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = br * 16 + (lane >> 4) + 4 * r;
+            double dl = 0.0;
+            if (m < M && col < sx) {
+                const double a = act_f<ACT>(z[r] + bc[col]);
+                const double res = xn1[r] - a;
+                vfe += res * res;
+                dl = -cq * res * act_d<ACT>(a);
+            }
+            Dl[m * PS + col] = dl;
+        }
+    }
+    __syncthreads();
+    // ---- dA/dx_n = q_n + delta_n W_n + measurement term
+    {
+        d4 gx = {0.0, 0.0, 0.0, 0.0};
+        if (has_next && rows_m && bcol * 16 < sn) gx = mma32<false, false>(Dl, Wc, br, bcol, lane, (sx + 3) >> 2);   // B[k=i][c=j] = W_n[i][j]
+        int l = -1; double rm = 0.0; const double *dat = nullptr; int L = 0;
+        if (col < sn) {
+            if (n == 0) { l = nn.lmap_in[col]; rm = nn.rm_in; dat = nn.din; L = nn.Lin; }
+            else if (n == NL - 1) { l = nn.lmap_out[col]; rm = nn.rm_out; dat = nn.dout; L = nn.Lout; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = br * 16 + (lane >> 4) + 4 * r;
+            if (m >= M || col >= sn) continue;
+            const int idx = m * nn.NDnet + offc + col;
+            double g = gx[r] + q[r];
+            if (l >= 0) {
+                const double diff = Xc[m * PS + col] - dat[(size_t)m * L + l];
+                v[0] += rm * diff * diff;
+                g += 2.0 * dv.dm.cme * rm * diff;
+            }
+            dv.gt[vo + idx] = g;
+            if (use_d) v[1] += g * d[idx];
+            v[2] += g * g;
+            v[3] = fmax(v[3], fabs(g));
+        }
+    }
+    // ---- dA/dW_n = delta_n^T x_n (rows i of layer n+1, columns j of layer n), dA/db_n
+    if (has_next && nn.NPest > 0) {
+        d4 gw = {0.0, 0.0, 0.0, 0.0};
+        if (br * 16 < sx && bcol * 16 < sn) gw = mma32<true, false>(Dl, Xc, br, bcol, lane, (M + 3) >> 2);   // A[r=i][k=m], B[k=m][c=j]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = br * 16 + (lane >> 4) + 4 * r;
+            if (i >= sx || col >= sn) continue;
+            const int k = nn.pmap[wofc + i * sn + col];
+            if (k < 0) continue;
+            const double g = gw[r];
+            dv.gt[vo + nn.NDens + k] = g;
+            if (use_d) v[1] += g * d[nn.NDens + k];
+            v[2] += g * g;
+            v[3] = fmax(v[3], fabs(g));
+        }
+        if (tid < sx) {
+            const int k = nn.pmap[bofc + tid];
+            if (k >= 0) {
+                double g = 0.0;
+                for (int m = 0; m < M; ++m) g += Dl[m * PS + tid];
+                dv.gt[vo + nn.NDens + k] = g;
+                if (use_d) v[1] += g * d[nn.NDens + k];
+                v[2] += g * g;
+                v[3] = fmax(v[3], fabs(g));
+            }
+        }
+    }
+    vfe = wave_sum(vfe);
+    if (lane == 0) red[16 + wave] = vfe;
+    wg_reduce4(v, red, tid);                       // (contains the barrier that publishes red[16..19])
+    if (tid == 0) put_row(dv, nn, b, n, v[0], red[16] + red[17] + red[18] + red[19], v[1], v[2], v[3]);
+}
+
 void launch_nnet_eval(const Dev &dv, const NnetDev &nn, hipStream_t s)
 {
     const int B = dv.dm.B;
     const dim3 blk(NN_THREADS);
+    if (nn.small) {
+        const size_t lds = nnet_small_lds(nn.small);
+        switch (nn.act) {
+        case NNET_SIGMOID: hipLaunchKernelGGL(k_nnet_small<NNET_SIGMOID>, dim3(nn.NL, B), blk, lds, s, dv, nn); break;
+        case NNET_TANH: hipLaunchKernelGGL(k_nnet_small<NNET_TANH>, dim3(nn.NL, B), blk, lds, s, dv, nn); break;
+        default: hipLaunchKernelGGL(k_nnet_small<NNET_LINEAR>, dim3(nn.NL, B), blk, lds, s, dv, nn); break;
+        }
+        return;
+    }
     hipLaunchKernelGGL(k_nnet_pack, dim3(nn.n0, B), blk, 0, s, dv, nn);
     switch (nn.act) {
     case NNET_SIGMOID: hipLaunchKernelGGL(k_nnet_fwd<NNET_SIGMOID>, dim3(nn.n1, B), blk, 0, s, dv, nn); break;
