@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VA_ABI_VERSION 3
+#define VA_ABI_VERSION 4
 
 enum { VA_OK = 0, VA_EINVAL = -1, VA_ENOMEM = -2, VA_EHIP = -3, VA_EUNSUPPORTED = -4,
        VA_ESTATE = -5 };
@@ -84,6 +84,10 @@ typedef struct va_problem_desc {
     const double *t_model;    /* NULL or [N_model]: times passed to a non-autonomous RHS (va_ode.py:553,558) */
     const double *stim;       /* NULL or [N_model*n_stim]: external stimulus rows, f(t,x,(p,stim)) (va_ode.py:345-375) */
     int32_t n_stim;
+    int32_t p_time_dependent; /* 1: P is [B][N_model][NP] (P0.ndim == 2 upstream, va_ode.py:170-188); the path
+                               * vector is then [X (N_model*D) | p_est (N_model*NPest), time-major],
+                               * n_var = N_model*(D+NPest); trapezoid and SimpsonHermite only (upstream's
+                               * euler/forwardmap branches slice p one row short, va_ode.py:345-349) */
     void *stream;             /* hipStream_t to run on; NULL = library-owned stream  */
 } va_problem_desc;
 

@@ -211,6 +211,73 @@ def nakl_cases(va):
     return out
 
 
+def tdp_cases(va):
+    """g8_*: time-dependent parameters, P0 of shape (N_model, NP) (va_ode.py:170-188, 362-375,
+    404-437, 660-699, 750-769).  Upstream handles them for trapezoid / SimpsonHermite; its
+    euler / forwardmap branches slice p one row short and its anneal_step only writes the
+    parameters back correctly when all of them are estimated, so the ladder uses NPest == NP.
+    Model: Lorenz-96 with a forcing k_n per time point (the same callable broadcasts)."""
+    import adolc
+    from varanneal_amd import twin
+    out = {}
+    D, L = 10, 4
+    Lidx = [0, 3, 5, 8]
+
+    def l96(t, x, k):
+        return np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - x + k
+
+    def setup(N, disc, seed):
+        t, Y, _, _ = twin.make_twin(D, N, Lidx=Lidx)
+        rng = np.random.RandomState(4000 + seed)
+        X0 = 20.0 * rng.rand(N, D) - 10.0
+        P0 = 6.0 + 4.0 * rng.rand(N, 1)
+        a = va.Annealer()
+        a.set_model(l96, D)
+        a.set_data(Y, t=t)
+        return a, t, Y, X0, P0
+
+    for disc, N in (("trapezoid", 40), ("SimpsonHermite", 41)):
+        for rf_scale in (1.0, 3.0e3):
+            a, t, Y, X0, P0 = setup(N, disc, 0)
+            with quiet():
+                a.anneal_init(X0, P0, 1.0, np.array([0]), 4.0, 4e-6 * rf_scale, Lidx, [0], dt_model=None,
+                              init_to_data=True, disc=disc, method='L-BFGS-B', opt_args=None, adolcID=0)
+            XP = np.array(a.minpaths[0])
+            A = float(a.A(XP)); me = float(a.me_gaussian(XP[:N * D])); fe = float(a.fe_gaussian(XP))
+            grad = _refload.complex_step_grad(a.A, XP)
+            name = "g8_tdp_%s_rf%.0e" % (disc, rf_scale)
+            out[name] = dict(XP=XP, Y=Y, t=t, D=D, N_model=N, Lidx=np.array(Lidx), dt_model=twin.DT, disc=disc,
+                             RM=4.0, RF0=4e-6, rf_scale=rf_scale, P0=P0, A=A, me=me, fe=fe, grad=grad)
+            print("%-34s A=%.16e me=%.3e fe=%.3e |g|max=%.3e" % (name, A, me, fe, np.abs(grad).max()))
+    # ladder: reference anneal() + SciPy; gradient = complex step through the reference's A
+    N, nb = 41, 12
+    a, t, Y, X0, P0 = setup(N, "SimpsonHermite", 1)
+    adolc.function = lambda _id, XP: a.A(XP)
+    adolc.gradient = lambda _id, XP: _refload.complex_step_grad(a.A, np.asarray(XP, dtype=np.float64))
+    nits = []
+    import scipy.optimize as so
+    real_min = so.minimize
+
+    def spy(*args, **kw):
+        r = real_min(*args, **kw)
+        nits.append(r.nit)
+        return r
+    so.minimize = spy
+    X0in, P0in = X0.copy(), P0.copy()
+    try:
+        with quiet():
+            a.anneal(X0, P0, 1.5, np.arange(0, 2 * nb, 2), 4.0, 4e-6, Lidx, [0], dt_model=None, init_to_data=True,
+                     disc="SimpsonHermite", method='L-BFGS-B',
+                     opt_args={'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000000, 'maxiter': 1000000}, adolcID=0)
+    finally:
+        so.minimize = real_min
+    out["g8_tdp_ladder_SH_N41"] = dict(Y=Y, t=t, D=D, N=N, Lidx=np.array(Lidx), X0=X0in, P0=P0in, alpha=1.5,
+                                       beta=np.arange(0, 2 * nb, 2), A_array=a.A_array, me_array=a.me_array,
+                                       fe_array=a.fe_array, minpaths_last=a.minpaths[-1], nit=np.array(nits))
+    print("g8_tdp_ladder_SH_N41  A=%s nit=%s" % (a.A_array, nits))
+    return out
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     va = _refload.load_reference("va_ode")
@@ -240,6 +307,12 @@ def main():
         for k, v in rec.items():
             flat["%s/%s" % (cname, k)] = v
     np.savez_compressed(os.path.join(GOLD, "nakl.npz"), **flat)
+
+    flat = {}
+    for cname, rec in tdp_cases(va).items():
+        for k, v in rec.items():
+            flat["%s/%s" % (cname, k)] = v
+    np.savez_compressed(os.path.join(GOLD, "tdp.npz"), **flat)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 

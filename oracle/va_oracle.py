@@ -204,14 +204,20 @@ def numpy_action_generic(f, XP, D, N, Y, Lidx, dt, RM, RF, NP, Pidx, P, disc, t_
                          nskip=1):
     """The reference's action (va_ode.py:130-234, 341-454) for an arbitrary user `f`, array op
     for array op, including the stimulus tuple convention (:345-375).  Type-polymorphic, so a
-    complex XP gives complex-step derivatives.  RM: scalar or (N_data,L); RF: scalar or (N-1,D)."""
+    complex XP gives complex-step derivatives.  RM: scalar or (N_data,L); RF: scalar or (N-1,D).
+    P of shape (N, NP) = time-dependent parameters (trapezoid / SimpsonHermite as upstream)."""
     x = np.reshape(XP[:N * D], (N, D))
     p = np.array(P, dtype=XP.dtype)
-    p[list(Pidx)] = XP[N * D:]
+    tdp = p.ndim == 2                       # time-dependent parameters: P is (N, NP) (va_ode.py:170-188)
+    if tdp:
+        p[:, list(Pidx)] = np.reshape(XP[N * D:], (N, len(Pidx)))
+    else:
+        p[list(Pidx)] = XP[N * D:]
     t = np.zeros(N) if t_model is None else np.asarray(t_model)
     diff = x[::nskip, list(Lidx)] - Y
     me = (np.sum(RM * diff * diff) if isinstance(RM, np.ndarray) else RM * np.sum(diff * diff)) / (len(Lidx) * Y.shape[0])
-    arg = (lambda sl: p) if stim is None else (lambda sl: (p, stim[sl]))
+    pp = (lambda sl: p[sl]) if tdp else (lambda sl: p)            # f sees the rows' own parameters
+    arg = pp if stim is None else (lambda sl: (pp(sl), stim[sl]))
     arr = isinstance(RF, np.ndarray)
     if disc == "SimpsonHermite":
         a, m_, b = slice(None, -2, 2), slice(1, -1, 2), slice(2, None, 2)

@@ -35,6 +35,8 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     m.D = d->D; m.N = d->N_model; m.ND = m.D * m.N; m.L = d->L; m.N_data = d->N_data;
     m.nskip = d->merr_nskip; m.NP = d->NP; m.NPest = d->NPest; m.B = d->batch;
     m.m = d->lbfgs_m > 0 ? d->lbfgs_m : 10; m.disc = d->disc;
+    m.tdp = d->p_time_dependent ? 1 : 0; m.NPt = d->NP; m.NPe = d->NPest;
+    if (m.tdp) { m.ND = m.N * (m.D + m.NPe); m.NP = 0; m.NPest = 0; }
     m.ld = ((m.ND + m.NPest + 15) / 16) * 16;
     if (m.disc == DISC_SH && (T & 1)) ++T;
     m.emode = (d->eval_kernel >= 1 && d->eval_kernel <= 3) ? d->eval_kernel : 3;
@@ -62,8 +64,8 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     E.Y.assign(d->Y, d->Y + (size_t)m.N_data * m.L);
     if (d->rm_kind) E.rm.assign(d->rm_array, d->rm_array + (size_t)m.N_data * m.L);
     if (d->rf_kind) E.rf0.assign(d->rf0_array, d->rf0_array + (size_t)(m.N - 1) * m.D);
-    E.pidx.assign(d->Pidx, d->Pidx + m.NPest);
-    E.P.assign(d->P, d->P + (size_t)m.B * m.NP);
+    E.pidx.assign(d->Pidx, d->Pidx + m.NPe);
+    E.P.assign(d->P, d->P + (size_t)m.B * (m.tdp ? (size_t)m.N * m.NPt : (size_t)m.NPt));
     E.pp.lmap = E.lmap.data(); E.pp.Y = E.Y.data();
     E.pp.rm_arr = d->rm_kind ? E.rm.data() : nullptr;
     E.pp.rf0_arr = d->rf_kind ? E.rf0.data() : nullptr;
@@ -72,7 +74,7 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     if (d->n_stim > 0) E.stim.assign(d->stim, d->stim + (size_t)m.N * d->n_stim);
     E.pp.tmodel = d->t_model ? E.tm.data() : nullptr;
     E.pp.stim = d->n_stim > 0 ? E.stim.data() : nullptr; E.pp.nstim = d->n_stim;
-    if (d->rhs >= VA_RHS_USER_BASE) m.emode = 1;
+    if (d->rhs >= VA_RHS_USER_BASE || m.tdp) m.emode = 1;
     E.rhs = d->rhs;
     if (m.disc == DISC_SH && (m.N % 2) == 0) return VA_EINVAL;
     return VA_OK;
@@ -87,22 +89,25 @@ void eval_seed(const Emul &E, int b, const double *x, const double *d, int use_d
     const int NT = 48;                         // deliberately not a divisor of anything
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
     const int R = dm.T + HL + HR;
-    std::vector<double> xs(R * dm.D), fs(R * dm.D), qs(R * dm.D);
+    std::vector<double> xs(R * dm.D), fs(R * dm.D), qs(R * dm.D), ps((size_t)R * (dm.NPt > 0 ? dm.NPt : 1));
     for (int k = 0; k < EP_N; ++k) ev[k] = 0.0;
     for (int tile = 0; tile < dm.ntiles; ++tile) {
         TileCtx c;
+        c.ps = ps.data();
         c.n0 = tile * dm.T; c.R = R; c.use_d = use_d; c.stp = stp; c.c = 2.0 * rf_scale * dm.cfe;
         c.xs = xs.data(); c.fs = fs.data(); c.qs = qs.data();
         c.xg = x; c.dg = d; c.gtg = gt;
         c.tmodel = E.pp.tmodel; c.stim = E.pp.stim; c.nstim = E.pp.nstim;
-        tile_params<RHS>(dm, E.pp, b, c);
+        if (!dm.tdp) tile_params<RHS>(dm, E.pp, b, c);
         std::vector<ThreadAcc> acc(NT);
         for (auto &a : acc) a.clear();
         for (int t = 0; t < NT; ++t) tile_load<DISC>(dm, c, t, NT);
+        if (dm.tdp) for (int t = 0; t < NT; ++t) tile_load_p<DISC>(dm, E.pp, b, c, t, NT);
         for (int t = 0; t < NT; ++t) tile_f<RHS, DISC>(dm, c, t, NT);
         for (int t = 0; t < NT; ++t) tile_q<DISC>(dm, E.pp, c, acc[t], t, NT);
         for (int t = 0; t < NT; ++t) tile_s<DISC>(dm, c, t, NT);
         for (int t = 0; t < NT; ++t) tile_g<RHS, DISC>(dm, E.pp, c, acc[t], t, NT);
+        if (dm.tdp) for (int t = 0; t < NT; ++t) tile_gp<RHS, DISC>(dm, E.pp, c, acc[t], t, NT);
         for (int t = 0; t < NT; ++t)
             for (int k = 0; k < EP_N; ++k) {
                 if (k == EP_GMAX) ev[k] = fmax(ev[k], acc[t].v[k]);

@@ -41,3 +41,10 @@ def l96_damped(t, x, p):
     """a Lorenz-96 variant NOT in the built-in registry: two parameters (forcing, damping)
     and an explicit time dependence -- exercises the generic path with D = 12."""
     return np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - p[1] * x + p[0] * (1.0 + 0.1 * np.sin(t))[:, None]
+
+
+def l96_damped_tdp(t, x, p):
+    """l96_damped written for time-dependent parameters: p has one row per time point
+    (va_ode.py:170-188 hands f the rows' own parameter vectors)."""
+    return (np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - p[:, 1:2] * x
+            + p[:, 0:1] * (1.0 + 0.1 * np.sin(t))[:, None])

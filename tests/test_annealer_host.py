@@ -112,8 +112,11 @@ def test_unsupported_inputs_fail_loudly(fake_device, golden_ladders):
     with pytest.raises(TypeError):                   # a model that branches on its inputs cannot be traced
         a.anneal_init(*args())
     a = _setup(c)
-    with pytest.raises(NotImplementedError):         # time-dependent parameters
-        a.anneal_init(c["X0"].copy(), np.ones((200, 1)), 1.5, np.arange(3), 4.0, 4e-6, list(c["Lidx"]), [0])
+    with pytest.raises(NotImplementedError):         # time-dependent parameters: not with euler (broken upstream)
+        a.anneal_init(c["X0"].copy(), np.ones((200, 1)), 1.5, np.arange(3), 4.0, 4e-6, list(c["Lidx"]), [0],
+                      disc="euler")
+    with pytest.raises(ValueError):                  # ... and one row per model time point
+        a.anneal_init(c["X0"].copy(), np.ones((199, 1)), 1.5, np.arange(3), 4.0, 4e-6, list(c["Lidx"]), [0])
     with pytest.raises(NotImplementedError):         # full RM matrix
         a.anneal_init(c["X0"].copy(), c["P0"].copy(), 1.5, np.arange(3), np.eye(7), 4e-6, list(c["Lidx"]), [0])
     with pytest.raises(ValueError):
@@ -253,3 +256,53 @@ def test_nakl_bounded_ladder_host_flow(monkeypatch):
     assert np.all(np.abs(a.A_array - c["A_array"]) <= 2e-2 * c["A_array"])
     lo, hi = c["bounds"][4:, 0], c["bounds"][4:, 1]
     assert np.all(a.P >= lo - 1e-12) and np.all(a.P <= hi + 1e-12)
+
+
+class EmulTdpProblem(object):
+    """Test double for _capi.Problem with time-dependent parameters on the built-in Lorenz-96:
+    evaluations by the CPU emulator's flat tile phases."""
+
+    def __init__(self, batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, disc="trapezoid",
+                 rhs="lorenz96", merr_nskip=1, t_model=None, stim=None, p_time_dependent=False, **kw):
+        from cpu_emul import emul
+        assert p_time_dependent and rhs == "lorenz96"
+        self.emul, self.B = emul, batch
+        self.desc, self.keep = _capi.make_desc(batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, disc=disc,
+                                               merr_nskip=merr_nskip, t_model=t_model, p_time_dependent=True)
+
+    def close(self):
+        pass
+
+    def action_grad(self, XP, rf_scale=1.0, want_grad=True):
+        A, me, fe, g = self.emul.action_grad(self.desc, 9, np.asarray(XP), rf_scale)
+        return A, me, fe, (g if want_grad else None)
+
+
+def test_time_dependent_parameters_host_flow(monkeypatch, tmp_path):
+    """P0 of shape (N_model, NP) (va_ode.py:565-570): packing [X | P time-major], warm starts,
+    write-back into the caller's P, bounds repeated per time point, save_params (Nbeta, N, NP) --
+    against the ladder the reference produced (tests/golden/tdp.npz; SciPy route here because the
+    stand-in only evaluates)."""
+    from _util import load_npz_cases
+    c = load_npz_cases("tdp.npz")["g8_tdp_ladder_SH_N41"]
+    monkeypatch.setattr(_capi, "Problem", EmulTdpProblem)
+    N, D, nb = int(c["N"]), int(c["D"]), 5
+    a = va_ode.Annealer()
+    a.set_model(twin.l96, D)
+    a.set_data(c["Y"], t=c["t"])
+    X0, P0 = c["X0"].copy(), c["P0"].copy()
+    # open bounds: L-BFGS-B then takes the same steps as unbounded (any finite bound, even an
+    # inactive one, changes its first step length), while the expansion over time points is exercised
+    big = [(None, None)] * (D + 1)
+    a.anneal(X0, P0, float(c["alpha"]), c["beta"][:nb], 4.0, 4e-6, list(c["Lidx"]), [0], dt_model=None,
+             init_to_data=True, disc="SimpsonHermite", method='L-BFGS-B', bounds=big, opt_args=OPTS, adolcID=0,
+             verbose=False)
+    assert len(a.bounds) == N * D + N
+    assert list(a.nit_array) == list(c["nit"][:nb])
+    assert np.all(np.abs(a.A_array - c["A_array"][:nb]) <= 1e-6 * c["A_array"][:nb])
+    assert a.minpaths.shape == (nb, N * D + N) and P0.shape == (N, 1)
+    assert np.array_equal(P0[:, 0], a.minpaths[-1, N * D:])           # written back into the caller's array
+    a.save_params(str(tmp_path / "p.npy"))
+    assert np.load(str(tmp_path / "p.npy")).shape == (nb, N, 1)
+    with pytest.raises(NotImplementedError):
+        a.anneal(X0, P0, 1.5, np.arange(2), 4.0, 4e-6, list(c["Lidx"]), [0], disc="euler", verbose=False)

@@ -45,7 +45,7 @@ class ProblemDesc(C.Structure):
                 ("disc", C.c_int32), ("rhs", C.c_int32), ("lbfgs_m", C.c_int32),
                 ("max_beta", C.c_int32), ("keep_paths", C.c_int32), ("tile_rows", C.c_int32),
                 ("eval_kernel", C.c_int32), ("t_model", c_dp), ("stim", c_dp), ("n_stim", C.c_int32),
-                ("stream", C.c_void_p)]
+                ("p_time_dependent", C.c_int32), ("stream", C.c_void_p)]
 
 
 class NnetDesc(C.Structure):
@@ -80,14 +80,20 @@ def _f64(a):
 
 def make_desc(batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, disc="trapezoid",
               rhs="lorenz96", merr_nskip=1, lbfgs_m=10, max_beta=1, keep_paths=0, tile_rows=0,
-              eval_kernel=0, device=0, stream=None, t_model=None, stim=None):
-    """Build a ProblemDesc plus the list of arrays that must outlive it."""
+              eval_kernel=0, device=0, stream=None, t_model=None, stim=None, p_time_dependent=False):
+    """Build a ProblemDesc plus the list of arrays that must outlive it.  With
+    p_time_dependent, P has shape (batch, N_model, NP) (or (N_model, NP), shared by the seeds)."""
     Y = _f64(Y)
     N_data, L = Y.shape
     Lidx = np.ascontiguousarray(Lidx, dtype=np.int32)
     Pidx = np.ascontiguousarray(Pidx, dtype=np.int32)
     P = _f64(P)
-    if P.ndim == 1:
+    if p_time_dependent:
+        if P.ndim == 2:
+            P = np.ascontiguousarray(np.broadcast_to(P, (batch,) + P.shape))
+        if P.ndim != 3 or P.shape[:2] != (batch, N_model):
+            raise ValueError("time-dependent P must have shape (batch, N_model, NP)")
+    elif P.ndim == 1:
         P = np.ascontiguousarray(np.broadcast_to(P, (batch, P.shape[0])))
     keep = [Y, Lidx, Pidx, P]
     d = ProblemDesc()
@@ -113,7 +119,8 @@ def make_desc(batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, disc="trap
         d.rf_kind, d.rf0, d.rf0_array = 1, 0.0, rf.ctypes.data_as(c_dp)
     else:
         d.rf_kind, d.rf0, d.rf0_array = 0, float(RF0), None
-    d.NP, d.NPest = P.shape[1], len(Pidx)
+    d.NP, d.NPest = P.shape[-1], len(Pidx)
+    d.p_time_dependent = 1 if p_time_dependent else 0
     d.Pidx = Pidx.ctypes.data_as(c_ip)
     d.P = P.ctypes.data_as(c_dp)
     d.disc = DISC[disc] if isinstance(disc, str) else int(disc)
@@ -214,6 +221,11 @@ class Problem(object):
         self.B, self.D, self.N = batch, D, N_model
         self.NP, self.NPest = self.desc.NP, self.desc.NPest
         self.n_var = N_model * D + self.NPest
+        if self.desc.p_time_dependent:
+            # [X | p_est time-major]: to the shared solver one flat run without a parameter tail
+            self.n_var = N_model * (D + self.NPest)
+            self.NPe_t, self.NPt = self.NPest, self.NP
+            self.N, self.D, self.NP, self.NPest = 1, self.n_var, 0, 0
         self.max_beta = self.desc.max_beta
         self._h = C.c_void_p()
         check(self._L.va_problem_create(C.byref(self.desc), C.byref(self._h)))

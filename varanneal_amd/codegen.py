@@ -83,8 +83,9 @@ class Sym(object):
         raise AttributeError(name)
 
 
-def trace(f, D, NP, nstim=0, stim_ndim=1):
-    """Run `f` once on symbols.  Returns (exprs[D], symbols dict)."""
+def trace(f, D, NP, nstim=0, stim_ndim=1, p_rows=False):
+    """Run `f` once on symbols.  Returns (exprs[D], symbols dict).  p_rows: the model takes
+    time-dependent parameters, i.e. p of shape (rows, NP) indexed p[:, k] (va_ode.py:170-188)."""
     sp = _sympy()
     xs = sp.symbols("x0:%d" % D, real=True)
     ps = sp.symbols("p0:%d" % max(NP, 1), real=True)[:NP]
@@ -93,9 +94,9 @@ def trace(f, D, NP, nstim=0, stim_ndim=1):
     X = np.empty((1, D), dtype=object)
     for j in range(D):
         X[0, j] = Sym(xs[j])
-    P = np.empty(NP, dtype=object)
+    P = np.empty((1, NP) if p_rows else NP, dtype=object)
     for k in range(NP):
-        P[k] = Sym(ps[k])
+        P[(0, k) if p_rows else k] = Sym(ps[k])
     T = np.empty(1, dtype=object)
     T[0] = Sym(t)
     if nstim:
@@ -201,7 +202,7 @@ def generate_header(exprs, syms, D, NP, nstim, name="user"):
     return "\n".join(out) + "\n"
 
 
-def check_against(f, exprs, syms, D, NP, nstim, stim_ndim=1, trials=3, rtol=1e-10):
+def check_against(f, exprs, syms, D, NP, nstim, stim_ndim=1, trials=3, rtol=1e-10, p_rows=False):
     """The traced expressions must reproduce `f` on random numeric slices."""
     sp = _sympy()
     args = list(syms["x"]) + list(syms["p"]) + list(syms["st"]) + [syms["t"]]
@@ -209,7 +210,7 @@ def check_against(f, exprs, syms, D, NP, nstim, stim_ndim=1, trials=3, rtol=1e-1
     rng = np.random.RandomState(20260102)
     for _ in range(trials):
         x = rng.rand(5, D) * 0.8 + 0.1
-        p = rng.rand(NP) * 0.8 + 0.6
+        p = rng.rand(5, NP) * 0.8 + 0.6 if p_rows else rng.rand(NP) * 0.8 + 0.6
         t = rng.rand(5)
         if nstim:
             st = rng.randn(5) if stim_ndim == 1 else rng.randn(5, nstim)
@@ -219,7 +220,7 @@ def check_against(f, exprs, syms, D, NP, nstim, stim_ndim=1, trials=3, rtol=1e-1
             want = np.asarray(f(t, x, p), dtype=np.float64)
         for r in range(5):
             srow = [] if not nstim else (list(np.atleast_1d(st[r])))
-            got = np.array(fn(*(list(x[r]) + list(p) + srow + [t[r]])), dtype=np.float64)
+            got = np.array(fn(*(list(x[r]) + list(p[r] if p_rows else p) + srow + [t[r]])), dtype=np.float64)
             if not np.allclose(got, want[r], rtol=rtol, atol=1e-12):
                 raise ValueError("traced model disagrees with the model function "
                                  "(does it branch on its inputs?): %s vs %s" % (got, want[r]))
@@ -253,12 +254,12 @@ def build_module(header_text, verbose=False):
     return so, hdr
 
 
-def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False):
+def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False, p_rows=False):
     """trace + check + generate + build.  Returns dict(so=, header=, exprs=)."""
     if NP > MAX_NP:
         raise NotImplementedError("right-hand sides with more than %d parameters" % MAX_NP)
-    exprs, syms = trace(f, D, NP, nstim, stim_ndim)
-    check_against(f, exprs, syms, D, NP, nstim, stim_ndim)
+    exprs, syms = trace(f, D, NP, nstim, stim_ndim, p_rows)
+    check_against(f, exprs, syms, D, NP, nstim, stim_ndim, p_rows=p_rows)
     text = generate_header(exprs, syms, D, NP, nstim, getattr(f, "__name__", "f"))
     so, hdr = build_module(text, verbose)
     return dict(so=so, header=hdr, exprs=exprs, text=text)

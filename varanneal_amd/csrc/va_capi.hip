@@ -93,6 +93,7 @@ void run_eval(va_handle h)
 // Tile geometry of the eval kernel: which mapping, rows per workgroup, threads.
 void pick_eval_geometry(const va_problem_desc *d, Dims &dm, bool user_rhs)
 {
+    user_rhs = user_rhs || d->p_time_dependent;          // per-row parameters: flat kernel only
     const int D = d->D, N = d->N_model;
     const bool sh = d->disc == VA_DISC_SIMPSON_HERMITE;
     const int HLR = sh ? 3 : 2;
@@ -361,6 +362,11 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
         return fail(VA_EINVAL, "Lorenz-96 needs NP=1 and D>=4 (NP=%d D=%d)", d->NP, d->D);
     if (d->n_stim < 0 || (d->n_stim > 0 && !d->stim)) return fail(VA_EINVAL, "n_stim=%d without a stimulus array", d->n_stim);
     if (d->NPest < 0 || d->NPest > d->NP || d->NP > RHS_MAX_NP) return fail(VA_EINVAL, "bad NP/NPest (%d/%d)", d->NP, d->NPest);
+    const bool tdp = d->p_time_dependent != 0;
+    if (tdp && d->disc != VA_DISC_TRAPEZOID && d->disc != VA_DISC_SIMPSON_HERMITE)
+        return fail(VA_EUNSUPPORTED, "time-dependent parameters: trapezoid and SimpsonHermite only (upstream's euler/forwardmap "
+                                     "branches are inconsistent, va_ode.py:345-349)");
+    if (tdp && (int64_t)d->N_model * (d->D + d->NPest) > 2000000000LL) return fail(VA_EUNSUPPORTED, "n_var does not fit 32-bit indexing");
     if (!d->Y || (d->L > 0 && !d->Lidx) || !d->P || (d->NPest > 0 && !d->Pidx)) return fail(VA_EINVAL, "null array in desc");
     if ((d->rm_kind && !d->rm_array) || (d->rf_kind && !d->rf0_array)) return fail(VA_EINVAL, "rm/rf array kind without array");
     for (int l = 0; l < d->L; ++l)
@@ -391,6 +397,8 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dm.D = d->D; dm.N = d->N_model; dm.ND = dm.D * dm.N; dm.L = d->L; dm.N_data = d->N_data;
     dm.nskip = d->merr_nskip; dm.NP = d->NP; dm.NPest = d->NPest; dm.B = d->batch; dm.m = m;
     dm.disc = d->disc;
+    dm.tdp = tdp ? 1 : 0; dm.NPt = d->NP; dm.NPe = d->NPest;
+    if (tdp) { dm.ND = dm.N * (dm.D + dm.NPe); dm.NP = 0; dm.NPest = 0; }   // one flat run for the L-BFGS kernels
     dm.ld = ((dm.ND + dm.NPest + 15) / 16) * 16;
     pick_eval_geometry(d, dm, user != nullptr);
     dm.nprow = dm.emode == 3 ? dm.ntiles * (dm.NT / 64) : dm.ntiles;
@@ -417,8 +425,9 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
 #define TRY(x) do { rc = (x); if (rc) { va_problem_destroy(h); return rc; } } while (0)
     TRY(h->alloc(&lmap_d, dm.D));
     TRY(h->alloc(&Y_d, (size_t)dm.N_data * dm.L));
-    TRY(h->alloc(&pidx_d, dm.NPest));
-    TRY(h->alloc(&P_d, B * dm.NP));
+    const size_t np_seed = tdp ? (size_t)dm.N * dm.NPt : (size_t)dm.NPt;       // parameters stored per seed
+    TRY(h->alloc(&pidx_d, dm.NPe));
+    TRY(h->alloc(&P_d, B * np_seed));
     if (d->rm_kind) TRY(h->alloc(&rm_d, (size_t)dm.N_data * dm.L));
     if (d->rf_kind) TRY(h->alloc(&rf_d, (size_t)(dm.N - 1) * dm.D));
     if (d->t_model) TRY(h->alloc(&t_d, (size_t)dm.N));
@@ -431,8 +440,8 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
         if (e_ != hipSuccess) { va_problem_destroy(h); return fail(VA_EHIP, "H2D %s: %s", #dst, hipGetErrorString(e_)); } } while (0)
     H2D(lmap_d, lmap.data(), dm.D, int);
     H2D(Y_d, d->Y, (size_t)dm.N_data * dm.L, double);
-    if (dm.NPest) H2D(pidx_d, d->Pidx, dm.NPest, int);
-    H2D(P_d, d->P, B * dm.NP, double);
+    if (dm.NPe) H2D(pidx_d, d->Pidx, dm.NPe, int);
+    H2D(P_d, d->P, B * np_seed, double);
     if (d->rm_kind) H2D(rm_d, d->rm_array, (size_t)dm.N_data * dm.L, double);
     if (d->rf_kind) H2D(rf_d, d->rf0_array, (size_t)(dm.N - 1) * dm.D, double);
     if (d->t_model) H2D(t_d, d->t_model, (size_t)dm.N, double);

@@ -55,6 +55,11 @@ struct Dims {
     unsigned long long obsmask; // bit i set <=> state column i is observed (valid when D <= 64)
     int dbg;                   // ablation bits for profiling builds (env VA_DEBUG_EVAL; 0 in production):
                                // 1 = no gradient stores, 2 = copy only (skip phases B/C), 4 = no staging loads
+    // time-dependent parameters (va_ode.py:170-188): P is (N, NPt) per seed and the vector is
+    // [X (N*D) | p_est (N*NPe), time-major].  Then ND = N*D + N*NPe and NP = NPest = 0 for the
+    // L-BFGS kernels (one flat run), and the flat tile kernel uses NPt / NPe.  Static: tdp = 0,
+    // NPt = NP, NPe = NPest.
+    int tdp, NPt, NPe;
     double dt, cme, cfe, rm, rf0;
 };
 
@@ -143,6 +148,7 @@ struct TileCtx {
     double *gtg;                 // this seed's gradient output
     const double *tmodel, *stim; // per-row time / stimulus (NULL / unused for autonomous RHS)
     int nstim;
+    double *ps;                  // time-dependent parameters: staged rows [R*NPt] (LDS)
     double p[RHS_MAX_NP];
 };
 
@@ -176,14 +182,39 @@ VA_HD void tile_load(const Dims &dm, TileCtx &c, int tid, int nt)
 {
     const long base = (long)(c.n0 - Halo<DISC>::HL) * dm.D;
     const int tot = c.R * dm.D;
+    const long NDx = (long)dm.N * dm.D;          // (dm.ND also counts the parameter block when tdp)
     for (int e = tid; e < tot; e += nt) {
         long gi = base + e;
         double v = 0.0;
-        if (gi >= 0 && gi < dm.ND) {
+        if (gi >= 0 && gi < NDx) {
             v = c.xg[gi];
             if (c.use_d) v = trial(v, c.stp, c.dg[gi]);
         }
         c.xs[e] = v;
+    }
+}
+
+// phase 1b (time-dependent parameters): stage the rows' own parameter vectors -- estimated
+// entries from the trial point, the others from the fixed table (va_ode.py:177-188).
+template <int DISC>
+VA_HD void tile_load_p(const Dims &dm, const ProblemPtrs &pp, int b, TileCtx &c, int tid, int nt)
+{
+    const int NPt = dm.NPt, tot = c.R * NPt;
+    const long NDx = (long)dm.N * dm.D;
+    for (int e = tid; e < tot; e += nt) {
+        const int lr = e / NPt, k = e - lr * NPt;
+        const int row = c.n0 - Halo<DISC>::HL + lr;
+        double v = 0.0;
+        if (row >= 0 && row < dm.N) {
+            int est = -1;
+            for (int j = 0; j < dm.NPe; ++j) est = (pp.Pidx[j] == k) ? j : est;
+            if (est >= 0) {
+                const long gi = NDx + (long)row * dm.NPe + est;
+                v = c.xg[gi];
+                if (c.use_d) v = trial(v, c.stp, c.dg[gi]);
+            } else v = pp.Pfull[((size_t)b * dm.N + row) * NPt + k];
+        }
+        c.ps[e] = v;
     }
 }
 
@@ -197,7 +228,8 @@ VA_HD void tile_f(const Dims &dm, TileCtx &c, int tid, int nt)
     for (int e = tid; e < tot; e += nt) {
         int row = c.n0 - Halo<DISC>::HL + lr;
         c.fs[e] = (row >= 0 && row < dm.N)
-                      ? RHS::f(c.xs + lr * D, i, D, c.p, c.tmodel ? c.tmodel[row] : 0.0, c.stim + (size_t)row * c.nstim)
+                      ? RHS::f(c.xs + lr * D, i, D, dm.tdp ? c.ps + lr * dm.NPt : c.p,
+                               c.tmodel ? c.tmodel[row] : 0.0, c.stim + (size_t)row * c.nstim)
                       : 0.0;
         lr += dlr; i += di;
         if (i >= D) { i -= D; ++lr; }
@@ -310,8 +342,9 @@ VA_HD void tile_g(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &
             const double *xr = c.xs + lr * D, *sr = c.fs + lr * D;
             const double tm = c.tmodel ? c.tmodel[m] : 0.0;
             const double *st = c.stim + (size_t)m * c.nstim;
-            double g = direct + RHS::vjp(xr, sr, j, D, c.p, tm, st);
-            RHS::pgrad(xr, sr, j, D, c.p, tm, st, acc.v + EP_GP);
+            const double *pr = dm.tdp ? c.ps + lr * dm.NPt : c.p;
+            double g = direct + RHS::vjp(xr, sr, j, D, pr, tm, st);
+            if (!dm.tdp) RHS::pgrad(xr, sr, j, D, pr, tm, st, acc.v + EP_GP);
             const int l = pp.lmap[j];
             if (l >= 0 && (m % dm.nskip) == 0) {
                 const int nd = m / dm.nskip;
@@ -328,6 +361,36 @@ VA_HD void tile_g(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &
         }
         lt += dlr; j += dj;
         if (j >= D) { j -= D; ++lt; }
+    }
+}
+
+// phase 5b (time-dependent parameters): dA/dp_m = (df/dp)^T s_m row by row -- one thread per
+// owned row walks the D state components (generic path, not a tuned one).
+template <class RHS, int DISC>
+VA_HD void tile_gp(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &acc, int tid, int nt)
+{
+    constexpr int HL = Halo<DISC>::HL;
+    const int D = dm.D;
+    const long NDx = (long)dm.N * D;
+    for (int lt = tid; lt < dm.T; lt += nt) {
+        const int lr = lt + HL, m = c.n0 + lt;
+        if (m >= dm.N) continue;
+        const double *xr = c.xs + lr * D, *sr = c.fs + lr * D, *pr = c.ps + lr * dm.NPt;
+        const double tm = c.tmodel ? c.tmodel[m] : 0.0;
+        const double *st = c.stim + (size_t)m * c.nstim;
+        double gp[RHS_MAX_NP];
+        for (int k = 0; k < RHS_MAX_NP; ++k) gp[k] = 0.0;
+        for (int j = 0; j < D; ++j) RHS::pgrad(xr, sr, j, D, pr, tm, st, gp);
+        for (int e = 0; e < dm.NPe; ++e) {
+            const int dst = pp.Pidx[e];
+            double g = 0.0;
+            for (int k = 0; k < RHS_MAX_NP; ++k) g = (k == dst) ? gp[k] : g;      // no runtime-indexed array
+            const long gi = NDx + (long)m * dm.NPe + e;
+            c.gtg[gi] = g;
+            if (c.use_d) acc.v[EP_GTD] += g * c.dg[gi];
+            acc.v[EP_GN2] += g * g;
+            acc.v[EP_GMAX] = fmax(acc.v[EP_GMAX], fabs(g));
+        }
     }
 }
 

@@ -52,15 +52,17 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
     c.stp = st.stp; c.c = 2.0 * st.rf_scale * dm.cfe;
     c.xs = smem; c.fs = smem + RD; c.qs = smem + 2 * RD;
     double *red = smem + 3 * RD;
+    c.ps = red + (EVAL_THREADS / 64) * EP_N;     // [R * NPt], time-dependent parameters only
     c.xg = dv.x + (size_t)b * dm.ld; c.dg = dv.d + (size_t)b * dm.ld;
     c.gtg = dv.gt + (size_t)b * dm.ld;
     c.tmodel = dv.pp.tmodel; c.stim = dv.pp.stim; c.nstim = dv.pp.nstim;
-    tile_params<RHS>(dm, dv.pp, b, c);
+    if (!dm.tdp) tile_params<RHS>(dm, dv.pp, b, c);
 
     const int tid = threadIdx.x, nt = blockDim.x;
     ThreadAcc acc;
     acc.clear();
     tile_load<DISC>(dm, c, tid, nt);
+    if (dm.tdp) tile_load_p<DISC>(dm, dv.pp, b, c, tid, nt);
     __syncthreads();
     tile_f<RHS, DISC>(dm, c, tid, nt);
     __syncthreads();
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
     tile_s<DISC>(dm, c, tid, nt);
     __syncthreads();
     tile_g<RHS, DISC>(dm, dv.pp, c, acc, tid, nt);
+    if (dm.tdp) tile_gp<RHS, DISC>(dm, dv.pp, c, acc, tid, nt);
 
     // wave64 shuffle reduction, then across the workgroup's waves through LDS
     const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
@@ -90,7 +93,8 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
 inline size_t eval_flat_lds_bytes(const Dims &dm)
 {
     const int HL = dm.disc == DISC_SH ? 2 : 1;
-    return sizeof(double) * ((size_t)3 * (dm.T + HL + 1) * dm.D + (EVAL_THREADS / 64) * EP_N);
+    return sizeof(double) * ((size_t)3 * (dm.T + HL + 1) * dm.D + (EVAL_THREADS / 64) * EP_N
+                             + (dm.tdp ? (size_t)(dm.T + HL + 1) * dm.NPt : 0));
 }
 inline int eval_flat_grid(const Dims &dm) { return ((dm.B * dm.ntiles + 7) / 8) * 8; }
 

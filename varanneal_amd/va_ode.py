@@ -27,9 +27,14 @@ traced once, differentiated symbolically and compiled into a device module
 (varanneal_amd.codegen) -- including the reference's `f(t, x, (p, stim))` stimulus
 convention (va_ode.py:345-375).
 
-Not implemented yet (SURVEY.md 8(f) "next" rows; raise NotImplementedError):
-time-dependent parameters (P0.ndim == 2 with 2-D X0), full (L,L)/(D,D) RM/RF matrices,
-user-defined action callables.
+Time-dependent parameters (upstream: P0 of shape (N_model, NP) with a 2-D X0,
+va_ode.py:170-188, 565-570) are supported for the discretisations that work upstream
+(trapezoid, SimpsonHermite); the model then receives the rows' own parameters, p[:, k].
+Here any subset Pidx may be estimated and bounds work (upstream's anneal_step and bounds
+branches for this case are broken, va_ode.py:597-601, 715-732).  A batch uses P0 (B, N_model, NP).
+
+Not implemented (raise NotImplementedError): full (L,L)/(D,D) RM/RF matrices (va_ode.py:149-152,
+211-222), user-defined action callables, method='LM'.
 """
 from __future__ import print_function
 
@@ -159,13 +164,23 @@ class Annealer(object):
         P0 = np.asarray(P0, dtype=np.float64)
         self._batched = X0.ndim == 3
         if self._batched:
-            if P0.ndim != 2 or P0.shape[0] != X0.shape[0]:
-                raise ValueError("batched X0 (B,N,D) needs P0 of shape (B,NP)")
+            if P0.ndim not in (2, 3) or P0.shape[0] != X0.shape[0]:
+                raise ValueError("batched X0 (B,N,D) needs P0 of shape (B,NP), or (B,N_model,NP) for "
+                                 "time-dependent parameters")
             self.B = X0.shape[0]
+            self._tdp = P0.ndim == 3
         else:
-            if P0.ndim != 1:
-                raise NotImplementedError("time-dependent parameters (P0.ndim == 2, va_ode.py:170-188)")
+            if P0.ndim not in (1, 2):
+                raise ValueError("P0 must be 1-D (static) or (N_model, NP) (time-dependent, va_ode.py:565-570)")
             self.B = 1
+            self._tdp = P0.ndim == 2
+        if self._tdp:
+            # upstream's euler / forwardmap branches slice p one row short (va_ode.py:345-349,
+            # 443-447 against :174-175): only the discretisations that work there are offered
+            if disc not in ("trapezoid", "SimpsonHermite"):
+                raise NotImplementedError("time-dependent parameters with disc=%r (inconsistent upstream)" % disc)
+            if P0.shape[-2] != self.N_model:
+                raise ValueError("time-dependent P0 must have N_model = %d rows" % self.N_model)
         if X0.shape[-2:] != (self.N_model, self.D):
             raise ValueError("X0 must have shape (N_model, D) = (%d, %d)" % (self.N_model, self.D))
         self.P = P0                                   # reference keeps a reference to the caller's array
@@ -188,7 +203,8 @@ class Annealer(object):
             # any other callable: trace it, differentiate it, emit HIP, compile a module
             from . import codegen
             nstim = 0 if stim is None else (1 if stim.ndim == 1 else stim.shape[1])
-            mod = codegen.module_for(self.f, self.D, self.NP, nstim, 1 if stim is None else stim.ndim)
+            mod = codegen.module_for(self.f, self.D, self.NP, nstim, 1 if stim is None else stim.ndim,
+                                     p_rows=self._tdp)
             rhs_id = _capi.load_rhs_module(mod["so"])
             self._rhs_module = mod
 
@@ -233,7 +249,9 @@ class Annealer(object):
         if bounds is not None:
             state_b, param_b = list(bounds[:self.D]), list(bounds[self.D:])
             self.bounds = [state_b[i] for _ in range(self.N_model) for i in range(self.D)]
-            self.bounds += [param_b[i] for i in range(self.NPest)]
+            # (upstream's time-dependent branch, va_ode.py:597-601, names undefined variables;
+            # this is what it means: the parameter bounds repeated for every time point)
+            self.bounds += [param_b[i] for _ in range(self.N_model if self._tdp else 1) for i in range(self.NPest)]
         else:
             self.bounds = None
         self._device_minimiser = (method == 'L-BFGS-B' and bounds is None)
@@ -245,8 +263,12 @@ class Annealer(object):
             X0[..., ::self.merr_nskip, self.Lidx] = self.Y[:]
         ND = self.N_model * self.D
         Xf = np.reshape(np.asarray(X0, dtype=np.float64), (self.B, ND))
-        Pf = np.reshape(P0, (self.B, self.NP))
-        self._mp = np.zeros((self.B, self.Nbeta, ND + self.NP), dtype=np.float64)
+        npw = self.N_model * self.NP if self._tdp else self.NP          # stored parameter block, time-major
+        Pf = np.reshape(P0, (self.B, npw))
+        # positions of the estimated entries inside that block, in path-vector order (va_ode.py:183-188)
+        self._estpos = ([n * self.NP + k for n in range(self.N_model) for k in self.Pidx] if self._tdp
+                        else list(self.Pidx))
+        self._mp = np.zeros((self.B, self.Nbeta, ND + npw), dtype=np.float64)
         self._mp[:, 0, :ND] = Xf
         self._mp[:, 0, ND:] = Pf
         self._A = np.zeros((self.B, self.Nbeta)); self._me = np.zeros((self.B, self.Nbeta))
@@ -261,8 +283,10 @@ class Annealer(object):
         if self._pb is not None:
             self._pb.close()
         self._pb = _capi.Problem(self.B, self.D, self.N_model, np.asarray(self.Y, dtype=np.float64),
-                                 self.Lidx, float(self.dt_model), self.RM, self.RF0, self._Pfull,
+                                 self.Lidx, float(self.dt_model), self.RM, self.RF0,
+                                 self._Pfull.reshape(self.B, self.N_model, self.NP) if self._tdp else self._Pfull,
                                  self.Pidx, disc=disc, rhs=rhs_id, merr_nskip=self.merr_nskip,
+                                 p_time_dependent=self._tdp,
                                  t_model=np.asarray(self.t_model, dtype=np.float64), stim=stim,
                                  lbfgs_m=int((opt_args or {}).get("maxcor", 10)),
                                  max_beta=self.Nbeta, keep_paths=1, device=device)
@@ -288,15 +312,27 @@ class Annealer(object):
         (va_ode.py:715-732)"""
         ND = self.N_model * self.D
         src = self._mp[:, k - 1 if k > 0 else 0]
-        return np.concatenate([src[:, :ND], src[:, ND:][:, self.Pidx]], axis=1)
+        return np.concatenate([src[:, :ND], src[:, ND:][:, self._estpos]], axis=1)
+
+    def _write_back_P(self):
+        """estimated values into the caller's P array (va_ode.py:750-769)"""
+        if self.NPest == 0:
+            return
+        if self._tdp:
+            est = self._Pfull.reshape(self.B, self.N_model, self.NP)[:, :, self.Pidx]
+            if self._batched:
+                self.P[:, :, self.Pidx] = est
+            else:
+                self.P[:, self.Pidx] = est[0]
+        elif self._batched:
+            self.P[:, self.Pidx] = self._Pfull[:, self.Pidx]
+        else:
+            self.P[self.Pidx] = self._Pfull[0, self.Pidx]
 
     def _store(self, k, x, A, me, fe, flag, nit, nfev):
         ND = self.N_model * self.D
-        self._Pfull[:, self.Pidx] = x[:, ND:]                          # va_ode.py:750-756
-        if self._batched:
-            self.P[:, self.Pidx] = x[:, ND:]
-        else:
-            self.P[self.Pidx] = x[0, ND:]
+        self._Pfull[:, self._estpos] = x[:, ND:]
+        self._write_back_P()
         self._A[:, k] = A; self._me[:, k] = me; self._fe[:, k] = fe      # :773-775
         self._mp[:, k, :ND] = x[:, :ND]; self._mp[:, k, ND:] = self._Pfull  # :776
         self._flags[:, k] = flag; self._nit[:, k] = nit; self._nfev[:, k] = nfev
@@ -339,12 +375,15 @@ class Annealer(object):
         nb = self.Nbeta - k0
         self._A[:, k0:] = r["A"]; self._me[:, k0:] = r["me"]; self._fe[:, k0:] = r["fe"]
         self._flags[:, k0:] = r["status"]; self._nit[:, k0:] = r["nit"]; self._nfev[:, k0:] = r["nfev"]
-        self._mp[:, k0:] = r["minpaths"]
-        self._Pfull[:] = self._mp[:, -1, ND:]
-        if self._batched:
-            self.P[:, self.Pidx] = self._Pfull[:, self.Pidx]
+        if self._tdp:                                 # rows come back as [X | p_est], time-major
+            mp = r["minpaths"]
+            self._mp[:, k0:, :ND] = mp[:, :, :ND]
+            self._mp[:, k0:, ND:] = self._Pfull[:, None, :]
+            self._mp[:, k0:, [ND + j for j in self._estpos]] = mp[:, :, ND:]
         else:
-            self.P[self.Pidx] = self._Pfull[0, self.Pidx]
+            self._mp[:, k0:] = r["minpaths"]
+        self._Pfull[:] = self._mp[:, -1, ND:]
+        self._write_back_P()
         self.betaidx = self.Nbeta - 1
         self.beta = self.beta_array[self.betaidx]
         self.RF = self.RF0 * self.alpha ** self.beta
@@ -386,7 +425,7 @@ class Annealer(object):
         X = np.asarray(X, dtype=np.float64)
         ND = self.N_model * self.D
         if X.shape[-1] == ND:
-            pad = self._Pfull[:, self.Pidx] if X.ndim == 2 else self._Pfull[0, self.Pidx]
+            pad = self._Pfull[:, self._estpos] if X.ndim == 2 else self._Pfull[0, self._estpos]
             X = np.concatenate([X, pad], axis=-1)
         return self._eval(X, False)[1]
 
@@ -428,6 +467,8 @@ class Annealer(object):
                   "parameter values to file anyway.")
         ND = self.N_model * self.D
         sav = self._mp[:, :, ND:]
+        if self._tdp:                                 # (Nbeta, N_model, NP), va_ode.py:824-840
+            sav = sav.reshape(self.B, self.Nbeta, self.N_model, self.NP)
         sav = sav if self._batched else sav[0]
         if filename.endswith('.npy'):
             np.save(filename, sav.astype(dtype))
