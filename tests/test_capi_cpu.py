@@ -52,9 +52,10 @@ def test_rhs_module_loader_rejects_bad_paths(capi, tmp_path):
 def test_struct_layout_matches_header(capi, tmp_path):
     prog = tmp_path / "sz.c"
     prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "varanneal_amd.h"\n'
-                    'int main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(va_problem_desc), sizeof(va_lbfgs_opts),'
+                    'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(va_problem_desc), sizeof(va_lbfgs_opts),'
                     ' offsetof(va_problem_desc, rf0_array), offsetof(va_problem_desc, stream),'
-                    ' offsetof(va_lbfgs_opts, maxfun)); return 0;}\n')
+                    ' offsetof(va_lbfgs_opts, maxfun), sizeof(va_nnet_desc), offsetof(va_nnet_desc, rf0),'
+                    ' offsetof(va_nnet_desc, stream)); return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(prog)])
     out = subprocess.check_output([str(exe)]).split()
@@ -63,6 +64,8 @@ def test_struct_layout_matches_header(capi, tmp_path):
     assert int(out[2]) == capi.ProblemDesc.rf0_array.offset
     assert int(out[3]) == capi.ProblemDesc.stream.offset
     assert int(out[4]) == capi.LbfgsOpts.maxfun.offset
+    assert int(out[5]) == C.sizeof(capi.NnetDesc)
+    assert int(out[6]) == capi.NnetDesc.rf0.offset and int(out[7]) == capi.NnetDesc.stream.offset
 
 
 def test_validation_without_gpu(capi):
