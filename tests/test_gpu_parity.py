@@ -193,6 +193,44 @@ def test_c3_shape_properties(capi):
     pb.close(); pb2.close()
 
 
+def test_c4_shape_properties(capi):
+    """BASELINE config 4 per-GPU shape (D=200, N=5000, L=80, 64 seeds; n_var = 1,000,001):
+    two seeds against the oracle, the rest through size-independent properties."""
+    import va_oracle
+    from varanneal_amd import twin
+    D, N, B = 200, 5000, 64
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    assert len(Lidx) == 80
+    rng = np.random.RandomState(44)
+    XP = np.concatenate([3.0 * rng.randn(B, N * D), 6.0 + 4.0 * rng.rand(B, 1)], axis=1)
+    XP[:, :N * D].reshape(B, N, D)[:, :, Lidx] = Y                       # init_to_data
+    XP[:, :N * D] += 0.1 * rng.randn(B, N * D)
+    P = XP[:, -1:].copy()
+    pb = capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid")
+    assert pb.info()["n_var"] == 1000001
+    A1, me1, fe1, g1 = pb.action_grad(XP, 1.0)
+    A2, me2, fe2, g2 = pb.action_grad(XP, 1000.0)
+    assert np.array_equal(me1, me2) and np.allclose(fe2, 1000.0 * fe1, rtol=1e-13)
+    assert np.allclose(A2, me2 + fe2, rtol=1e-15)
+    for b in (0, 37):
+        opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[b], [0], disc="trapezoid")
+        Ao, meo, feo, go = opb.action_grad(XP[b], 1000.0)
+        assert abs(A2[b] - Ao) <= RTOL_A * abs(Ao) and abs(me2[b] - meo) <= RTOL_A * abs(Ao)
+        assert np.abs(g2[b] - go).max() <= RTOL_G * np.abs(go).max()
+    # directional derivative along one random direction per seed
+    v = rng.randn(*XP.shape)
+    h = 1e-6
+    Ap = pb.action_grad(XP + h * v, 1000.0, want_grad=False)[0]
+    Am = pb.action_grad(XP - h * v, 1000.0, want_grad=False)[0]
+    assert np.allclose((Ap - Am) / (2 * h), np.sum(g2 * v, axis=1), rtol=1e-5, atol=1e-5)
+    # seeds are independent: a reversed batch gives the reversed outputs bit for bit
+    pb.close()
+    pb2 = capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[::-1].copy(), [0], disc="trapezoid")
+    Ar, _, _, gr = pb2.action_grad(XP[::-1].copy(), 1000.0)
+    assert np.array_equal(Ar, A2[::-1]) and np.array_equal(gr[5], g2[B - 6])
+    pb2.close()
+
+
 @pytest.mark.parametrize("D,disc", [(7, "trapezoid"), (36, "SimpsonHermite"), (64, "euler"),
                                     (100, "forwardmap"), (200, "trapezoid"), (200, "SimpsonHermite"),
                                     (300, "trapezoid"), (600, "trapezoid")])
