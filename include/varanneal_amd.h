@@ -168,7 +168,9 @@ int va_get_counters(va_handle h, int64_t *eval_launches, int64_t *seed_evals, in
  * row-major), b_0, W_1, b_1, ... (va_nnet.py:194-207).  minpaths rows returned by va_anneal
  * for such a handle are [X | p_est] (n_var wide); the caller scatters p_est into P. */
 enum { VA_ACT_SIGMOID = 0,   /* 1/(1+exp(-(W x + b))): examples/nnet_twin/nnet_twin_anneal.py:20-22 */
-       VA_ACT_TANH = 1, VA_ACT_LINEAR = 2 };
+       VA_ACT_TANH = 1, VA_ACT_LINEAR = 2,
+       VA_ACT_RELU = 3,      /* max(W x + b, 0) */
+       VA_ACT_SOFTPLUS = 4   /* log(1 + exp(W x + b)) */ };
 
 typedef struct va_nnet_desc {
     int32_t struct_size;      /* = sizeof(va_nnet_desc)                                  */

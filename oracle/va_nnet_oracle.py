@@ -21,6 +21,7 @@ ACTS = {
     "tanh": (lambda z: np.tanh(z), lambda a, z: 1.0 - a * a),
     "linear": (lambda z: z, lambda a, z: np.ones_like(z)),
     "softplus": (lambda z: np.log(1.0 + np.exp(z)), lambda a, z: 1.0 / (1.0 + np.exp(-z))),
+    "relu": (lambda z: z * (z.real > 0), lambda a, z: 1.0 * (z > 0)),
 }
 
 

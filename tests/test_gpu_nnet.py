@@ -49,6 +49,9 @@ def test_single_eval_matches_reference(gold, name):
     ([64, 64, 64, 64], 256, "sigmoid", False),      # tiles exactly full
     ([70, 33, 129, 5], 300, "tanh", True),          # ragged in every dimension, 2 example chunks
     ([784, 30, 10], 37, "sigmoid", False),          # tutorial MNIST shape (VarAnneal_tutorial.ipynb:3413-3415)
+    ([40, 50, 20], 70, "relu", False),
+    ([9, 14, 6], 12, "softplus", False),             # single-kernel path
+    ([9, 14, 6], 12, "relu", True),
 ])
 def test_larger_shapes_against_oracle(structure, M, act, weights_only):
     din, dout, _ = twin.make_nnet_twin(structure, M)

@@ -70,7 +70,9 @@ def test_activation_recognition():
     assert va_nnet.recognise_activation(twin.sigmoid) == "sigmoid"
     assert va_nnet.recognise_activation(lambda x, W, b: np.tanh(W.dot(x) + b)) == "tanh"
     assert va_nnet.recognise_activation(lambda x, W, b: np.dot(W, x) + b) == "linear"
-    assert va_nnet.recognise_activation(lambda x, W, b: np.maximum(np.dot(W, x) + b, 0.0)) is None
+    assert va_nnet.recognise_activation(lambda x, W, b: np.maximum(np.dot(W, x) + b, 0.0)) == "relu"
+    assert va_nnet.recognise_activation(lambda x, W, b: np.log(1.0 + np.exp(np.dot(W, x) + b))) == "softplus"
+    assert va_nnet.recognise_activation(lambda x, W, b: np.sin(np.dot(W, x) + b)) is None
     assert va_nnet.recognise_activation("tanh") == "tanh"
 
 
@@ -159,7 +161,7 @@ def test_bad_inputs_fail_loudly(fake_device):
     with pytest.raises(ValueError):
         a.anneal(X0, P0, 2.0, np.arange(2), 1.0, 1e-3, Pidx)
     a.set_structure(s); a.set_input_data(din); a.set_output_data(dout)
-    a.set_activation(lambda x, W, b: np.maximum(np.dot(W, x) + b, 0.0))
+    a.set_activation(lambda x, W, b: np.sin(np.dot(W, x) + b))
     with pytest.raises(NotImplementedError):
         a.anneal(X0, P0, 2.0, np.arange(2), 1.0, 1e-3, Pidx)
     a.set_activation(twin.sigmoid)

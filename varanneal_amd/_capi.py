@@ -58,7 +58,7 @@ class NnetDesc(C.Structure):
                 ("keep_paths", C.c_int32), ("stream", C.c_void_p)]
 
 
-ACTIVATION = {"sigmoid": 0, "tanh": 1, "linear": 2}
+ACTIVATION = {"sigmoid": 0, "tanh": 1, "linear": 2, "relu": 3, "softplus": 4}
 
 
 class LbfgsOpts(C.Structure):

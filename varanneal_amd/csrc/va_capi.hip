@@ -463,7 +463,7 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
     *out = nullptr;
     if (d->struct_size != (int32_t)sizeof(va_nnet_desc)) return fail(VA_EINVAL, "struct_size %d != %zu", d->struct_size, sizeof(va_nnet_desc));
     if (d->batch < 1 || d->n_layers < 2 || d->M < 1 || !d->structure) return fail(VA_EINVAL, "bad sizes (batch=%d n_layers=%d M=%d)", d->batch, d->n_layers, d->M);
-    if (d->activation < VA_ACT_SIGMOID || d->activation > VA_ACT_LINEAR) return fail(VA_EUNSUPPORTED, "unknown activation %d", d->activation);
+    if (d->activation < VA_ACT_SIGMOID || d->activation > VA_ACT_SOFTPLUS) return fail(VA_EUNSUPPORTED, "unknown activation %d", d->activation);
     const int NL = d->n_layers;
     std::vector<int> s(d->structure, d->structure + NL), off(NL + 1, 0), woff(NL - 1), boff(NL - 1);
     long long np = 0;

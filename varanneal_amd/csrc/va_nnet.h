@@ -8,7 +8,7 @@
 
 namespace va {
 
-enum { NNET_SIGMOID = 0, NNET_TANH = 1, NNET_LINEAR = 2 };
+enum { NNET_SIGMOID = 0, NNET_TANH = 1, NNET_LINEAR = 2, NNET_RELU = 3, NNET_SOFTPLUS = 4 };
 
 constexpr int NN_TILE = 64;      // workgroup output tile: 2 x 2 waves, each 2 x 2 MFMA blocks of 16x16
 constexpr int NN_KC = 32;        // K elements staged in LDS per step

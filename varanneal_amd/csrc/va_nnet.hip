@@ -37,12 +37,17 @@ template <int ACT> __device__ __forceinline__ double act_f(double z)
 {
     if (ACT == NNET_SIGMOID) return 1.0 / (1.0 + exp(-z));
     if (ACT == NNET_TANH) return tanh(z);
+    if (ACT == NNET_RELU) return fmax(z, 0.0);
+    if (ACT == NNET_SOFTPLUS) return z > 30.0 ? z : log1p(exp(z));
     return z;
 }
+// derivative of the activation expressed through its value a = act(z)
 template <int ACT> __device__ __forceinline__ double act_d(double a)
 {
     if (ACT == NNET_SIGMOID) return a * (1.0 - a);
     if (ACT == NNET_TANH) return 1.0 - a * a;
+    if (ACT == NNET_RELU) return a > 0.0 ? 1.0 : 0.0;
+    if (ACT == NNET_SOFTPLUS) return -expm1(-a);            // 1 - exp(-softplus(z)) = sigmoid(z)
     return 1.0;
 }
 
@@ -613,6 +618,8 @@ void launch_nnet_eval(const Dev &dv, const NnetDev &nn, hipStream_t s)
         switch (nn.act) {
         case NNET_SIGMOID: hipLaunchKernelGGL(k_nnet_small<NNET_SIGMOID>, dim3(nn.NL, B), blk, lds, s, dv, nn); break;
         case NNET_TANH: hipLaunchKernelGGL(k_nnet_small<NNET_TANH>, dim3(nn.NL, B), blk, lds, s, dv, nn); break;
+        case NNET_RELU: hipLaunchKernelGGL(k_nnet_small<NNET_RELU>, dim3(nn.NL, B), blk, lds, s, dv, nn); break;
+        case NNET_SOFTPLUS: hipLaunchKernelGGL(k_nnet_small<NNET_SOFTPLUS>, dim3(nn.NL, B), blk, lds, s, dv, nn); break;
         default: hipLaunchKernelGGL(k_nnet_small<NNET_LINEAR>, dim3(nn.NL, B), blk, lds, s, dv, nn); break;
         }
         return;
@@ -621,6 +628,8 @@ void launch_nnet_eval(const Dev &dv, const NnetDev &nn, hipStream_t s)
     switch (nn.act) {
     case NNET_SIGMOID: hipLaunchKernelGGL(k_nnet_fwd<NNET_SIGMOID>, dim3(nn.n1, B), blk, 0, s, dv, nn); break;
     case NNET_TANH: hipLaunchKernelGGL(k_nnet_fwd<NNET_TANH>, dim3(nn.n1, B), blk, 0, s, dv, nn); break;
+    case NNET_RELU: hipLaunchKernelGGL(k_nnet_fwd<NNET_RELU>, dim3(nn.n1, B), blk, 0, s, dv, nn); break;
+    case NNET_SOFTPLUS: hipLaunchKernelGGL(k_nnet_fwd<NNET_SOFTPLUS>, dim3(nn.n1, B), blk, 0, s, dv, nn); break;
     default: hipLaunchKernelGGL(k_nnet_fwd<NNET_LINEAR>, dim3(nn.n1, B), blk, 0, s, dv, nn); break;
     }
     hipLaunchKernelGGL(k_nnet_bwd_x, dim3(nn.n2, B), blk, 0, s, dv, nn);

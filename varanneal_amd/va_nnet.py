@@ -19,7 +19,7 @@ P0 of shape (B, NP) anneal B initial guesses as one batch; `device`, `verbose`, 
 
 The activation is the reference's callable f(x, W, b) (examples/nnet_twin/
 nnet_twin_anneal.py:20-22); it is matched numerically against the built-in registry
-(sigmoid, tanh, linear of W.x + b) -- anything else raises NotImplementedError.
+(sigmoid, tanh, linear, relu, softplus of W.x + b) -- anything else raises NotImplementedError.
 
 Upstream defects fixed rather than reproduced: the default `Lidx` is an integer range
 (va_nnet.py:326-327 builds a float linspace NumPy refuses as an index); `save_params` slices
@@ -38,6 +38,8 @@ ACT_IMPL = {
     "sigmoid": lambda x, W, b: 1.0 / (1.0 + np.exp(-(np.dot(W, x) + b))),
     "tanh": lambda x, W, b: np.tanh(np.dot(W, x) + b),
     "linear": lambda x, W, b: np.dot(W, x) + b,
+    "relu": lambda x, W, b: np.maximum(np.dot(W, x) + b, 0.0),
+    "softplus": lambda x, W, b: np.logaddexp(0.0, np.dot(W, x) + b),
 }
 
 
