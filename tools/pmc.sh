@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> <bench args...>   -- rocprofv3 counter passes for the eval kernel (own runs, no tracing domains)
+# usage: tools/pmc.sh <tag> <bench args...>   -- rocprofv3 counter passes for the eval kernel (own runs, no tracing domains)
 tag=$1; shift
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc_$tag
