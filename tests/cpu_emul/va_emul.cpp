@@ -44,7 +44,8 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     if (m.emode == 3) {                      // column-run: T = RY*K, K in {4,6,8}
         m.RY = tile3_RY(m.D); m.NT = tile3_threads(m.D);
         int K = (T + m.RY - 1) / m.RY;
-        K = K <= 4 ? 4 : (K <= 6 ? 6 : 8);
+        K = K < 4 ? 4 : (K > 8 ? 8 : K);
+        if (m.disc == DISC_SH && (K & 1)) ++K;   // Simpson-Hermite runs start on even rows
         m.maxr = K; T = m.RY * K;
     }
     if (m.emode == 2) {                      // a lane walks at most 16 rows of the staged tile
@@ -224,7 +225,9 @@ void eval_seed_rhs(const Emul &E, int b, const double *x, const double *d, int u
 #endif
     if (E.dm.emode == 3) {
         if (E.dm.maxr == 4) eval_seed3<RhsL96g, DISC, 4>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 5) eval_seed3<RhsL96g, DISC, 5>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
         else if (E.dm.maxr == 6) eval_seed3<RhsL96g, DISC, 6>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 7) eval_seed3<RhsL96g, DISC, 7>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
         else eval_seed3<RhsL96g, DISC, 8>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
     } else if (E.dm.emode == 2) eval_seed2<RhsL96c, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
     else eval_seed<RhsL96, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev);

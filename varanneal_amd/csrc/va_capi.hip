@@ -112,9 +112,23 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, bool user_rhs)
         // seeds (profiles/r01_sweep_*.txt); drop to 4 when that leaves CUs without a workgroup
         int K = 6;
         if ((long)d->batch * ((N + dm.RY * K - 1) / (dm.RY * K)) < 256) K = 4;
+        else if ((long)d->batch * ((N + dm.RY * K - 1) / (dm.RY * K)) < 8 * 256 && dm.NT == 256) {
+            // small grids run as a handful of workgroups per CU, all resident at once: the busiest
+            // CU sets the time.  Pick the K whose (workgroups per CU, rounded up) x (rows per lane +
+            // fixed per-workgroup cost) is smallest, e.g. C3 (64 seeds, N = 1000): K = 7 gives
+            // 12 tiles x 64 = 768 workgroups = exactly 3 per CU (10.2 us) against 3.5 for K = 6 (10.7 us).
+            long best = -1;
+            for (int k = 5; k <= 8; ++k) {
+                if (sh && (k & 1)) continue;              // Simpson-Hermite runs start on even rows
+                const long wgs = (long)d->batch * ((N + dm.RY * k - 1) / (dm.RY * k));
+                const long cost = ((wgs + 255) / 256) * (k + 2) * 4 + (k == 6 ? 0 : 1);     // ties go to 6
+                if (best < 0 || cost < best) { best = cost; K = k; }
+            }
+        }
         if (d->tile_rows > 0) {
             K = (d->tile_rows + dm.RY - 1) / dm.RY;
-            K = K <= 4 ? 4 : (K <= 6 ? 6 : 8);
+            K = K < 4 ? 4 : (K > 8 ? 8 : K);
+            if (sh && (K & 1)) ++K;
         }
         if (dm.NT > 256 && K > 6) K = 6;                  // 1024-thread groups: 128-VGPR budget
         for (;;) {                                        // shrink until the staging arrays fit in LDS

@@ -286,7 +286,9 @@ void launch_eval(const Dev &dv, int rhs, hipStream_t s)
     (void)rhs;                 // VA_RHS_LORENZ96 is the only built-in RHS so far
     if (dv.dm.emode == 3) {
         if (dv.dm.maxr == 4) launch_eval3_d<RhsL96g, 4>(dv, s);
+        else if (dv.dm.maxr == 5) launch_eval3_d<RhsL96g, 5>(dv, s);
         else if (dv.dm.maxr == 6) launch_eval3_d<RhsL96g, 6>(dv, s);
+        else if (dv.dm.maxr == 7) launch_eval3_d<RhsL96g, 7>(dv, s);
         else launch_eval3_d<RhsL96g, 8>(dv, s);
     } else if (dv.dm.emode == 2) {
         if (dv.dm.maxr <= 8) launch_eval2_rhs<RhsL96c, 8>(dv, s);
