@@ -155,3 +155,25 @@ def test_bounds_route_uses_device_evaluator(gold):
     assert np.all(np.abs(est) <= 0.05 + 1e-15) and np.all(a.exitflags == 0)
     assert np.allclose(a.A_array, a.me_array + a.fe_array, rtol=1e-12)
     a.close()
+
+
+@pytest.mark.parametrize("structure,M,act", [([1, 1], 1, "sigmoid"), ([3, 2], 1, "tanh"), ([2, 5, 1], 2, "linear"),
+                                             ([33, 2], 3, "sigmoid"), ([2, 33], 33, "tanh")])
+def test_smallest_networks(structure, M, act):
+    """two layers (no hidden layer), one example, single neurons, and shapes just past the
+    single-kernel limit (33 > 32) so both evaluators see their edge."""
+    rng = np.random.RandomState(1)
+    din, dout = rng.randn(M, structure[0]), rng.rand(M, structure[-1])     # (the twin recipe standardises
+    Lidx = [np.arange(structure[0]), np.arange(structure[-1])]             # the input: undefined for 1 neuron)
+    NP = twin.nnet_param_layout(structure)[2]
+    X0, P0, Pidx = rng.rand(M * int(np.sum(structure))), 0.3 * rng.randn(NP), list(range(NP))
+    XP = np.append(X0, P0[Pidx])
+    pr = _capi.NnetProblem(1, structure, din, dout, Lidx, 2.0, 0.3, P0[None, :], Pidx, act=act)
+    A, me, fe, g = pr.action_grad(XP[None, :], 4.0)
+    pb = vno.NnetProblem(structure, din, dout, Lidx, 2.0, 0.3, P0, Pidx, act=act)
+    A1, me1, fe1, g1 = pb.action_grad(XP, 4.0)
+    assert abs(A[0] - A1) <= 1e-12 * abs(A1) and abs(me[0] - me1) <= 1e-12 * abs(A1)
+    assert np.abs(g[0] - g1).max() <= 1e-10 * np.abs(g1).max()
+    r = pr.minimize_lbfgs(XP[None, :], 4.0, {'gtol': 1e-10, 'ftol': 1e-12, 'maxfun': 500, 'maxiter': 500})
+    assert r["A"][0] < A[0] and r["status"][0] in (0, 1)
+    pr.close()

@@ -274,3 +274,30 @@ def test_wide_state_minimisation_matches_oracle(capi):
     pb.close()
     assert (r["nit"][0], r["nfev"][0], r["status"][0]) == (nit, nfev, st)
     assert abs(r["A"][0] - A) <= 1e-6 * abs(A) and np.abs(r["x"][0] - x).max() <= 1e-6
+
+
+@pytest.mark.parametrize("D,N,disc", [(4, 2, "trapezoid"), (4, 3, "SimpsonHermite"), (5, 2, "euler"),
+                                      (4, 2, "forwardmap"), (6, 5, "SimpsonHermite"), (21, 13, "trapezoid")])
+def test_smallest_problems(capi, D, N, disc):
+    """the smallest shapes the reference accepts: two time points (one residual row), the
+    three-point Simpson-Hermite stencil, D = 4 (the Lorenz-96 stencil wraps onto itself)."""
+    import va_oracle
+    rng = np.random.RandomState(100 * D + N)
+    Lidx = [0, D - 1]
+    Y = rng.randn(N, 2)
+    B = 2
+    XP = np.concatenate([2.0 * rng.randn(B, N * D), 7.0 + rng.rand(B, 1)], axis=1)
+    P = XP[:, -1:].copy()
+    for ek in (0, 1, 2):
+        pb = capi.Problem(B, D, N, Y, Lidx, 0.025, 3.0, 0.7, P, [0], disc=disc, eval_kernel=ek)
+        A, me, fe, g = pb.action_grad(XP, 2.5)
+        r = pb.minimize_lbfgs(XP, 2.5, dict(OPTS, maxiter=5))
+        pb.close()
+        for b in range(B):
+            opb = va_oracle.Problem(D, N, Y, Lidx, 0.025, 3.0, 0.7, P[b], [0], disc=disc)
+            Ao, meo, feo, go = opb.action_grad(XP[b], 2.5)
+            assert abs(A[b] - Ao) <= RTOL_A * abs(Ao) and abs(me[b] - meo) <= RTOL_A * abs(Ao), (ek, b)
+            assert np.abs(g[b] - go).max() <= RTOL_G * np.abs(go).max(), (ek, b)
+            x, Am, st, nit, nfev = opb.minimize_lbfgs(XP[b], 2.5, dict(OPTS, maxiter=5))
+            assert (r["nit"][b], r["nfev"][b], r["status"][b]) == (nit, nfev, st), (ek, b)
+            assert abs(r["A"][b] - Am) <= 1e-9 * abs(Am)
