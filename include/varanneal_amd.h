@@ -153,6 +153,11 @@ int va_get_minpath(va_handle h, int32_t seed, int32_t beta_idx, double *out);
  * bracketed by HIP events on the handle's stream; returns elapsed ms. */
 int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms);
 
+/* Profiling hook: copy the first n doubles of the L-BFGS inner-product partial table to the
+ * host.  With VA_DEBUG_EVAL=16 in the environment at create time the eval kernel records a
+ * per-workgroup timeline there instead (tools/timeline.py); production runs never set it. */
+int va_debug_read_partials(va_handle h, double *out, int64_t n);
+
 /* Cumulative counters since create: batched eval launches, seed-evaluations,
  * L-BFGS cycles. */
 int va_get_counters(va_handle h, int64_t *eval_launches, int64_t *seed_evals, int64_t *cycles);

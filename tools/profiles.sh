@@ -18,4 +18,5 @@ for w in c5 c5x; do
   cp $out/trace_$w/*/*kernel_stats.csv $out/nnet_${w}_kernel_stats.csv
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/mfma_f64_peak tools/mfma_f64_peak.hip 2>/dev/null && ./tools/mfma_f64_peak > $out/mfma_f64_peak.txt; cat $out/mfma_f64_peak.txt
+python tools/timeline.py > $out/timeline_c3.txt 2>&1; tail -12 $out/timeline_c3.txt
 rm -rf $out/trace_eval $out/trace_ladder $out/trace_c5 $out/trace_c5x

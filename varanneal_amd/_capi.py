@@ -180,10 +180,11 @@ def lib():
     L.va_get_minpath.argtypes = [h, C.c_int32, C.c_int32, c_dp]
     L.va_eval_timed.argtypes = [h, C.c_double, C.c_int32, C.POINTER(C.c_float)]
     L.va_get_counters.argtypes = [h, c_lp, c_lp, c_lp]
+    L.va_debug_read_partials.argtypes = [h, c_dp, C.c_int64]
     for fn in ("va_device_count", "va_rhs_load_module", "va_problem_create", "va_nnet_problem_create",
                "va_problem_info", "va_action_grad",
                "va_minimize_lbfgs", "va_anneal", "va_get_minpath", "va_eval_timed",
-               "va_get_counters"):
+               "va_get_counters", "va_debug_read_partials"):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -191,7 +192,7 @@ def lib():
 
 EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_problem_create",
            "va_problem_destroy", "va_problem_info", "va_action_grad", "va_minimize_lbfgs",
-           "va_anneal", "va_get_minpath", "va_eval_timed", "va_get_counters", "va_nnet_problem_create"]
+           "va_anneal", "va_get_minpath", "va_eval_timed", "va_get_counters", "va_nnet_problem_create", "va_debug_read_partials"]
 
 
 def check(rc):
@@ -304,6 +305,11 @@ class Problem(object):
         ms = C.c_float()
         check(self._L.va_eval_timed(self._h, float(rf_scale), int(iters), C.byref(ms)))
         return ms.value
+
+    def debug_partials(self, n):
+        out = np.empty(n)
+        check(self._L.va_debug_read_partials(self._h, out.ctypes.data_as(c_dp), n))
+        return out
 
     def counters(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()

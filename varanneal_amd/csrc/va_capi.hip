@@ -736,6 +736,18 @@ int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms
     return VA_OK;
 }
 
+int va_debug_read_partials(va_handle h, double *out, int64_t n)
+{
+    if (!h || !out || n < 0) return fail(VA_EINVAL, "bad argument");
+    const Dev &dv = h->dv;
+    const int64_t have = (int64_t)dv.dm.B * dv.dm.nchunks * dv.ups;
+    if (n > have) return fail(VA_EINVAL, "n=%lld > %lld partials", (long long)n, (long long)have);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(out, dv.upp, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return VA_OK;
+}
+
 int va_get_counters(va_handle h, int64_t *eval_launches, int64_t *seed_evals, int64_t *cycles)
 {
     if (!h) return fail(VA_EINVAL, "null handle");

@@ -107,6 +107,17 @@ __global__ __launch_bounds__(NTMAX) void k_eval3(const Dev dv)
     const bool evenD = (D & 1) == 0;
     const double *xg = dv.x + (size_t)b * dm.ld;
 
+    // profiling builds only (dm.dbg & 16): per-workgroup timeline -> the update-partials table,
+    // read back with va_debug_read_partials (tools/timeline.py)
+    unsigned long long *tl = nullptr;
+    if (dm.dbg & 16) {
+        tl = reinterpret_cast<unsigned long long *>(dv.upp) + (size_t)blockIdx.x * 8;
+        if (threadIdx.x == 0) {
+            tl[0] = wall_clock64();
+            tl[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_ID
+            tl[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));    // XCC_ID
+        }
+    }
     // phase A step 1: x loads in flight before anything else is waited for
     double xr[NS][2];
     if (evenD) {
@@ -158,6 +169,7 @@ __global__ __launch_bounds__(NTMAX) void k_eval3(const Dev dv)
         else tile3_stage_odd<RHS, DISC, K, DC, true, false>(dm, t, tid, nt);
     }
     __syncthreads();
+    if (tl && threadIdx.x == 0) tl[1] = wall_clock64();
     if (dm.dbg & 2) {                    // ablation: copy kernel (stage -> store), no arithmetic
         if (active && !edge)
             for (int k = 0; k < K; ++k)
@@ -169,6 +181,7 @@ __global__ __launch_bounds__(NTMAX) void k_eval3(const Dev dv)
         else tile3_rows<RHS, DISC, K, false, DC>(dm, dv.pp, t, rg, acc);
     }
     __syncthreads();
+    if (tl && threadIdx.x == 0) tl[2] = wall_clock64();
     if (active) {
         if (edge) tile3_grad<RHS, DISC, K, true, DC>(dm, t, rg, acc);
         else tile3_grad<RHS, DISC, K, false, DC>(dm, t, rg, acc);
@@ -216,6 +229,11 @@ __global__ __launch_bounds__(NTMAX) void k_eval3(const Dev dv)
     const int kcol = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
     if ((lane & 7) == 0 && kcol != EP_GMAX && kcol - EP_GP < RHS::NP) prow[kcol] = y;
     if (lane == 0) prow[EP_GMAX] = gm;
+    if (tl && threadIdx.x == 0) {
+        tl[3] = wall_clock64();                       // stores issued
+        __builtin_amdgcn_s_waitcnt(0);
+        tl[4] = wall_clock64();                       // this wave's stores acknowledged
+    }
 }
 
 size_t eval_lds_bytes(const Dims &dm)
