@@ -306,3 +306,25 @@ def test_time_dependent_parameters_host_flow(monkeypatch, tmp_path):
     assert np.load(str(tmp_path / "p.npy")).shape == (nb, N, 1)
     with pytest.raises(NotImplementedError):
         a.anneal(X0, P0, 1.5, np.arange(2), 4.0, 4e-6, list(c["Lidx"]), [0], disc="euler", verbose=False)
+
+
+def test_admin_surface(fake_device, golden_ladders):
+    """the ADmin method names user code may call directly (_autodiffmin.py:32-143)"""
+    c = golden_ladders["g4_c1_trapezoid_N200"]
+    a = _setup(c)
+    a.anneal_init(c["X0"].copy(), c["P0"].copy(), 1.5, np.arange(3), 4.0, 4e-6, list(c["Lidx"]), [0],
+                  opt_args=OPTS, verbose=False)
+    XP0 = a._xp0(0)[0]
+    a.tape_A(a.gen_xtrace())
+    assert a.gen_xtrace().shape == XP0.shape
+    A, g = a.A_gradA_taped(XP0)
+    assert a.A_taped(XP0) == A and np.array_equal(a.gradA_taped(XP0), g)
+    x, Amin, status = a.min_lbfgs_scipy(XP0)
+    assert x.shape == XP0.shape and Amin < A and status in (0, 1, 2)
+    x2, A2, st2 = a.min_cg_scipy(XP0)
+    x3, A3, st3 = a.min_tnc_scipy(XP0)
+    assert A2 < A and A3 < A
+    with pytest.raises(NotImplementedError):
+        a.hessianA_taped(XP0)
+    with pytest.raises(NotImplementedError):
+        a.min_lm_scipy(XP0)

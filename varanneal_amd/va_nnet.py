@@ -33,6 +33,7 @@ import time
 import numpy as np
 
 from . import _capi
+from ._hipmin import HIPmin
 
 ACT_IMPL = {
     "sigmoid": lambda x, W, b: 1.0 / (1.0 + np.exp(-(np.dot(W, x) + b))),
@@ -68,7 +69,7 @@ def recognise_activation(f):
     return None
 
 
-class Annealer(object):
+class Annealer(HIPmin):
     def __init__(self):
         self.taped = False
         self.annealing_initialized = False
@@ -324,10 +325,6 @@ class Annealer(object):
         if single:
             return A[0], me[0], fe[0], (g[0] if want_grad else None)
         return A, me, fe, g
-
-    def A_gradA_taped(self, XP):
-        A, me, fe, g = self._eval(XP, True)
-        return A, g
 
     def A_gaussian(self, XP):
         return self._eval(XP, False)[0]

@@ -43,11 +43,12 @@ import time
 import numpy as np
 
 from . import _capi, rhs as _rhs
+from ._hipmin import HIPmin
 
 _DISCS = ("euler", "trapezoid", "SimpsonHermite", "forwardmap")
 
 
-class Annealer(object):
+class Annealer(HIPmin):
     def __init__(self):
         self.taped = False                    # reference attribute (va_ode.py:53); unused here
         self.annealing_initialized = False
@@ -400,11 +401,6 @@ class Annealer(object):
                   % (nb, self.B, dt, int(self._nfev[:, k0:].sum())))
 
     # ------------------------------------------------------------------ S1 evaluator
-    def A_gradA_taped(self, XP):
-        """Name kept from ADmin (_autodiffmin.py:57-58): (A, grad A) at the current RF."""
-        A, me, fe, g = self._eval(XP, True)
-        return A, g
-
     def _eval(self, XP, want_grad):
         XP = np.asarray(XP, dtype=np.float64)
         single = XP.ndim == 1
@@ -500,6 +496,10 @@ class Annealer(object):
         exitR = self._flags[seed].reshape((self.Nbeta, 1))
         AR = self._A[seed].reshape((self.Nbeta, 1))
         np.savetxt(savefile, np.hstack((betaR, exitR, AR, self._mp[seed])))
+
+    def gen_xtrace(self):
+        """kept for API compatibility (va_ode.py:894-905); nothing is taped here"""
+        return np.random.rand(self._mp.shape[-1] - (self._Pfull.shape[1] - len(self._estpos)))
 
     def close(self):
         if self._pb is not None:
