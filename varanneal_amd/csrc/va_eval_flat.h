@@ -8,17 +8,44 @@
 namespace va {
 
 // ------------------------------------------------------------------ helpers
+// Cross-lane reductions without LDS round trips.  Inside a row of 16 lanes the exchanges are DPP
+// moves (row_mirror: i <-> 15-i, row_half_mirror: i <-> 7-i, quad_perm for xor 2 / xor 1): every
+// step pairs groups that were disjoint so far, so after four steps each lane holds its row's
+// total.  The four rows are then combined through v_readlane (wave-uniform scalars), in a fixed
+// order: every lane returns the same, deterministic total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141, DPP_QUAD_XOR2 = 0x4E, DPP_QUAD_XOR1 = 0xB1;
+template <bool MAX>
+__device__ __forceinline__ double row16_reduce(double v)
+{
+    double o;
+    o = dpp_mov<DPP_ROW_MIRROR>(v); v = MAX ? fmax(v, o) : v + o;
+    o = dpp_mov<DPP_ROW_HALF_MIRROR>(v); v = MAX ? fmax(v, o) : v + o;
+    o = dpp_mov<DPP_QUAD_XOR2>(v); v = MAX ? fmax(v, o) : v + o;
+    o = dpp_mov<DPP_QUAD_XOR1>(v); v = MAX ? fmax(v, o) : v + o;
+    return v;
+}
+__device__ __forceinline__ double lane_scalar(double x, int i)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), i);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), i);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    v = row16_reduce<false>(v);
+    return ((lane_scalar(v, 0) + lane_scalar(v, 16)) + lane_scalar(v, 32)) + lane_scalar(v, 48);
 }
 __device__ __forceinline__ double wave_max(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-    return v;
+    v = row16_reduce<true>(v);
+    return fmax(fmax(lane_scalar(v, 0), lane_scalar(v, 16)), fmax(lane_scalar(v, 32), lane_scalar(v, 48)));
 }
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one):

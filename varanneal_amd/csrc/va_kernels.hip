@@ -187,48 +187,26 @@ __global__ __launch_bounds__(NTMAX) void k_eval3(const Dev dv)
         else tile3_grad<RHS, DISC, K, false, DC>(dm, t, rg, acc);
     }
 
-    // every wave writes its own partial row (no LDS, no barrier: a __syncthreads here would
+    // every wave writes its own partial row (no workgroup barrier: a __syncthreads here would
     // also wait for the gradient stores to land); k_ls sums the rows in a fixed order.
-    // The 7 sums go through ONE halving butterfly (10 lane exchanges instead of 7 x 6): after
-    // the xor-32/16/8 steps each lane carries one value, after xor-4/2/1 its wave total.
-    static_assert(EP_GMAX == 4 && EP_GP == 5 && RHS::NP <= 3, "butterfly slot layout");
+    // Rows of 16 lanes reduce through DPP moves (no LDS latency); the four row totals of each
+    // value meet in a wave-private LDS strip, and lane k finishes value k.
     (void)KP;
     const int lane = tid & 63, wave = tid >> 6;
     double *prow = dv.evp + (((size_t)b * dm.ntiles + tile) * (nt >> 6) + wave) * EP_N;
-    const double gm = wave_max(acc.v[EP_GMAX]);
-    double v8[8];
+    double *strip = smem + SE + tile3_s_elems(K, D, G, RY) + wave * (4 * 8);      // [4 rows][8 values]
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v8[k] = (k == EP_GMAX || k - EP_GP >= RHS::NP) ? 0.0 : acc.v[k];
-    double w4[4], z2[2];
-    {
-        const bool up = (lane & 32) != 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const double send = up ? v8[i] : v8[i + 4], keep = up ? v8[i + 4] : v8[i];
-            w4[i] = keep + __shfl_xor(send, 32, 64);
-        }
+    for (int k = 0; k < KP; ++k) {
+        const double r = (k == EP_GMAX) ? row16_reduce<true>(acc.v[k]) : row16_reduce<false>(acc.v[k]);
+        if ((lane & 15) == 0) strip[(lane >> 4) * 8 + k] = r;
     }
-    {
-        const bool up = (lane & 16) != 0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const double send = up ? w4[i] : w4[i + 2], keep = up ? w4[i + 2] : w4[i];
-            z2[i] = keep + __shfl_xor(send, 16, 64);
-        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < KP) {
+        const double r0 = strip[lane], r1 = strip[8 + lane], r2 = strip[16 + lane], r3 = strip[24 + lane];
+        prow[lane] = (lane == EP_GMAX) ? fmax(fmax(r0, r1), fmax(r2, r3)) : ((r0 + r1) + r2) + r3;
     }
-    double y;
-    {
-        const bool up = (lane & 8) != 0;
-        const double send = up ? z2[0] : z2[1], keep = up ? z2[1] : z2[0];
-        y = keep + __shfl_xor(send, 8, 64);
-    }
-    y += __shfl_xor(y, 4, 64);
-    y += __shfl_xor(y, 2, 64);
-    y += __shfl_xor(y, 1, 64);
-    // lane with bits (5,4,3) = k holds the total of value k
-    const int kcol = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
-    if ((lane & 7) == 0 && kcol != EP_GMAX && kcol - EP_GP < RHS::NP) prow[kcol] = y;
-    if (lane == 0) prow[EP_GMAX] = gm;
     if (tl && threadIdx.x == 0) {
         tl[3] = wall_clock64();                       // stores issued
         __builtin_amdgcn_s_waitcnt(0);
@@ -244,7 +222,7 @@ size_t eval_lds_bytes(const Dims &dm)
     if (dm.emode == 3)
         elems = (size_t)tile3_stage_elems(dm.maxr, dm.D, 2, dm.RY, HL + 1) + tile3_s_elems(dm.maxr, dm.D, 2, dm.RY);
     else elems = (size_t)((dm.emode == 2 && dm.disc != DISC_SH) ? 2 : 3) * R * dm.D;
-    return sizeof(double) * (elems + (256 / 64) * EP_N);
+    return sizeof(double) * (elems + (size_t)(dm.emode == 3 ? (dm.NT / 64) * 32 : (256 / 64) * EP_N));
 }
 
 template <class RHS, int DISC, int K, int DC, int NTMAX>
