@@ -16,8 +16,11 @@ namespace va {
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double x)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    // every lane has a valid source under these row permutations: `old` is never used, so the
+    // value itself stands in for it and no register has to be initialised
+    const int xl = __double2loint(x), xh = __double2hiint(x);
+    const int lo = __builtin_amdgcn_update_dpp(xl, xl, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(xh, xh, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 constexpr int DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141, DPP_QUAD_XOR2 = 0x4E, DPP_QUAD_XOR1 = 0xB1;

@@ -320,6 +320,9 @@ VA_HD void tile3_rows(const Dims &dm, const ProblemPtrs &pp, const Tile3 &t, T3R
     }
     // direct_m, s_m (same linear combinations as disc_direct_s, on registers); s with ghosts
     double *sc0 = t.ss + t.ty * (K * DP + P) + G + i;
+    // ghost copy for the cyclic neighbours, branch-free: the first G columns also write D to the
+    // right, the last G columns D to the left, every other lane rewrites its own slot (D >= 2G)
+    const int goff = i < G ? D : (i >= D - G ? -D : 0);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int j = k + HL;
@@ -338,8 +341,7 @@ VA_HD void tile3_rows(const Dims &dm, const ProblemPtrs &pp, const Tile3 &t, T3R
         if (EDGE && t.r0 + k >= N) { direct = 0.0; s = 0.0; }
         rg.direct[k] = direct; rg.sown[k] = s; rg.xown[k] = xo[j];
         sc0[k * DP] = s;
-        if (i < G) sc0[k * DP + D] = s;             // ghost copies for the cyclic neighbours
-        if (i >= D - G) sc0[k * DP - D] = s;
+        sc0[k * DP + goff] = s;
     }
 }
 
@@ -369,8 +371,7 @@ VA_HD void tile3_grad(const Dims &dm, const Tile3 &t, const T3Regs<K> &rg, Threa
         if (!EDGE || t.r0 + k < dm.N) gout[k * D] = g; else g = 0.0;
         acc.v[EP_GTD] += g * rg.dval[k];
         acc.v[EP_GN2] += g * g;
-        const double ag = fabs(g);
-        gmax = ag > gmax ? ag : gmax;               // compare-select: fmax() would canonicalise twice
+        gmax = __builtin_fmax(gmax, __builtin_fabs(g));      // one v_max_f64 with |g| as a source modifier
     }
     acc.v[EP_GMAX] = gmax;
 }
