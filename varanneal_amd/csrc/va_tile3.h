@@ -320,8 +320,8 @@ VA_HD void tile3_rows(const Dims &dm, const ProblemPtrs &pp, const Tile3 &t, T3R
     }
     // direct_m, s_m (same linear combinations as disc_direct_s, on registers); s with ghosts
     double *sc0 = t.ss + t.ty * (K * DP + P) + G + i;
-    // ghost copy for the cyclic neighbours, branch-free: the first G columns also write D to the
-    // right, the last G columns D to the left, every other lane rewrites its own slot (D >= 2G)
+    // ghost copies for the cyclic neighbours: the first G columns also write D to the right,
+    // the last G columns D to the left (D >= 2G, so a lane is in at most one of the two sets)
     const int goff = i < G ? D : (i >= D - G ? -D : 0);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -341,7 +341,10 @@ VA_HD void tile3_rows(const Dims &dm, const ProblemPtrs &pp, const Tile3 &t, T3R
         if (EDGE && t.r0 + k >= N) { direct = 0.0; s = 0.0; }
         rg.direct[k] = direct; rg.sown[k] = s; rg.xown[k] = xo[j];
         sc0[k * DP] = s;
-        sc0[k * DP + goff] = s;
+    }
+    if (goff != 0) {                                 // one divergent region for all K ghost copies
+#pragma unroll
+        for (int k = 0; k < K; ++k) sc0[k * DP + goff] = rg.sown[k];
     }
 }
 
