@@ -277,14 +277,35 @@ int run_ladder(va_handle h, const double *rf_scale, int nbeta)
     long long max_cycles = bound > 4e18 ? (long long)4e18 : (long long)bound;
     long long cyc = 0;
     int poll = 4;
-    for (;;) {
-        for (int k = 0; k < poll; ++k) {
+    // Long ladders on small problems are bound by the host's launch rate (5+ launches per cycle at
+    // ~5 us each against ~25 us of device time): once the polling interval has grown to 64 cycles,
+    // that batch is captured ONCE into a hipGraph and replayed.  The kernels take the device image
+    // by value, so the graph is private to this call (ladder length, options).
+    static const bool no_graph = [] { const char *e = getenv("VA_NO_GRAPH"); return e && atoi(e) != 0; }();
+    hipGraphExec_t gexec = nullptr;
+    auto enqueue = [&](int n) {
+        for (int k = 0; k < n; ++k) {
             run_eval(h);
             launch_ls(dv, h->stream);
             launch_update(dv, h->stream);
             launch_coeffs(dv, h->stream);
             launch_direction(dv, h->stream);
         }
+    };
+    struct GraphGuard { hipGraphExec_t &g; ~GraphGuard() { if (g) (void)hipGraphExecDestroy(g); } } guard{gexec};
+    for (;;) {
+        if (poll == 64 && !no_graph) {
+            if (!gexec) {
+                hipGraph_t g = nullptr;
+                HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+                enqueue(poll);
+                HIPCHK(hipStreamEndCapture(h->stream, &g));
+                const hipError_t e = hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (e != hipSuccess) return fail(VA_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+            }
+            HIPCHK(hipGraphLaunch(gexec, h->stream));
+        } else enqueue(poll);
         cyc += poll;
         HIPCHK(hipMemcpyAsync(h->h_nactive, dv.n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(h->h_nactive + 2, dv.n_evals, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
