@@ -154,7 +154,10 @@ __global__ __launch_bounds__(NTMAX) void k_eval3(const Dev dv)
     T3Regs<K> rg;
     ThreadAcc acc;
     acc.clear();
-    if (active) tile3_obs<K>(dm, dv.pp, t, rg);
+    // observations / own d entries: early (under the staging latency) when registers allow it;
+    // the 1024-thread variants are capped at 128 VGPRs and would spill them across phase B
+    constexpr bool EARLY_OBS = NTMAX <= 256;
+    if (EARLY_OBS && active) tile3_obs<K>(dm, dv.pp, t, rg);
     // phase A step 2: (+ d for a line-search point) -> LDS incl. ghost columns
     if (evenD) {
         if (edge) {
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(NTMAX) void k_eval3(const Dev dv)
     }
     __syncthreads();
     if (tl && threadIdx.x == 0) tl[2] = wall_clock64();
+    if (!EARLY_OBS && active) tile3_obs<K>(dm, dv.pp, t, rg);
     if (active) {
         if (edge) tile3_grad<RHS, DISC, K, true, DC>(dm, t, rg, acc);
         else tile3_grad<RHS, DISC, K, false, DC>(dm, t, rg, acc);
