@@ -96,3 +96,51 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "va_oracle" not in txt and "cpu_emul" not in txt.replace("tests/cpu_emul", ""), f
+
+
+def test_nnet_validation_without_gpu(capi):
+    """va_nnet_problem_create checks its descriptor before it touches a device."""
+    import numpy as np
+    lib = capi.lib()
+    h = C.c_void_p()
+    st = [3, 4, 2]
+    NP = 3 * 4 + 4 + 4 * 2 + 2
+
+    def desc(**kw):
+        args = dict(batch=1, structure=st, data_in=np.zeros((2, 3)), data_out=np.zeros((2, 2)),
+                    Lidx=[np.arange(3), np.arange(2)], RM=1.0, RF0=0.1, P=np.zeros(NP), Pidx=[0, 1])
+        args.update(kw)
+        return capi.make_nnet_desc(**args)
+    d, keep = desc()
+    d.struct_size = 8
+    assert lib.va_nnet_problem_create(C.byref(d), C.byref(h)) == -1 and b"struct_size" in lib.va_last_error()
+    d, keep = desc(P=np.zeros(NP + 1))
+    assert lib.va_nnet_problem_create(C.byref(d), C.byref(h)) == -1 and b"weights and biases" in lib.va_last_error()
+    d, keep = desc(Pidx=[0, 0])
+    assert lib.va_nnet_problem_create(C.byref(d), C.byref(h)) == -1 and b"twice" in lib.va_last_error()
+    d, keep = desc(Pidx=[NP])
+    assert lib.va_nnet_problem_create(C.byref(d), C.byref(h)) == -1
+    d, keep = desc(Lidx=[np.array([0, 1, 5]), np.arange(2)])
+    assert lib.va_nnet_problem_create(C.byref(d), C.byref(h)) == -1 and b"input layer" in lib.va_last_error()
+    d, keep = desc()
+    d.activation = 17
+    assert lib.va_nnet_problem_create(C.byref(d), C.byref(h)) == -4          # VA_EUNSUPPORTED
+    with pytest.raises(NotImplementedError):
+        desc(RM=np.eye(3))
+    with pytest.raises(NotImplementedError):
+        desc(act="sine")
+    with pytest.raises(ValueError):
+        desc(data_in=np.zeros((2, 2)))
+
+
+def test_time_dependent_validation_without_gpu(capi):
+    import numpy as np
+    lib = capi.lib()
+    h = C.c_void_p()
+    N, D = 6, 5
+    d, keep = capi.make_desc(1, D, N, np.zeros((N, 2)), [0, 1], 0.1, 1.0, 1.0, np.ones((1, N, 1)), [0], disc="euler",
+                             p_time_dependent=True)
+    assert lib.va_problem_create(C.byref(d), C.byref(h)) == -4 and b"trapezoid and SimpsonHermite" in lib.va_last_error()
+    with pytest.raises(ValueError):
+        capi.make_desc(1, D, N, np.zeros((N, 2)), [0, 1], 0.1, 1.0, 1.0, np.ones((1, N - 1, 1)), [0],
+                       p_time_dependent=True)

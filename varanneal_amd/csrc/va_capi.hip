@@ -133,8 +133,8 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, bool user_rhs)
         if (dm.NT > 256 && K > 6) K = 6;                  // 1024-thread groups: 128-VGPR budget
         for (;;) {                                        // shrink until the staging arrays fit in LDS
             const size_t elems = (size_t)tile3_stage_elems(K, D, 2, dm.RY, HLR) + tile3_s_elems(K, D, 2, dm.RY);
-            if (sizeof(double) * elems <= (D <= 64 ? 60 : 78) * 1024 || K == 4) break;   // 2 groups/CU at 1024 threads
-            K -= 2;
+            if (sizeof(double) * elems <= (D <= 64 ? 60 : 78) * 1024 || K <= 4) break;   // 2 groups/CU at 1024 threads
+            K -= (sh || K == 5) ? (K == 5 ? 1 : 2) : 1;  // Simpson-Hermite keeps K even; never below 4
         }
         dm.maxr = K; dm.T = dm.RY * K;
         dm.ntiles = (N + dm.T - 1) / dm.T;
