@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NTMAX) void k_eval3(const Dev dv)
     ThreadAcc acc;
     acc.clear();
     // observations / own d entries: early (under the staging latency) when registers allow it;
-    // the 1024-thread variants are capped at 128 VGPRs and would spill them across phase B
+    // the 512/1024-thread variants need their groups at <= 128 VGPRs and would spill them across phase B
     constexpr bool EARLY_OBS = NTMAX <= 256;
     if (EARLY_OBS && active) tile3_obs<K>(dm, dv.pp, t, rg);
     // phase A step 2: (+ d for a line-search point) -> LDS incl. ghost columns
@@ -255,14 +255,15 @@ static void launch_eval3_rhs(const Dev &dv, hipStream_t s)
 }
 
 // D fixed at compile time for the state sizes of the Lorenz-96 configurations the reference
-// and BASELINE.json name (D = 20: examples/Lorenz96_D20; D = 200: BASELINE config 4); any
+// and BASELINE.json name (D = 20: examples/Lorenz96_D20; D = 200: BASELINE config 4, 512-thread groups); any
 // other D runs the same kernel with D in a register.
 template <class RHS, int K>
 static void launch_eval3_d(const Dev &dv, hipStream_t s)
 {
     if (dv.dm.D == 20) launch_eval3_rhs<RHS, K, 20, 256>(dv, s);
-    else if (dv.dm.D == 200) launch_eval3_rhs<RHS, K, 200, 1024>(dv, s);
+    else if (dv.dm.D == 200) launch_eval3_rhs<RHS, K, 200, 512>(dv, s);
     else if (dv.dm.D <= 64) launch_eval3_rhs<RHS, K, 0, 256>(dv, s);
+    else if (dv.dm.D <= 256) launch_eval3_rhs<RHS, K, 0, 512>(dv, s);
     else launch_eval3_rhs<RHS, K, 0, 1024>(dv, s);
 }
 

@@ -60,10 +60,12 @@ struct Tile3 {
     double p[RHS_MAX_NP];
 };
 
-// workgroup geometry: RY lanes per state column; 256-thread groups up to D = 64, 1024-thread
-// groups (5 lanes per column at D = 200) beyond, so that a lane's run stays >= 4 rows and the
-// tile's halo rows stay a small fraction of the staged rows
-VA_HD constexpr int tile3_ntmax(int D) { return D <= 64 ? 256 : 1024; }
+// workgroup geometry: RY lanes per state column.  256-thread groups up to D = 64 (12 lanes per
+// column at D = 20); 512-thread groups up to D = 256 (2 lanes per column at D = 200: two such
+// groups fit a CU at up to 128 VGPRs, so their phases overlap -- a 1024-thread group is alone
+// on its CU above 64 VGPRs; measured at C4: 329 us against 378 us); 1024-thread groups beyond,
+// so that a column still gets at least 2 lanes
+VA_HD constexpr int tile3_ntmax(int D) { return D <= 64 ? 256 : (D <= 256 ? 512 : 1024); }
 VA_HD constexpr int tile3_RY(int D) { return tile3_ntmax(D) / D > 0 ? tile3_ntmax(D) / D : 1; }
 VA_HD constexpr int tile3_threads(int D) { return ((D * tile3_RY(D) + 63) / 64) * 64; }
 
