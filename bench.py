@@ -193,6 +193,20 @@ def ladder_mode(args, pb0, XP, P, D, N, B, Y, Lidx, device):
                       "A_final_median": float(np.median(r["A"][:, -1])),
                       "k_final_median": float(np.median(r["pest"][:, -1, 0])),
                       "status_counts": np.bincount(r["status"].ravel(), minlength=3).tolist()}), flush=True)
+    if not args.no_cpu:
+        # the same ladder for ONE of these seeds by the C oracle (vao_anneal: restated L-BFGS-B +
+        # fused forward/adjoint) on one host core -- the reference's execution model
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import va_oracle
+        opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[0], [0], disc="trapezoid")
+        t0 = time.perf_counter()
+        ro = opb.anneal(XP[0], 1.5, np.arange(nb), opts)
+        dtc = time.perf_counter() - t0
+        print(json.dumps({"mode": "ladder_cpu_baseline", "kind": "port", "cores": 1, "seeds": 1,
+                          "seconds": dtc, "seed_evals": int(ro["nfev"].sum()),
+                          "seed_evals_per_s": int(ro["nfev"].sum()) / dtc,
+                          "A_final": float(ro["A"][-1]), "device_A_final_seed0": float(r["A"][0, -1]),
+                          "device_seconds_per_seed": dt / B}), flush=True)
     pb.close()
 
 
