@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VA_ABI_VERSION 4
+#define VA_ABI_VERSION 5
 
 enum { VA_OK = 0, VA_EINVAL = -1, VA_ENOMEM = -2, VA_EHIP = -3, VA_EUNSUPPORTED = -4,
        VA_ESTATE = -5 };
@@ -64,7 +64,8 @@ typedef struct va_problem_desc {
     const int32_t *Lidx;      /* [L]                                                 */
     const double *Y;          /* [N_data*L] observations, shared by all seeds        */
     double dt_model;
-    int32_t rm_kind;          /* 0: scalar rm;  1: rm_array [N_data*L] (va_ode.py:147-148) */
+    int32_t rm_kind;          /* 0: scalar rm;  1: rm_array [N_data*L] (va_ode.py:147-148);
+                               * 2: rm_array [N_data*L*L], full precision matrices (va_ode.py:149-152) */
     double rm;
     const double *rm_array;
     int32_t rf_kind;          /* 0: scalar rf0; 1: rf0_array [(N_model-1)*D] (va_ode.py:203-209) */

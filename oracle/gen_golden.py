@@ -278,6 +278,40 @@ def tdp_cases(va):
     return out
 
 
+def rmfull_cases(va):
+    """g9_*: full measurement precision matrices, RM of shape (L, L) (resized over time,
+    va_ode.py:617-618) and (N_data, L, L) (va_ode.py:149-152).  Deliberately not symmetric: the
+    reference contracts diff . (RM . diff) whatever RM is."""
+    from varanneal_amd import twin
+    out = {}
+    D, Lidx = 10, [0, 3, 5, 8]
+    L = len(Lidx)
+
+    def l96(t, x, k):
+        return np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - x + k
+    for disc, N, timedep in (("trapezoid", 30, False), ("SimpsonHermite", 31, True), ("euler", 12, True)):
+        t, Y, _, _ = twin.make_twin(D, N, Lidx=Lidx)
+        rng = np.random.RandomState(7000 + N)
+        base = 4.0 * np.eye(L) + 0.8 * rng.randn(L, L)
+        RM = np.array([base + 0.3 * rng.randn(L, L) for _ in range(N)]) if timedep else base
+        X0 = 20.0 * rng.rand(N, D) - 10.0
+        P0 = np.array([6.0 + 4.0 * rng.rand()])
+        a = va.Annealer()
+        a.set_model(l96, D)
+        a.set_data(Y, t=t)
+        with quiet():
+            a.anneal_init(X0, P0, 1.0, np.array([0]), RM, 0.37, Lidx, [0], dt_model=None, init_to_data=False,
+                          disc=disc, method='L-BFGS-B', opt_args=None, adolcID=0)
+        XP = np.array(a.minpaths[0])
+        A = float(a.A(XP)); me = float(a.me_gaussian(XP[:N * D])); fe = float(a.fe_gaussian(XP))
+        grad = _refload.complex_step_grad(a.A, XP)
+        name = "g9_rmfull_%s_%s" % (disc, "time" if timedep else "const")
+        out[name] = dict(XP=XP, Y=Y, t=t, D=D, N_model=N, Lidx=np.array(Lidx), dt_model=twin.DT, disc=disc, RM=RM,
+                         RF0=0.37, A=A, me=me, fe=fe, grad=grad)
+        print("%-34s A=%.16e me=%.3e fe=%.3e |g|max=%.3e" % (name, A, me, fe, np.abs(grad).max()))
+    return out
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     va = _refload.load_reference("va_ode")
@@ -313,6 +347,12 @@ def main():
         for k, v in rec.items():
             flat["%s/%s" % (cname, k)] = v
     np.savez_compressed(os.path.join(GOLD, "tdp.npz"), **flat)
+
+    flat = {}
+    for cname, rec in rmfull_cases(va).items():
+        for k, v in rec.items():
+            flat["%s/%s" % (cname, k)] = v
+    np.savez_compressed(os.path.join(GOLD, "rmfull.npz"), **flat)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 

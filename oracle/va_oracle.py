@@ -215,7 +215,10 @@ def numpy_action_generic(f, XP, D, N, Y, Lidx, dt, RM, RF, NP, Pidx, P, disc, t_
         p[list(Pidx)] = XP[N * D:]
     t = np.zeros(N) if t_model is None else np.asarray(t_model)
     diff = x[::nskip, list(Lidx)] - Y
-    me = (np.sum(RM * diff * diff) if isinstance(RM, np.ndarray) else RM * np.sum(diff * diff)) / (len(Lidx) * Y.shape[0])
+    if isinstance(RM, np.ndarray) and RM.ndim == 3:              # full matrices (va_ode.py:149-152)
+        me = sum(np.dot(diff[i], np.dot(RM[i], diff[i])) for i in range(Y.shape[0])) / (len(Lidx) * Y.shape[0])
+    else:
+        me = (np.sum(RM * diff * diff) if isinstance(RM, np.ndarray) else RM * np.sum(diff * diff)) / (len(Lidx) * Y.shape[0])
     pp = (lambda sl: p[sl]) if tdp else (lambda sl: p)            # f sees the rows' own parameters
     arg = pp if stim is None else (lambda sl: (pp(sl), stim[sl]))
     arr = isinstance(RF, np.ndarray)

@@ -24,7 +24,7 @@ namespace {
 struct Emul {
     Dims dm;
     ProblemPtrs pp;
-    std::vector<int> lmap, pidx;
+    std::vector<int> lmap, pidx, lidx;
     std::vector<double> Y, rm, rf0, P, tm, stim;
     int rhs;
 };
@@ -63,19 +63,21 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     E.lmap.assign(m.D, -1);
     for (int l = 0; l < m.L; ++l) E.lmap[d->Lidx[l]] = l;
     E.Y.assign(d->Y, d->Y + (size_t)m.N_data * m.L);
-    if (d->rm_kind) E.rm.assign(d->rm_array, d->rm_array + (size_t)m.N_data * m.L);
+    if (d->rm_kind) E.rm.assign(d->rm_array, d->rm_array + (size_t)m.N_data * m.L * (d->rm_kind == 2 ? m.L : 1));
+    E.lidx.assign(d->Lidx, d->Lidx + m.L);
     if (d->rf_kind) E.rf0.assign(d->rf0_array, d->rf0_array + (size_t)(m.N - 1) * m.D);
     E.pidx.assign(d->Pidx, d->Pidx + m.NPe);
     E.P.assign(d->P, d->P + (size_t)m.B * (m.tdp ? (size_t)m.N * m.NPt : (size_t)m.NPt));
     E.pp.lmap = E.lmap.data(); E.pp.Y = E.Y.data();
-    E.pp.rm_arr = d->rm_kind ? E.rm.data() : nullptr;
+    E.pp.rm_arr = d->rm_kind == 1 ? E.rm.data() : nullptr;
+    E.pp.rm_full = d->rm_kind == 2 ? E.rm.data() : nullptr; E.pp.Lidx = E.lidx.data();
     E.pp.rf0_arr = d->rf_kind ? E.rf0.data() : nullptr;
     E.pp.Pidx = E.pidx.data(); E.pp.Pfull = E.P.data();
     if (d->t_model) E.tm.assign(d->t_model, d->t_model + m.N);
     if (d->n_stim > 0) E.stim.assign(d->stim, d->stim + (size_t)m.N * d->n_stim);
     E.pp.tmodel = d->t_model ? E.tm.data() : nullptr;
     E.pp.stim = d->n_stim > 0 ? E.stim.data() : nullptr; E.pp.nstim = d->n_stim;
-    if (d->rhs >= VA_RHS_USER_BASE || m.tdp) m.emode = 1;
+    if (d->rhs >= VA_RHS_USER_BASE || m.tdp || d->rm_kind == 2) m.emode = 1;
     E.rhs = d->rhs;
     if (m.disc == DISC_SH && (m.N % 2) == 0) return VA_EINVAL;
     return VA_OK;

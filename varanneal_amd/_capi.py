@@ -105,10 +105,10 @@ def make_desc(batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, disc="trap
     d.dt_model = float(dt_model)
     if isinstance(RM, np.ndarray):
         rm = _f64(RM)
-        if rm.shape != (N_data, L):
-            raise ValueError("RM array must have shape (N_data, L)")
+        if rm.shape not in [(N_data, L), (N_data, L, L)]:
+            raise ValueError("RM array must have shape (N_data, L) or (N_data, L, L)")
         keep.append(rm)
-        d.rm_kind, d.rm, d.rm_array = 1, 0.0, rm.ctypes.data_as(c_dp)
+        d.rm_kind, d.rm, d.rm_array = rm.ndim - 1, 0.0, rm.ctypes.data_as(c_dp)
     else:
         d.rm_kind, d.rm, d.rm_array = 0, float(RM), None
     if isinstance(RF0, np.ndarray):

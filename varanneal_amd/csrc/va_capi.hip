@@ -93,7 +93,7 @@ void run_eval(va_handle h)
 // Tile geometry of the eval kernel: which mapping, rows per workgroup, threads.
 void pick_eval_geometry(const va_problem_desc *d, Dims &dm, bool user_rhs)
 {
-    user_rhs = user_rhs || d->p_time_dependent;          // per-row parameters: flat kernel only
+    user_rhs = user_rhs || d->p_time_dependent || d->rm_kind == 2;   // per-row parameters / full RM: flat kernel only
     const int D = d->D, N = d->N_model;
     const bool sh = d->disc == VA_DISC_SIMPSON_HERMITE;
     const int HLR = sh ? 3 : 2;
@@ -465,7 +465,11 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     const size_t np_seed = tdp ? (size_t)dm.N * dm.NPt : (size_t)dm.NPt;       // parameters stored per seed
     TRY(h->alloc(&pidx_d, dm.NPe));
     TRY(h->alloc(&P_d, B * np_seed));
-    if (d->rm_kind) TRY(h->alloc(&rm_d, (size_t)dm.N_data * dm.L));
+    if (d->rm_kind < 0 || d->rm_kind > 2) { va_problem_destroy(h); return fail(VA_EINVAL, "rm_kind %d", d->rm_kind); }
+    const size_t rm_elems = (size_t)dm.N_data * dm.L * (d->rm_kind == 2 ? dm.L : 1);
+    int *lidx_d = nullptr;
+    if (d->rm_kind) TRY(h->alloc(&rm_d, rm_elems));
+    if (d->rm_kind == 2) TRY(h->alloc(&lidx_d, dm.L));
     if (d->rf_kind) TRY(h->alloc(&rf_d, (size_t)(dm.N - 1) * dm.D));
     if (d->t_model) TRY(h->alloc(&t_d, (size_t)dm.N));
     if (d->n_stim > 0) TRY(h->alloc(&st_d, (size_t)dm.N * d->n_stim));
@@ -479,11 +483,14 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     H2D(Y_d, d->Y, (size_t)dm.N_data * dm.L, double);
     if (dm.NPe) H2D(pidx_d, d->Pidx, dm.NPe, int);
     H2D(P_d, d->P, B * np_seed, double);
-    if (d->rm_kind) H2D(rm_d, d->rm_array, (size_t)dm.N_data * dm.L, double);
+    if (d->rm_kind) H2D(rm_d, d->rm_array, rm_elems, double);
+    if (d->rm_kind == 2) H2D(lidx_d, d->Lidx, dm.L, int);
     if (d->rf_kind) H2D(rf_d, d->rf0_array, (size_t)(dm.N - 1) * dm.D, double);
     if (d->t_model) H2D(t_d, d->t_model, (size_t)dm.N, double);
     if (d->n_stim > 0) H2D(st_d, d->stim, (size_t)dm.N * d->n_stim, double);
-    dv.pp.lmap = lmap_d; dv.pp.Y = Y_d; dv.pp.rm_arr = rm_d; dv.pp.rf0_arr = rf_d;
+    dv.pp.lmap = lmap_d; dv.pp.Y = Y_d; dv.pp.rf0_arr = rf_d;
+    dv.pp.rm_arr = d->rm_kind == 1 ? rm_d : nullptr;
+    dv.pp.rm_full = d->rm_kind == 2 ? rm_d : nullptr; dv.pp.Lidx = lidx_d;
     dv.pp.Pidx = pidx_d; dv.pp.Pfull = P_d;
     dv.pp.tmodel = t_d; dv.pp.stim = st_d; dv.pp.nstim = d->n_stim;
 

@@ -74,6 +74,8 @@ struct ProblemPtrs {
     const double *tmodel;  // NULL or [N]: model times, for non-autonomous right-hand sides
     const double *stim;    // NULL or [N*nstim]: external stimulus rows (va_ode.py:345-354)
     int nstim;
+    const int *Lidx;       // [L] observed state columns (full-RM problems only)
+    const double *rm_full; // NULL or [N_data*L*L]: full measurement precision matrices (va_ode.py:149-152)
 };
 
 struct LsState {
@@ -349,9 +351,23 @@ VA_HD void tile_g(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &
             if (l >= 0 && (m % dm.nskip) == 0) {
                 const int nd = m / dm.nskip;
                 const double diff = xr[j] - pp.Y[(size_t)nd * dm.L + l];
-                const double w = pp.rm_arr ? pp.rm_arr[(size_t)nd * dm.L + l] : dm.rm;
-                acc.v[EP_ME] += w * diff * diff;
-                g += 2.0 * dm.cme * w * diff;
+                if (pp.rm_full) {
+                    // diff^T RM_n diff (va_ode.py:149-152): this element's share is its own row of the
+                    // quadratic form; its derivative picks up row and column l of RM_n (not assumed symmetric)
+                    const double *R = pp.rm_full + (size_t)nd * dm.L * dm.L;
+                    double row = 0.0, sym = 0.0;
+                    for (int k = 0; k < dm.L; ++k) {
+                        const double dk = xr[pp.Lidx[k]] - pp.Y[(size_t)nd * dm.L + k];
+                        row += R[l * dm.L + k] * dk;
+                        sym += (R[l * dm.L + k] + R[k * dm.L + l]) * dk;
+                    }
+                    acc.v[EP_ME] += diff * row;
+                    g += dm.cme * sym;
+                } else {
+                    const double w = pp.rm_arr ? pp.rm_arr[(size_t)nd * dm.L + l] : dm.rm;
+                    acc.v[EP_ME] += w * diff * diff;
+                    g += 2.0 * dm.cme * w * diff;
+                }
             }
             const long gi = (long)m * D + j;
             c.gtg[gi] = g;

@@ -33,8 +33,10 @@ va_ode.py:170-188, 565-570) are supported for the discretisations that work upst
 Here any subset Pidx may be estimated and bounds work (upstream's anneal_step and bounds
 branches for this case are broken, va_ode.py:597-601, 715-732).  A batch uses P0 (B, N_model, NP).
 
-Not implemented (raise NotImplementedError): full (L,L)/(D,D) RM/RF matrices (va_ode.py:149-152,
-211-222), user-defined action callables, method='LM'.
+Full measurement precision matrices (`RM` of shape (L,L) or (N_data,L,L), va_ode.py:149-152) are
+supported (flat tile kernel).  Not implemented (raise NotImplementedError): full (D,D) RF matrices
+(the upstream branch is wrong: va_ode.py:222 contracts `diff` where `diff[i]` is meant),
+user-defined action callables, method='LM'.
 """
 from __future__ import print_function
 
@@ -217,8 +219,10 @@ class Annealer(HIPmin):
                 self.RM = np.resize(RM, (self.N_data, self.L))
             elif RM.shape == (self.N_data, self.L):
                 self.RM = RM
-            elif RM.shape in [(self.L, self.L), (self.N_data, self.L, self.L)]:
-                raise NotImplementedError("full RM matrices (va_ode.py:149-152)")
+            elif RM.shape == (self.L, self.L):
+                self.RM = np.resize(RM, (self.N_data, self.L, self.L))      # va_ode.py:617-618
+            elif RM.shape == (self.N_data, self.L, self.L):
+                self.RM = RM
             else:
                 raise ValueError("ERROR: RM has an invalid shape.")
         else:
