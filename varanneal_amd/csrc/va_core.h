@@ -53,8 +53,8 @@ struct Dims {
     int emode, RY, NT, maxr;   // eval kernel: 1 = flat-mapped, 2 = column-mapped (va_tile2.h), 3 = column-run (va_tile3.h)
     int nprow;                 // eval partial rows per seed (ntiles, or ntiles*4 when every wave writes its own)
     unsigned long long obsmask; // bit i set <=> state column i is observed (valid when D <= 64)
-    int dbg;                   // ablation bits for profiling builds (env VA_DEBUG_EVAL; 0 in production):
-                               // 1 = no gradient stores, 2 = copy only (skip phases B/C), 4 = no staging loads
+    int dbg;                   // profiling builds only (env VA_DEBUG_EVAL; 0 in production): 2 = copy only (skip
+                               // phases B/C), 8 = return right after dispatch, 16 = per-workgroup timeline into upp
     // time-dependent parameters (va_ode.py:170-188): P is (N, NPt) per seed and the vector is
     // [X (N*D) | p_est (N*NPe), time-major].  Then ND = N*D + N*NPe and NP = NPest = 0 for the
     // L-BFGS kernels (one flat run), and the flat tile kernel uses NPt / NPe.  Static: tdp = 0,
