@@ -7,8 +7,8 @@ on MI355X, against the HBM roofline, with the CPU oracle timed beside it.
 A "step" is ONE batched evaluation (one k_eval launch): the action A(X,p) and its
 full gradient for all B resident seeds.  Paths are resident in HBM before the
 timed region.  N>1: one process per GPU (torch.distributed over RCCL), B seeds per
-GPU (weak scaling), no data-path collective; one all_gather of the per-seed actions
-closes the timed region.
+GPU (weak scaling), no data-path collective; the job's one all_gather of the per-seed
+actions is issued after the K timed steps and timed separately (config.final_gather_ms).
 
 Workloads (BASELINE.json configs):
   c3 (default)  Lorenz-96 D=20,  N=1000, L=7,  B=64 seeds per GPU, trapezoid
@@ -95,6 +95,34 @@ def cpu_baseline(D, N, Y, Lidx, XP, P, budget_s=10.0):
                       % (n, D, N, dt, os.cpu_count() or 0)}
 
 
+def timed_steps(pb, rf, steps, A, dist, world, torch, barrier):
+    """EXACTLY `steps` batched evaluations between two (barrier + synchronize) brackets; returns
+    (wall seconds, kernel ms by HIP events, gather ms), each the MAX over ranks.  The run's one
+    collective -- the RCCL all-gather of the per-seed actions that closes a multi-GPU job -- is
+    issued once after the timed steps and timed on its own: it is per job, not per step.  Its
+    buffers and the communicator are set up (and warmed) before the clock starts."""
+    recv = mine = None
+    if dist is not None:
+        mine = torch.from_numpy(np.ascontiguousarray(A)).cuda()
+        recv = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(recv, mine)          # warm-up: communicator, RCCL kernels
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = pb.eval_timed(rf, steps)                 # HIP events on the launch stream
+    barrier()
+    wall = time.perf_counter() - t0
+    gather_ms = 0.0
+    if dist is not None:
+        t1 = time.perf_counter()
+        dist.all_gather_into_tensor(recv, mine)          # the single RCCL gather of the job
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - t1) * 1e3
+        tmax = torch.tensor([wall, kernel_ms, gather_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall, kernel_ms, gather_ms = (float(v) for v in tmax)
+    return wall, kernel_ms, gather_ms
+
+
 def nnet_main(args, rank, local_rank, world, dist, torch):
     """C5: (A, grad A) of the feed-forward-network action; one step = one batched evaluation
     (k_nnet_pack, k_nnet_fwd, k_nnet_bwd_x, k_nnet_bwd_w, k_nnet_pred) of B seeds."""
@@ -118,19 +146,7 @@ def nnet_main(args, rank, local_rank, world, dist, torch):
             dist.barrier()
         torch.cuda.synchronize()
     pb.eval_timed(rf, max(args.warmup, 1))
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms = pb.eval_timed(rf, args.steps)
-    if dist is not None:
-        mine = torch.from_numpy(A).cuda()
-        allA = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allA, mine)
-    barrier()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall, kernel_ms = float(tmax[0]), float(tmax[1])
+    wall, kernel_ms, gather_ms = timed_steps(pb, rf, args.steps, A, dist, world, torch, barrier)
     if rank != 0:
         return
     # three products per layer transition: Z = X W^T, dX = delta W, dW = delta^T X
@@ -144,7 +160,8 @@ def nnet_main(args, rank, local_rank, world, dist, torch):
         "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic (sigmoid twin network, sigma=0.005, seeded)",
         "config": {"workload": w["name"], "seeds_per_gpu": B, "structure": [int(v) for v in s], "M": M,
-                   "n_var": int(XP.shape[1]), "parallelism": "seeds sharded, %d per GPU" % B},
+                   "n_var": int(XP.shape[1]), "parallelism": "seeds sharded, %d per GPU" % B,
+                   "final_gather_ms": gather_ms},
         "roofline": {"bound": "mfma", "achieved": flops / ks / 1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": flops / ks / 1e12 / F64_MFMA_PEAK_TFLOPS, "traffic": None,
                      "kernel": "k_nnet_fwd + k_nnet_bwd_x + k_nnet_bwd_w (+ pack, pred): one evaluation",
@@ -260,19 +277,7 @@ def main():
         torch.cuda.synchronize()
 
     pb.eval_timed(RF_SCALE, max(args.warmup, 1))
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms = pb.eval_timed(RF_SCALE, args.steps)      # HIP events on the launch stream
-    if dist is not None:                                 # the single RCCL gather of per-seed actions
-        mine = torch.from_numpy(A).cuda()
-        allA = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allA, mine)
-    barrier()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall, kernel_ms = float(tmax[0]), float(tmax[1])
+    wall, kernel_ms, gather_ms = timed_steps(pb, RF_SCALE, args.steps, A, dist, world, torch, barrier)
 
     if rank == 0:
         balg = bytes_alg(B, N, D, 1, N, len(Lidx))
@@ -286,7 +291,7 @@ def main():
             "data": "synthetic (Lorenz-96 twin experiment, k=8.17, sigma=0.5, seeded)",
             "config": {"workload": w["name"], "seeds_per_gpu": B, "D": D, "N": N, "L": len(Lidx),
                        "disc": "trapezoid", "tile_rows": info["tile_rows"], "ntiles": info["ntiles"],
-                       "parallelism": "seeds sharded, %d per GPU" % B},
+                       "parallelism": "seeds sharded, %d per GPU" % B, "final_gather_ms": gather_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(w["name"]),
                          "kernel": {3: "k_eval3<RhsL96g,trapezoid,K=%d>"
