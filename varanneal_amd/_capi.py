@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvaranneal_amd.so")
 
 VA_OK = 0
+ABI_VERSION = 5          # VA_ABI_VERSION of include/varanneal_amd.h
 ERRNAMES = {-1: "VA_EINVAL", -2: "VA_ENOMEM", -3: "VA_EHIP", -4: "VA_EUNSUPPORTED", -5: "VA_ESTATE"}
 DISC = {"euler": 0, "trapezoid": 1, "SimpsonHermite": 2, "forwardmap": 3}
 RHS = {"lorenz96": 0}
@@ -163,6 +164,9 @@ def lib():
         raise VaLibraryError("cannot load %s: %s" % (LIB_PATH, e))
     h = C.c_void_p
     L.va_abi_version.restype = C.c_int32
+    if L.va_abi_version() != ABI_VERSION:
+        raise VaLibraryError("%s has ABI version %d, this binding expects %d: rebuild it with "
+                             "`python -m varanneal_amd._build --force`" % (LIB_PATH, L.va_abi_version(), ABI_VERSION))
     L.va_last_error.restype = C.c_char_p
     L.va_device_count.argtypes = [c_ip]
     L.va_problem_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(h)]
