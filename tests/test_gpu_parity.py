@@ -301,3 +301,36 @@ def test_smallest_problems(capi, D, N, disc):
             x, Am, st, nit, nfev = opb.minimize_lbfgs(XP[b], 2.5, dict(OPTS, maxiter=5))
             assert (r["nit"][b], r["nfev"][b], r["status"][b]) == (nit, nfev, st), (ek, b)
             assert abs(r["A"][b] - Am) <= 1e-9 * abs(Am)
+
+
+def test_long_path_and_many_seeds(capi):
+    """sizes past the BASELINE configs: one 200,001-point path (4,000,021 unknowns per seed: index
+    arithmetic beyond 2^22 rows) and 4096 seeds of the C2 shape (8.2e7 unknowns resident)."""
+    import va_oracle
+    from varanneal_amd import twin
+    D, N, B = 20, 200001, 2
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    rng = np.random.RandomState(9)
+    XP = np.concatenate([3.0 * rng.randn(B, N * D), 6.0 + 4.0 * rng.rand(B, 1)], axis=1)
+    P = XP[:, -1:].copy()
+    pb = capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="SimpsonHermite")
+    A, me, fe, g = pb.action_grad(XP, 30.0)
+    opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[1], [0], disc="SimpsonHermite")
+    Ao, meo, feo, go = opb.action_grad(XP[1], 30.0)
+    assert abs(A[1] - Ao) <= RTOL_A * abs(Ao) and np.abs(g[1] - go).max() <= RTOL_G * np.abs(go).max()
+    r = pb.minimize_lbfgs(XP, 30.0, dict(OPTS, maxiter=3))
+    x, Am, st, nit, nfev = opb.minimize_lbfgs(XP[1], 30.0, dict(OPTS, maxiter=3))
+    assert (r["nit"][1], r["nfev"][1]) == (nit, nfev) and abs(r["A"][1] - Am) <= 1e-9 * abs(Am)
+    pb.close()
+
+    D, N, B = 20, 1000, 4096
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    XP = np.concatenate([3.0 * rng.randn(B, N * D), 6.0 + 4.0 * rng.rand(B, 1)], axis=1)
+    P = XP[:, -1:].copy()
+    pb = capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", lbfgs_m=3)
+    A, me, fe, g = pb.action_grad(XP, 1000.0)
+    for b in (0, 2047, 4095):
+        opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[b], [0], disc="trapezoid")
+        Ao, meo, feo, go = opb.action_grad(XP[b], 1000.0)
+        assert abs(A[b] - Ao) <= RTOL_A * abs(Ao) and np.abs(g[b] - go).max() <= RTOL_G * np.abs(go).max()
+    pb.close()
