@@ -9,7 +9,7 @@
 //     dA/dX_n     += delta W_n               (product 2)
 //     dA/dW_n      = delta^T X_n,  dA/db_n = sum_m delta        (product 3)
 // Three float64 products per layer, all on v_mfma_f64_16x16x4_f64:
-//   k_nnet_pack   trial point: Xw = x + stp d, Pw = fixed | x + stp d   (read once, not per tile)
+//   k_nnet_pack   trial point: Xw = x + stp d (line-search points only), Pw = fixed | x + stp d
 //   k_nnet_fwd    Z tile -> residual, delta, q              (writes delta, q into gt, fe partial)
 //   k_nnet_bwd_x  delta W + q + measurement term -> gt       (me, g.d, g.g, max|g| partials)
 //   k_nnet_bwd_w  delta^T X per chunk of examples -> gpart   (no atomics: fixed-order reduce in
@@ -170,9 +170,8 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_pack(const Dev dv, const Nn
     if (!seed_live(dv, b, use_d, stp, rf)) return;
     const size_t vo = (size_t)b * dv.dm.ld;
     if (i < nn.NDens) {
-        double v = dv.x[vo + i];
-        if (use_d) v = trial(v, stp, dv.d[vo + i]);
-        nn.Xw[vo + i] = v;
+        // at a plain evaluation point (no line-search step) the products read x itself
+        if (use_d) nn.Xw[vo + i] = trial(dv.x[vo + i], stp, dv.d[vo + i]);
     } else if (i < nn.NDens + nn.NP) {
         const int j = i - nn.NDens, k = nn.pmap[j];
         double v;
@@ -196,7 +195,8 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const Nne
     const int m0 = tl.r0, i0 = tl.c0;
     const int sn = tl.sn, sn1 = tl.sn1, K = sn;
     const size_t vo = (size_t)b * dv.dm.ld;
-    const double *X = nn.Xw + vo + (size_t)m0 * nn.NDnet + tl.offn;
+    const double *Xs = use_d ? nn.Xw : dv.x;                 // trial point, or x itself
+    const double *X = Xs + vo + (size_t)m0 * nn.NDnet + tl.offn;
     const double *W = nn.Pw + (size_t)b * nn.NP + tl.woff + (size_t)i0 * sn;
     const int nra = min(NN_TILE, nn.M - m0), nrb = min(NN_TILE, sn1 - i0);
     const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const Nne
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
-                xn1[bi][bj][r] = (i < sn1 && m < nn.M) ? nn.Xw[vo + (size_t)m * nn.NDnet + tl.offn1 + i] : 0.0;
+                xn1[bi][bj][r] = (i < sn1 && m < nn.M) ? Xs[vo + (size_t)m * nn.NDnet + tl.offn1 + i] : 0.0;
             }
     }
     for (int k0 = 0; k0 < K; k0 += NN_KC) {
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_x(const Dev dv, const N
                 const size_t idx = vo + (size_t)m * nn.NDnet + tl.offn + j;
                 double g = acc[bi][bj][r] + q0[bi][bj][r];
                 if (l >= 0) {
-                    const double diff = nn.Xw[idx] - dat[(size_t)m * L + l];
+                    const double diff = (use_d ? nn.Xw : dv.x)[idx] - dat[(size_t)m * L + l];
                     v[0] += rm * diff * diff;
                     g += 2.0 * dv.dm.cme * rm * diff;
                 }
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_w(const Dev dv, const N
     const int K = min(nn.mch, nn.M - mb);                       // examples in this chunk
     const size_t vo = (size_t)b * dv.dm.ld;
     const double *Dl = nn.delta + vo + (size_t)mb * nn.NDnet + tl.offn1 + i0;
-    const double *X = nn.Xw + vo + (size_t)mb * nn.NDnet + tl.offn + j0;
+    const double *X = (use_d ? nn.Xw : dv.x) + vo + (size_t)mb * nn.NDnet + tl.offn + j0;
     const int nra = min(NN_TILE, sn1 - i0), nrb = min(NN_TILE, sn - j0);
     const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int live = live_mask(wr, wc, nra, nrb);
