@@ -206,20 +206,6 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const Nne
     double va[NLD], vb[NLD];
     load_rk(X, nn.NDnet, nra, K, tid, va);
     load_rk(W, sn, nrb, K, tid, vb);
-    // epilogue operands (bias, x_{n+1}) are requested now so they arrive under the K loop
-    double bias[2], xn1[2][2][4];
-#pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
-        const int i = i0 + wc * 32 + bj * 16 + (lane & 15);
-        bias[bj] = (i < sn1) ? nn.Pw[(size_t)b * nn.NP + tl.boff + i] : 0.0;
-#pragma unroll
-        for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
-                xn1[bi][bj][r] = (i < sn1 && m < nn.M) ? Xs[vo + (size_t)m * nn.NDnet + tl.offn1 + i] : 0.0;
-            }
-    }
     for (int k0 = 0; k0 < K; k0 += NN_KC) {
         store_rk(As, tid, va); store_rk(Bs, tid, vb);
         __syncthreads();
@@ -237,6 +223,8 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const Nne
     for (int bj = 0; bj < 2; ++bj) {
         const int i = i0 + wc * 32 + bj * 16 + (lane & 15);
         if (i >= sn1) continue;
+        // (no early request of bias / x_{n+1}: 32 fewer live registers put a fourth workgroup on the CU)
+        const double bias = nn.Pw[(size_t)b * nn.NP + tl.boff + i];
 #pragma unroll
         for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
@@ -244,8 +232,8 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const Nne
                 const int m = m0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
                 if (m >= nn.M) continue;
                 const size_t idx = vo + (size_t)m * nn.NDnet + tl.offn1 + i;
-                const double a = act_f<ACT>(acc[bi][bj][r] + bias[bj]);
-                const double res = xn1[bi][bj][r] - a;
+                const double a = act_f<ACT>(acc[bi][bj][r] + bias);
+                const double res = Xs[idx] - a;
                 const double q = cq * res;
                 v[1] += res * res;
                 nn.delta[idx] = -q * act_d<ACT>(a);
