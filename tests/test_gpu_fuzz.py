@@ -1,0 +1,106 @@
+"""GPU: seeded random problem shapes through the C-ABI against the C oracle -- state sizes on
+both sides of every kernel-geometry switch (column-run 256/512/1024-thread groups, flat kernel),
+all discretisations, dt_model = dt_data / nskip, scalar and array RM / RF0, random observed
+subsets, 1-5 seeds; every case also takes a few device L-BFGS iterations step for step."""
+import numpy as np
+import pytest
+
+import va_oracle
+from varanneal_amd import _capi
+
+pytestmark = pytest.mark.gpu
+OPTS = {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000000, 'maxiter': 4}
+
+
+def _case(seed):
+    rng = np.random.RandomState(7000 + seed)
+    D = int(rng.choice([4, 5, 6, 9, 16, 20, 21, 33, 64, 65, 100, 128, 200, 255, 256, 257, 300, 511, 513, 700, 1200]))
+    disc = str(rng.choice(["euler", "trapezoid", "SimpsonHermite", "forwardmap"]))
+    nskip = int(rng.choice([1, 1, 2, 3]))
+    N_data = int(rng.randint(2, 90 if D > 128 else 220))
+    N = (N_data - 1) * nskip + 1
+    if disc == "SimpsonHermite" and N % 2 == 0:
+        N_data += 1
+        N = (N_data - 1) * nskip + 1
+        if N % 2 == 0:                       # nskip even keeps N odd; otherwise fall back
+            disc = "trapezoid"
+    L = int(rng.randint(1, min(D, 12) + 1))
+    Lidx = sorted(rng.choice(D, L, replace=False).tolist())
+    B = int(rng.randint(1, 6))
+    Y = rng.randn(N_data, L)
+    RM = 0.5 + rng.rand(N_data, L) if rng.rand() < 0.4 else float(1.0 + rng.rand())
+    RF0 = 0.2 + rng.rand(N - 1, D) if rng.rand() < 0.4 else float(0.1 + rng.rand())
+    XP = np.concatenate([2.0 * rng.randn(B, N * D), 6.0 + 3.0 * rng.rand(B, 1)], axis=1)
+    est = rng.rand() < 0.8
+    return dict(D=D, N=N, disc=disc, nskip=nskip, Lidx=Lidx, B=B, Y=Y, RM=RM, RF0=RF0, XP=XP, est=est,
+                rf=float(10.0 ** rng.uniform(-2, 2)))
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_problem(seed):
+    c = _case(seed)
+    D, N, B = c["D"], c["N"], c["B"]
+    Pidx = [0] if c["est"] else []
+    P = c["XP"][:, -1:].copy()
+    XP = c["XP"] if c["est"] else c["XP"][:, :-1].copy()
+    pb = _capi.Problem(B, D, N, c["Y"], c["Lidx"], 0.025, c["RM"], c["RF0"], P, Pidx, disc=c["disc"],
+                       merr_nskip=c["nskip"])
+    A, me, fe, g = pb.action_grad(XP, c["rf"])
+    r = pb.minimize_lbfgs(XP, c["rf"], OPTS)
+    info = pb.info()
+    pb.close()
+    for b in range(B):
+        opb = va_oracle.Problem(D, N, c["Y"], c["Lidx"], 0.025, c["RM"], c["RF0"], P[b], Pidx, disc=c["disc"],
+                                merr_nskip=c["nskip"])
+        Ao, meo, feo, go = opb.action_grad(XP[b], c["rf"])
+        tag = (seed, D, N, c["disc"], c["nskip"], info)
+        assert abs(A[b] - Ao) <= 1e-12 * abs(Ao) and abs(me[b] - meo) <= 1e-12 * abs(Ao), tag
+        assert np.abs(g[b] - go).max() <= 1e-10 * np.abs(go).max(), tag
+        x, Am, st, nit, nfev = opb.minimize_lbfgs(XP[b], c["rf"], OPTS)
+        assert (r["nit"][b], r["nfev"][b], r["status"][b]) == (nit, nfev, st), tag
+        assert abs(r["A"][b] - Am) <= 1e-8 * abs(Am), tag
+
+
+def test_too_wide_state_is_refused_cleanly():
+    """the flat kernel stages (T + halo) rows of 3 arrays in LDS: beyond ~1600 columns not even two
+    owned rows fit the CU's 160 KiB and the problem is refused with a message, not a fault"""
+    D, N = 4000, 5
+    rng = np.random.RandomState(0)
+    with pytest.raises(_capi.VaError) as e:
+        _capi.Problem(1, D, N, rng.randn(N, 2), [0, 7], 0.025, 1.0, 1.0, np.ones((1, 1)), [0])
+    assert e.value.code == -4 and "too wide" in str(e.value)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_network(seed):
+    """random layer structures (1-80 neurons, 2-6 layers), 1-90 examples, every activation, random
+    estimated-parameter subsets and observed neurons, scalar or [in, out] RM, 1-3 seeds: both
+    evaluators (single-kernel and tiled) against the NumPy oracle"""
+    import va_nnet_oracle as vno
+    rng = np.random.RandomState(9000 + seed)
+    nl = int(rng.randint(2, 7))
+    wmax = int(rng.choice([6, 20, 32, 33, 80]))
+    structure = [int(rng.randint(1, wmax + 1)) for _ in range(nl)]
+    M = int(rng.choice([1, 2, 7, 32, 33, 90]))
+    act = str(rng.choice(["sigmoid", "tanh", "linear", "relu", "softplus"]))
+    B = int(rng.randint(1, 4))
+    Lin = sorted(rng.choice(structure[0], rng.randint(1, structure[0] + 1), replace=False).tolist())
+    Lout = sorted(rng.choice(structure[-1], rng.randint(1, structure[-1] + 1), replace=False).tolist())
+    din, dout = rng.randn(M, len(Lin)), rng.rand(M, len(Lout))
+    NP = sum(structure[n + 1] * structure[n] + structure[n + 1] for n in range(nl - 1))
+    npest = int(rng.randint(0, NP + 1))
+    Pidx = sorted(rng.choice(NP, npest, replace=False).tolist())
+    RM = [1.0 + rng.rand(), 2.0 + rng.rand()] if rng.rand() < 0.5 else float(1.0 + rng.rand())
+    P = 0.4 * rng.randn(B, NP)
+    X = rng.rand(B, M * sum(structure))
+    XP = np.concatenate([X, P[:, Pidx]], axis=1)
+    pr = _capi.NnetProblem(B, structure, din, dout, [Lin, Lout], RM, 0.3, P, Pidx, act=act)
+    A, me, fe, g = pr.action_grad(XP, 2.0)
+    pr.close()
+    for b in range(B):
+        pb = vno.NnetProblem(structure, din, dout, [Lin, Lout], np.asarray(RM) if isinstance(RM, list) else RM, 0.3,
+                             P[b], Pidx, act=act)
+        A1, me1, fe1, g1 = pb.action_grad(XP[b], 2.0)
+        tag = (seed, structure, M, act, npest)
+        assert abs(A[b] - A1) <= 1e-12 * abs(A1) and abs(me[b] - me1) <= 1e-12 * abs(A1), tag
+        assert np.abs(g[b] - g1).max() <= 1e-10 * max(np.abs(g1).max(), 1e-300), tag

@@ -17,6 +17,7 @@
 #include "../../include/varanneal_amd.h"
 #include "va_device.h"
 #include "va_nnet.h"
+#include "va_eval_flat.h"
 
 using namespace va;
 
@@ -156,7 +157,9 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, bool user_rhs)
     } else {
         dm.RY = 0; dm.NT = EVAL_THREADS; dm.maxr = 0;
         // LDS: 3 staged arrays of (T+halo) rows; keep a workgroup under ~48 KiB so several fit a CU
+        // (wide states: whatever still gives two owned rows, up to the CU's 160 KiB)
         tmax = (int)((48 * 1024) / (3 * sizeof(double) * D)) - HLR;
+        if (tmax < 2) tmax = (int)((150 * 1024) / (3 * sizeof(double) * D)) - HLR;
         tmin = (EVAL_THREADS + D - 1) / D;               // >= one element per lane
     }
     if (tmax < 2) tmax = 2;
@@ -450,9 +453,16 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dv.ups = UP_OLD + 4 * m; dv.max_beta = max_beta; dv.nbeta = 1;
     dv.o.m = m; dv.o.maxiter = 15000; dv.o.maxls = 20; dv.o.maxfun = 15000; dv.o.ftol = 2.2204460492503131e-09; dv.o.gtol = 1e-5;
 
-    if (eval_lds_bytes(dm) > (dm.emode == 3 ? 160 : 64) * 1024) {
-        va_problem_destroy(h);
-        return fail(VA_EUNSUPPORTED, "tile of %d rows x D=%d needs %zu B of LDS (> 64 KiB); lower tile_rows", dm.T, dm.D, eval_lds_bytes(dm));
+    {
+        // the flat kernel keeps 3 staged arrays of (T + halo) rows: up to the CU's 160 KiB
+        const size_t need = dm.emode == 1 ? eval_flat_lds_bytes(dm) : eval_lds_bytes(dm);
+        const size_t cap = (dm.emode == 2 ? 64 : 160) * 1024;
+        if (need > cap) {
+            const int T = dm.T, D = dm.D;
+            va_problem_destroy(h);
+            return fail(VA_EUNSUPPORTED, "a tile of %d rows x D=%d needs %zu B of LDS (> %zu): state too wide for this kernel",
+                        T, D, need, cap);
+        }
     }
 
     int rc = VA_OK;

@@ -133,6 +133,16 @@ inline void launch_eval_rhs(const Dev &dv, hipStream_t s)
 {
     const dim3 grid(eval_flat_grid(dv.dm)), block(EVAL_THREADS);
     const size_t lds = eval_flat_lds_bytes(dv.dm);
+    if (lds > 64 * 1024) {                                   // wide states: opt in to the CU's full LDS
+        static bool done = false;                            // per RHS instantiation
+        if (!done) {
+            (void)hipFuncSetAttribute((const void *)k_eval<RHS, DISC_EULER>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_eval<RHS, DISC_TRAPEZOID>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_eval<RHS, DISC_SH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_eval<RHS, DISC_FWDMAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done = true;
+        }
+    }
     switch (dv.dm.disc) {
     case DISC_EULER: hipLaunchKernelGGL((k_eval<RHS, DISC_EULER>), grid, block, lds, s, dv); break;
     case DISC_TRAPEZOID: hipLaunchKernelGGL((k_eval<RHS, DISC_TRAPEZOID>), grid, block, lds, s, dv); break;
