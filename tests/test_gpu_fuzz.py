@@ -104,3 +104,47 @@ def test_random_network(seed):
         tag = (seed, structure, M, act, npest)
         assert abs(A[b] - A1) <= 1e-12 * abs(A1) and abs(me[b] - me1) <= 1e-12 * abs(A1), tag
         assert np.abs(g[b] - g1).max() <= 1e-10 * max(np.abs(g1).max(), 1e-300), tag
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_flat_kernel_features(seed):
+    """time-dependent parameters and/or full RM matrices (both flat-kernel features) on random
+    shapes: value against the NumPy restatement, gradient through complex-step directional
+    derivatives of that restatement along three random directions"""
+    from varanneal_amd import twin
+    rng = np.random.RandomState(11000 + seed)
+    D = int(rng.choice([4, 5, 12, 20, 37, 70]))
+    tdp = rng.rand() < 0.7
+    rmfull = (not tdp) or rng.rand() < 0.5
+    disc = str(rng.choice(["trapezoid", "SimpsonHermite"] if tdp else ["euler", "trapezoid", "SimpsonHermite", "forwardmap"]))
+    nskip = int(rng.choice([1, 1, 2]))
+    N_data = int(rng.randint(2, 70))
+    N = (N_data - 1) * nskip + 1
+    if disc == "SimpsonHermite" and N % 2 == 0:
+        disc = "trapezoid"
+    L = int(rng.randint(1, min(D, 6) + 1))
+    Lidx = sorted(rng.choice(D, L, replace=False).tolist())
+    Y = rng.randn(N_data, L)
+    if rmfull:
+        RM = np.array([2.0 * np.eye(L) + 0.5 * rng.randn(L, L) for _ in range(N_data)])
+    else:
+        RM = 0.5 + rng.rand(N_data, L) if rng.rand() < 0.5 else float(1.0 + rng.rand())
+    RF0 = 0.2 + rng.rand(N - 1, D) if rng.rand() < 0.5 else float(0.1 + rng.rand())
+    P = 6.0 + 3.0 * rng.rand(N, 1) if tdp else 6.0 + 3.0 * rng.rand(1)
+    X = 2.0 * rng.randn(N * D)
+    XP = np.append(X, P.ravel())
+    rf = float(10.0 ** rng.uniform(-1, 1))
+    RFs = RF0 * rf
+    fun = lambda z: va_oracle.numpy_action_generic(twin.l96, z, D, N, Y, Lidx, 0.025, RM, RFs, 1, [0], P, disc,
+                                                   nskip=nskip)
+    A0, me0, fe0 = fun(XP)
+    pb = _capi.Problem(1, D, N, Y, Lidx, 0.025, RM, RF0, P[None] if tdp else P[None, :], [0], disc=disc,
+                       merr_nskip=nskip, p_time_dependent=tdp)
+    A, me, fe, g = pb.action_grad(XP[None, :], rf)
+    pb.close()
+    tag = (seed, D, N, disc, nskip, tdp, rmfull)
+    assert abs(A[0] - A0) <= 1e-12 * abs(A0) and abs(me[0] - me0) <= 1e-12 * abs(A0), tag
+    for _ in range(3):
+        v = rng.randn(XP.size)
+        dd = np.imag(fun(XP + 1e-30j * v)[0]) / 1e-30
+        assert abs(np.dot(g[0], v) - dd) <= 1e-10 * (np.abs(g[0]) * np.abs(v)).sum(), tag
