@@ -198,3 +198,76 @@ def test_random_ladder(seed):
     x, Am, st, nit, nfev = opb.minimize_lbfgs(XP[b], 1.0, o10)
     assert (r2["nit"][0], r2["nfev"][0], r2["status"][0]) == (nit, nfev, st), tag
     assert abs(r2["A"][0] - Am) <= 1e-9 * abs(Am), tag
+
+
+def _random_model(seed):
+    """a smooth random right-hand side mixing the functions user models use (products, powers,
+    exp / tanh / sqrt / division), with NP parameters and optionally a stimulus"""
+    rng = np.random.RandomState(15000 + seed)
+    D = int(rng.randint(2, 7)); NP = int(rng.randint(1, 6)); stim = bool(rng.rand() < 0.5)
+    A = rng.randn(D, D) * 0.3
+    c = rng.randn(D) * 0.5
+    kinds = rng.randint(0, 5, size=D)
+    pk = rng.randint(0, NP, size=(D, 2))
+
+    def f(t, x, pin):
+        p, s = pin if stim else (pin, None)
+        out = np.zeros_like(x)
+        for i in range(D):
+            lin = sum(A[i, j] * x[:, j] for j in range(D))
+            pa, pb = p[pk[i, 0]], p[pk[i, 1]]
+            xi, xn = x[:, i], x[:, (i + 1) % D]
+            if kinds[i] == 0:
+                term = pa * xi * xn + c[i] * xi ** 3
+            elif kinds[i] == 1:
+                term = pa * np.tanh(xn / (1.0 + pb ** 2)) - xi
+            elif kinds[i] == 2:
+                term = np.exp(-0.1 * xi ** 2) * pa + pb * xn
+            elif kinds[i] == 3:
+                term = pa / (1.0 + xn ** 2) + np.sqrt(1.0 + xi ** 2) * pb
+            else:
+                term = pa * np.sin(0.3 * t) * xn - pb * xi
+            out[:, i] = lin + term + (s * c[i] if stim else 0.0)
+        return out
+    return f, D, NP, stim
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_generated_model(seed):
+    """codegen on random models (trace -> SymPy derivatives -> HIP module built on the spot):
+    value against the NumPy restatement with the ORIGINAL callable, gradient through complex-step
+    directional derivatives; static and time-dependent parameters"""
+    from varanneal_amd import codegen
+    f, D, NP, stim = _random_model(seed)
+    rng = np.random.RandomState(16000 + seed)
+    tdp = seed % 2 == 1
+    if tdp:                                       # time-dependent form: p[:, k]
+        g0 = f
+        f = lambda t, x, pin: g0(t, x, (tuple(pin[0].T), pin[1]) if stim else tuple(pin.T))
+    N = int(rng.choice([21, 41]))
+    disc = str(rng.choice(["trapezoid", "SimpsonHermite"]))
+    t = 0.05 * np.arange(N)
+    st = rng.randn(N) if stim else None
+    mod = codegen.module_for(f, D, NP, 1 if stim else 0, 1, p_rows=tdp)
+    rid = _capi.load_rhs_module(mod["so"])
+    L = int(rng.randint(1, D + 1))
+    Lidx = sorted(rng.choice(D, L, replace=False).tolist())
+    Y = rng.randn(N, L)
+    npe = int(rng.randint(1, NP + 1))
+    Pidx = sorted(rng.choice(NP, npe, replace=False).tolist())
+    P = 0.5 + rng.rand(N, NP) if tdp else 0.5 + rng.rand(NP)
+    X = 0.8 * rng.randn(N * D)
+    XP = np.append(X, (P[:, Pidx] if tdp else P[Pidx]).ravel())
+    fun = lambda z: va_oracle.numpy_action_generic(f, z, D, N, Y, Lidx, 0.05, 2.0, 0.7, NP, Pidx, P, disc, t_model=t,
+                                                   stim=st)
+    A0, me0, fe0 = fun(XP)
+    pb = _capi.Problem(1, D, N, Y, Lidx, 0.05, 2.0, 0.7, P[None] if tdp else P[None, :], Pidx, disc=disc, rhs=rid,
+                       t_model=t, stim=st, p_time_dependent=tdp)
+    A, me, fe, g = pb.action_grad(XP[None, :], 1.0)
+    pb.close()
+    tag = (seed, D, NP, stim, tdp, disc)
+    assert abs(A[0] - A0) <= 1e-12 * abs(A0), tag
+    for _ in range(3):
+        v = rng.randn(XP.size)
+        dd = np.imag(fun(XP + 1e-30j * v)[0]) / 1e-30
+        assert abs(np.dot(g[0], v) - dd) <= 1e-10 * (np.abs(g[0]) * np.abs(v)).sum(), tag
