@@ -1,19 +1,22 @@
 // va_kernels.hip -- gfx950 kernels of the variational-annealing hot path.
 //
-//   k_eval       (A, me, fe, grad A) of every live seed at x (or x + stp*d):
-//                one workgroup = one tile of T time rows of one seed; rows (+halo)
-//                staged in LDS; forward residuals and the hand-coded adjoint of the
-//                discretisation stencil in the same kernel; wave64 shuffle + LDS
-//                reductions to one partial row per tile (deterministic: no atomics).
+//   k_eval3      (A, me, fe, grad A) of every live seed at x (or x + stp*d), production kernel:
+//                one workgroup = T = RY*K time rows of one seed (RY lanes per state column, K rows
+//                per lane); rows (+halo, +ghost columns) staged in LDS; residuals, q, direct and s
+//                in registers; gradient = direct + J^T s + measurement term; DPP row reductions,
+//                one partial row per wave (deterministic: no atomics).
+//   k_eval2      row-strided column mapping (D <= 256), k_eval (va_eval_flat.h): flat mapping for
+//                any D and any right-hand side; generic fallbacks and independent cross-checks.
 //   k_ls         one wave per seed: reduce partials, More'-Thuente line-search step,
 //                L-BFGS-B stopping rules, beta-ladder bookkeeping (va_core.h: ls_step).
 //   k_update     x += stp*d, history pair (s, y) into its slot, g <- g_t, and all the
 //                inner products the direction needs in ONE sweep over S and Y.
-//   k_coeffs     one wave per seed: Gram update + two-loop recursion in coefficient space.
+//   k_coeffs     one wave per seed: Gram update + compact-form (Byrd-Nocedal-Schnabel) direction
+//                coefficients by two lane-parallel triangular solves.
 //   k_direction  d = cg*g + sum_j cY_j*Y_j + cS_j*S_j, and g.d / d.d partials.
 //
-// Reference arithmetic: see va_core.h header.  All fp64.  HBM-bound streaming
-// kernels: nothing here is GEMM-shaped, so no MFMA.
+// Reference arithmetic: see va_core.h header.  All fp64.  HBM-bound streaming kernels: nothing
+// here is GEMM-shaped, so no MFMA (the network action in va_nnet.hip is, and uses it).
 #include "va_device.h"
 #include "va_eval_flat.h"
 
