@@ -295,7 +295,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(w["name"]),
                          "kernel": {3: "k_eval3<RhsL96g,trapezoid,K=%d>"
-                                       % (info["tile_rows"] // max(1, (256 if D <= 64 else 512 if D <= 256 else 1024) // D)),
+                                       % (info["tile_rows"] // max(1, (256 if D <= 64 else 512 if D <= 128 else 256 if D <= 256 else 1024) // D)),
                                     2: "k_eval2<RhsL96c,trapezoid>", 1: "k_eval<RhsL96,trapezoid>"}
                                    .get(args.eval_kernel or (3 if D <= 512 else 1)),
                          "kernel_us": kern_s * 1e6, "bytes_alg_per_launch": balg},

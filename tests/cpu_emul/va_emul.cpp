@@ -163,7 +163,7 @@ void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_
                 double rf_scale, double *gt, double *ev)
 {
     const Dims &dm = E.dm;
-    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, G = RHS::GHOST, NS = K / 2 + 1;
+    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, G = RHS::GHOST, NS = tile3_ns_runtime(K);
     const int D = dm.D, T = dm.T, RY = dm.RY, NTH = D * RY, NT = dm.NT;
     std::vector<double> xs(tile3_stage_elems(K, D, G, RY, HL + HR)), ss(tile3_s_elems(K, D, G, RY));
     for (int k = 0; k < EP_N; ++k) ev[k] = 0.0;

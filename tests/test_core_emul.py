@@ -86,7 +86,8 @@ def test_small_history_and_limits(golden_ladders):
 
 
 @pytest.mark.parametrize("D,disc", [(7, "trapezoid"), (36, "SimpsonHermite"), (64, "euler"),
-                                    (100, "trapezoid"), (200, "SimpsonHermite")])
+                                    (100, "trapezoid"), (200, "SimpsonHermite"), (131, "SimpsonHermite"),
+                                    (256, "forwardmap")])
 def test_other_state_sizes_against_oracle(D, disc):
     """odd D (scalar staging), 256-thread groups up to D=64, 1024-thread groups beyond."""
     from varanneal_amd import twin

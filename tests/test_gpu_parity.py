@@ -233,10 +233,12 @@ def test_c4_shape_properties(capi):
 
 @pytest.mark.parametrize("D,disc", [(7, "trapezoid"), (36, "SimpsonHermite"), (64, "euler"),
                                     (100, "forwardmap"), (200, "trapezoid"), (200, "SimpsonHermite"),
+                                    (130, "SimpsonHermite"), (255, "SimpsonHermite"), (256, "euler"),
                                     (300, "trapezoid"), (600, "trapezoid")])
 def test_other_state_sizes_against_oracle(capi, D, disc):
-    """every eval-kernel geometry: odd D, 256-thread groups (D <= 64), 1024-thread groups
-    (D = 200 compile-time, 100/300 run-time), flat fallback (D = 600); vector RF0; 3 seeds."""
+    """every eval-kernel geometry: odd D, 256-thread groups (D <= 64), 512-thread groups (D = 100),
+    one lane per column (128 < D <= 256: D = 200 compile-time, 130 / 255 / 256 run-time),
+    1024-thread groups (D = 300), flat fallback (D = 600); vector RF0; 3 seeds."""
     import va_oracle
     from varanneal_amd import twin
     N, B = 61, 3

@@ -132,7 +132,7 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, bool user_rhs)
             if (sh && (K & 1)) ++K;
         }
         if (dm.NT > 512 && K > 6) K = 6;                  // 1024-thread groups: 128-VGPR budget
-        if (dm.NT > 256 && dm.NT <= 512 && d->tile_rows <= 0 && (long)d->batch * ((N + dm.RY * 8 - 1) / (dm.RY * 8)) >= 256)
+        if (D > 64 && dm.NT <= 512 && d->tile_rows <= 0 && (long)d->batch * ((N + dm.RY * 8 - 1) / (dm.RY * 8)) >= 256)
             K = 8;                                         // few lanes per column: long runs keep the halo share down
         for (;;) {                                        // shrink until the staging arrays fit in LDS
             const size_t elems = (size_t)tile3_stage_elems(K, D, 2, dm.RY, HLR) + tile3_s_elems(K, D, 2, dm.RY);

@@ -96,10 +96,10 @@ __global__ __launch_bounds__(NTMAX) void k_eval3(const Dev dv)
 
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, G = RHS::GHOST;
     constexpr int KP = EP_GP + RHS::NP;
-    // staged double2 per lane = ceil(R / RP), RP = 2*NT/D rows per pass; <= K/2+1 for any D
+    // staged double2 per lane = ceil(R / RP), RP = 2*NT/D rows per pass
     constexpr int DCs = DC > 0 ? DC : 2;
     constexpr int RPc = 2 * tile3_threads(DCs) / DCs;
-    constexpr int NS = DC > 0 ? (tile3_RY(DCs) * K + HL + HR + RPc - 1) / RPc : K / 2 + 1;
+    constexpr int NS = DC > 0 ? (tile3_RY(DCs) * K + HL + HR + RPc - 1) / RPc : tile3_ns_runtime(K);
     // with D fixed at compile time the whole tile geometry (and every LDS offset) is constant
     const int D = DC > 0 ? DC : dm.D;
     const int RY = DC > 0 ? tile3_RY(DC > 0 ? DC : 1) : dm.RY;
@@ -258,15 +258,16 @@ static void launch_eval3_rhs(const Dev &dv, hipStream_t s)
 }
 
 // D fixed at compile time for the state sizes of the Lorenz-96 configurations the reference
-// and BASELINE.json name (D = 20: examples/Lorenz96_D20; D = 200: BASELINE config 4, 512-thread groups); any
+// and BASELINE.json name (D = 20: examples/Lorenz96_D20; D = 200: BASELINE config 4, 256-thread groups); any
 // other D runs the same kernel with D in a register.
 template <class RHS, int K>
 static void launch_eval3_d(const Dev &dv, hipStream_t s)
 {
     if (dv.dm.D == 20) launch_eval3_rhs<RHS, K, 20, 256>(dv, s);
-    else if (dv.dm.D == 200) launch_eval3_rhs<RHS, K, 200, 512>(dv, s);
+    else if (dv.dm.D == 200) launch_eval3_rhs<RHS, K, 200, 256>(dv, s);
     else if (dv.dm.D <= 64) launch_eval3_rhs<RHS, K, 0, 256>(dv, s);
-    else if (dv.dm.D <= 256) launch_eval3_rhs<RHS, K, 0, 512>(dv, s);
+    else if (dv.dm.D <= 128) launch_eval3_rhs<RHS, K, 0, 512>(dv, s);
+    else if (dv.dm.D <= 256) launch_eval3_rhs<RHS, K, 0, 256>(dv, s);
     else launch_eval3_rhs<RHS, K, 0, 1024>(dv, s);
 }
 

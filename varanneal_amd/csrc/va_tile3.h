@@ -60,14 +60,21 @@ struct Tile3 {
     double p[RHS_MAX_NP];
 };
 
-// workgroup geometry: RY lanes per state column.  256-thread groups up to D = 64 (12 lanes per
-// column at D = 20); 512-thread groups up to D = 256 (2 lanes per column at D = 200: two such
-// groups fit a CU at up to 128 VGPRs, so their phases overlap -- a 1024-thread group is alone
-// on its CU above 64 VGPRs; measured at C4: 329 us against 378 us); 1024-thread groups beyond,
-// so that a column still gets at least 2 lanes
-VA_HD constexpr int tile3_ntmax(int D) { return D <= 64 ? 256 : (D <= 256 ? 512 : 1024); }
+// workgroup geometry: RY lanes per state column.  Small groups win: what limits these kernels is
+// how many INDEPENDENT workgroups a CU holds (their load / compute / store phases overlap), not
+// the share of halo rows.  256-thread groups up to D = 64 (12 lanes per column at D = 20) and
+// again for 128 < D <= 256 (ONE lane per column at D = 200, K = 8: four groups per CU; measured
+// at C4: 314 us, against 329 us for 512-thread groups with two lanes per column and 378 us for a
+// 1024-thread group with five, which is alone on its CU above 64 VGPRs); 512-thread groups for
+// 64 < D <= 128; 1024-thread groups beyond 256 so that every column still has a lane
+VA_HD constexpr int tile3_ntmax(int D) { return D <= 64 ? 256 : (D <= 128 ? 512 : (D <= 256 ? 256 : 1024)); }
 VA_HD constexpr int tile3_RY(int D) { return tile3_ntmax(D) / D > 0 ? tile3_ntmax(D) / D : 1; }
 VA_HD constexpr int tile3_threads(int D) { return ((D * tile3_RY(D) + 63) / 64) * 64; }
+
+// staged double2 per lane when D is only known at run time: rows R = RY*K + HL + HR are fetched
+// RP = floor(2*NT/D) >= 2*RY at a time, so ceil(R / RP) <= K/2 + ceil((HL+HR) / 2) passes
+// (K/2 + 2: with ONE lane per column, RY = 1, Simpson-Hermite needs the second extra pass)
+VA_HD constexpr int tile3_ns_runtime(int K) { return (K + 1) / 2 + 2; }
 
 // geometry helpers (G = ghost columns per side)
 VA_HD constexpr int tile3_dp(int D, int G) { return D + 2 * G; }
