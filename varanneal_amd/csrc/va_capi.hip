@@ -131,7 +131,6 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, bool user_rhs)
             K = K < 4 ? 4 : (K > 8 ? 8 : K);
             if (sh && (K & 1)) ++K;
         }
-        if (dm.NT > 512 && K > 6) K = 6;                  // 1024-thread groups: 128-VGPR budget
         if (D > 64 && dm.NT <= 512 && d->tile_rows <= 0 && (long)d->batch * ((N + dm.RY * 8 - 1) / (dm.RY * 8)) >= 256)
             K = 8;                                         // few lanes per column: long runs keep the halo share down
         for (;;) {                                        // shrink until the staging arrays fit in LDS
