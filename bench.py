@@ -37,6 +37,7 @@ WORKLOADS = {
     "w100": dict(D=100, N=5000, B=64, name="lorenz96_D100_N5000_B64_trapezoid"),
     "w300": dict(D=300, N=3000, B=64, name="lorenz96_D300_N3000_B64_trapezoid"),
     "w500": dict(D=500, N=2000, B=64, name="lorenz96_D500_N2000_B64_trapezoid"),
+    "w900": dict(D=900, N=1000, B=64, name="lorenz96_D900_N1000_B64_trapezoid"),
     # batch-scaling points of the C3 shape (launch overhead amortised; not BASELINE configs)
     "c3x4": dict(D=20, N=1000, B=256, name="lorenz96_D20_N1000_L7_B256_trapezoid"),
     "c3x16": dict(D=20, N=1000, B=1024, name="lorenz96_D20_N1000_L7_B1024_trapezoid"),
@@ -299,9 +300,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(w["name"]),
                          "kernel": {3: "k_eval3<RhsL96g,trapezoid,K=%d>"
-                                       % (info["tile_rows"] // max(1, (256 if D <= 64 else 512 if D <= 128 else 256 if D <= 256 else 512) // D)),
+                                       % (info["tile_rows"] // max(1, (256 if D <= 64 else 512 if D <= 128 else 256 if D <= 256 else 512 if D <= 512 else 1024) // D)),
                                     2: "k_eval2<RhsL96c,trapezoid>", 1: "k_eval<RhsL96,trapezoid>"}
-                                   .get(args.eval_kernel or (3 if D <= 512 else 1)),
+                                   .get(args.eval_kernel or (3 if D <= 1024 else 1)),
                          "kernel_us": kern_s * 1e6, "bytes_alg_per_launch": balg},
             "cpu_baseline": None,
         }

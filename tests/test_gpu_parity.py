@@ -238,7 +238,8 @@ def test_c4_shape_properties(capi):
 def test_other_state_sizes_against_oracle(capi, D, disc):
     """every eval-kernel geometry: odd D, 256-thread groups (D <= 64), 512-thread groups (D = 100),
     one lane per column (128 < D <= 256: D = 200 compile-time, 130 / 255 / 256 run-time),
-    1024-thread groups (D = 300), flat fallback (D = 600); vector RF0; 3 seeds."""
+    one lane per column in wider groups (D = 300: 320 threads, D = 600: 640 threads); the flat kernel
+    (eval_kernel = 1) on every size; vector RF0; 3 seeds."""
     import va_oracle
     from varanneal_amd import twin
     N, B = 61, 3

@@ -101,10 +101,10 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, bool user_rhs)
     dm.emode = d->eval_kernel;
     // auto: column-run when a workgroup holds >= 4 lanes per column, row-strided columns for
     // wider states (their short runs would be mostly halo), flat mapping beyond 256 columns
-    if (dm.emode < 1 || dm.emode > 3) dm.emode = (D <= 512) ? 3 : 1;
+    if (dm.emode < 1 || dm.emode > 3) dm.emode = (D <= 1024) ? 3 : 1;
     if (user_rhs) dm.emode = 1;                           // generated modules instantiate the flat kernel
     if (dm.emode == 2 && D > 256) dm.emode = 1;           // row-strided columns: a row per <=256 lanes
-    if (dm.emode == 3 && D > 512) dm.emode = 1;           // column runs: >= 2 lanes per column
+    if (dm.emode == 3 && D > 1024) dm.emode = 1;          // column runs: a lane per column
     int tmin, tmax;
     if (dm.emode == 3) {
         // column-run kernel: T = RY*K exactly, K rows per lane in {4, 6, 8}
@@ -131,11 +131,11 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, bool user_rhs)
             K = K < 4 ? 4 : (K > 8 ? 8 : K);
             if (sh && (K & 1)) ++K;
         }
-        if (D > 64 && dm.NT <= 512 && d->tile_rows <= 0 && (long)d->batch * ((N + dm.RY * 8 - 1) / (dm.RY * 8)) >= 256)
+        if (D > 64 && d->tile_rows <= 0 && (long)d->batch * ((N + dm.RY * 8 - 1) / (dm.RY * 8)) >= 256)
             K = 8;                                         // few lanes per column: long runs keep the halo share down
         for (;;) {                                        // shrink until the staging arrays fit in LDS
             const size_t elems = (size_t)tile3_stage_elems(K, D, 2, dm.RY, HLR) + tile3_s_elems(K, D, 2, dm.RY);
-            if (sizeof(double) * elems <= (D <= 64 ? 60 : 78) * 1024 || K <= 4) break;   // two groups per CU
+            if (sizeof(double) * elems <= (D <= 64 ? 60 : (D <= 512 ? 78 : 150)) * 1024 || K <= 4) break;   // two groups per CU (one beyond D = 512)
             K -= (sh || K == 5) ? (K == 5 ? 1 : 2) : 1;  // Simpson-Hermite keeps K even; never below 4
         }
         dm.maxr = K; dm.T = dm.RY * K;

@@ -268,7 +268,8 @@ static void launch_eval3_d(const Dev &dv, hipStream_t s)
     else if (dv.dm.D <= 64) launch_eval3_rhs<RHS, K, 0, 256>(dv, s);
     else if (dv.dm.D <= 128) launch_eval3_rhs<RHS, K, 0, 512>(dv, s);
     else if (dv.dm.D <= 256) launch_eval3_rhs<RHS, K, 0, 256>(dv, s);
-    else launch_eval3_rhs<RHS, K, 0, 512>(dv, s);
+    else if (dv.dm.D <= 512) launch_eval3_rhs<RHS, K, 0, 512>(dv, s);
+    else launch_eval3_rhs<RHS, K, 0, 1024>(dv, s);
 }
 
 int eval_grid(const Dims &dm) { return ((dm.B * dm.ntiles + 7) / 8) * 8; }

@@ -67,8 +67,9 @@ struct Tile3 {
 // at C4: 314 us, against 329 us for 512-thread groups with two lanes per column and 378 us for a
 // 1024-thread group with five, which is alone on its CU above 64 VGPRs); 512-thread groups for
 // 64 < D <= 128 (D = 100: 156 us against 179 us with 256); one lane per column in groups of up to
-// 512 threads for 256 < D <= 512 (D = 500: 295 us against 410 us for a 1024-thread group)
-VA_HD constexpr int tile3_ntmax(int D) { return D <= 64 ? 256 : (D <= 128 ? 512 : (D <= 256 ? 256 : 512)); }
+// 512 threads for 256 < D <= 512 (D = 500: 295 us against 410 us for a 1024-thread group), of up to
+// 1024 threads for 512 < D <= 1024 (still 3x the flat kernel, which takes over beyond that)
+VA_HD constexpr int tile3_ntmax(int D) { return D <= 64 ? 256 : (D <= 128 ? 512 : (D <= 256 ? 256 : (D <= 512 ? 512 : 1024))); }
 VA_HD constexpr int tile3_RY(int D) { return tile3_ntmax(D) / D > 0 ? tile3_ntmax(D) / D : 1; }
 VA_HD constexpr int tile3_threads(int D) { return ((D * tile3_RY(D) + 63) / 64) * 64; }
 
