@@ -155,9 +155,11 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, bool user_rhs)
         tmin = dm.RY;
     } else {
         dm.RY = 0; dm.NT = EVAL_THREADS; dm.maxr = 0;
-        // LDS: 3 staged arrays of (T+halo) rows; keep a workgroup under ~48 KiB so several fit a CU
-        // (wide states: whatever still gives two owned rows, up to the CU's 160 KiB)
-        tmax = (int)((48 * 1024) / (3 * sizeof(double) * D)) - HLR;
+        // LDS: 3 staged arrays of (T+halo) rows
+        // ~24 KiB per workgroup (six per CU) measured best (D = 100: T = 8, 349 us against 403 us at
+        // T = 18); wider states take 48 KiB, then whatever still gives two owned rows
+        tmax = (int)((24 * 1024) / (3 * sizeof(double) * D)) - HLR;
+        if (tmax < 2) tmax = (int)((48 * 1024) / (3 * sizeof(double) * D)) - HLR;
         if (tmax < 2) tmax = (int)((150 * 1024) / (3 * sizeof(double) * D)) - HLR;
         tmin = (EVAL_THREADS + D - 1) / D;               // >= one element per lane
     }
