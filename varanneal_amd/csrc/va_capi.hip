@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -52,6 +53,7 @@ struct UserRhs {
     int NP = 0, D = 0, NSTIM = 0;
 };
 std::vector<UserRhs> g_user_rhs;
+std::mutex g_user_rhs_mutex;            // the registry is process-wide; handles are not shared
 
 }  // namespace
 
@@ -355,6 +357,7 @@ int va_device_count(int32_t *count)
 int va_rhs_load_module(const char *path, int32_t *rhs_id)
 {
     if (!path || !rhs_id) return fail(VA_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lock(g_user_rhs_mutex);
     for (size_t i = 0; i < g_user_rhs.size(); ++i)
         if (g_user_rhs[i].path == path) { *rhs_id = VA_RHS_USER_BASE + (int32_t)i; return VA_OK; }
     UserRhs u;
@@ -391,10 +394,13 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     if (d->disc < VA_DISC_EULER || d->disc > VA_DISC_FORWARDMAP) return fail(VA_EINVAL, "unknown disc %d", d->disc);
     if (d->disc == VA_DISC_SIMPSON_HERMITE && (d->N_model % 2) == 0)
         return fail(VA_EINVAL, "SimpsonHermite needs an odd number of time points (N_model=%d)", d->N_model);
+    UserRhs user_copy;
     const UserRhs *user = nullptr;
     if (d->rhs >= VA_RHS_USER_BASE) {
+        std::lock_guard<std::mutex> lock(g_user_rhs_mutex);
         if ((size_t)(d->rhs - VA_RHS_USER_BASE) >= g_user_rhs.size()) return fail(VA_EINVAL, "rhs module id %d was never registered", d->rhs);
-        user = &g_user_rhs[d->rhs - VA_RHS_USER_BASE];
+        user_copy = g_user_rhs[d->rhs - VA_RHS_USER_BASE];      // (the vector may grow under another thread)
+        user = &user_copy;
         if (user->NP != d->NP || user->D != d->D || user->NSTIM != d->n_stim)
             return fail(VA_EINVAL, "rhs module %s was generated for D=%d NP=%d n_stim=%d, problem has D=%d NP=%d n_stim=%d",
                         user->path.c_str(), user->D, user->NP, user->NSTIM, d->D, d->NP, d->n_stim);
