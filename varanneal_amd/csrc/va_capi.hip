@@ -291,6 +291,7 @@ int run_ladder(va_handle h, const double *rf_scale, int nbeta)
     // by value, so the graph is private to this call (ladder length, options).
     static const bool no_graph = [] { const char *e = getenv("VA_NO_GRAPH"); return e && atoi(e) != 0; }();
     hipGraphExec_t gexec = nullptr;
+    bool use_graph = !no_graph;
     auto enqueue = [&](int n) {
         for (int k = 0; k < n; ++k) {
             run_eval(h);
@@ -302,17 +303,20 @@ int run_ladder(va_handle h, const double *rf_scale, int nbeta)
     };
     struct GraphGuard { hipGraphExec_t &g; ~GraphGuard() { if (g) (void)hipGraphExecDestroy(g); } } guard{gexec};
     for (;;) {
-        if (poll == 64 && !no_graph) {
+        if (poll == 64 && use_graph) {
             if (!gexec) {
+                // any failure here just means plain launches for the rest of this call
                 hipGraph_t g = nullptr;
-                HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-                enqueue(poll);
-                HIPCHK(hipStreamEndCapture(h->stream, &g));
-                const hipError_t e = hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(g);
-                if (e != hipSuccess) return fail(VA_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+                if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    enqueue(poll);
+                    if (hipStreamEndCapture(h->stream, &g) != hipSuccess || !g ||
+                        hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0) != hipSuccess) gexec = nullptr;
+                    if (g) (void)hipGraphDestroy(g);
+                }
+                if (!gexec) { (void)hipGetLastError(); use_graph = false; }
             }
-            HIPCHK(hipGraphLaunch(gexec, h->stream));
+            if (gexec) HIPCHK(hipGraphLaunch(gexec, h->stream));
+            else enqueue(poll);
         } else enqueue(poll);
         cyc += poll;
         HIPCHK(hipMemcpyAsync(h->h_nactive, dv.n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
