@@ -58,6 +58,18 @@ def bytes_alg(B, N, D, NPest, N_data, L):
     return 8 * (B * (2 * N * D + 2 * NPest + 3) + N_data * L)
 
 
+def kernel_name(D, tile_rows, eval_kernel):
+    """the evaluation kernel va_problem_create picks (csrc/va_capi.hip: pick_eval_geometry)"""
+    t4 = 4 <= D <= 64 and D % 2 == 0 and (64 // D) * D >= 48
+    ek = eval_kernel or (4 if t4 else (3 if D <= 1024 else 1))
+    if ek == 4 and t4:
+        return "k_eval4<RhsL96s,trapezoid,K=%d,D=%d>" % (tile_rows // (4 * (64 // D)), D)
+    if ek in (2, 3, 4):
+        nt = 256 if D <= 64 else 512 if D <= 128 else 256 if D <= 256 else 512 if D <= 512 else 1024
+        return "k_eval3<RhsL96g,trapezoid,K=%d,D=%d>" % (tile_rows // max(1, nt // D), D)
+    return "k_eval<RhsL96,trapezoid>"
+
+
 def pmc_traffic(workload_name):
     """HBM bytes per k_eval launch from the rocprofv3 --pmc passes recorded under profiles/
     (FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE; own
@@ -244,7 +256,7 @@ def main():
                     help="eval: the contract line (batched A/gradA launches); ladder: a whole "
                          "RF ladder through va_anneal, extra information (stderr-style JSON)")
     ap.add_argument("--nbeta", type=int, default=30)
-    ap.add_argument("--eval-kernel", type=int, default=0, help="0 auto, 1 flat-mapped, 2 column-mapped")
+    ap.add_argument("--eval-kernel", type=int, default=0, help="0 auto, 1 flat-mapped, 3 workgroup column runs, 4 wave-private column runs")
     args = ap.parse_args()
 
     import torch
@@ -299,10 +311,7 @@ def main():
                        "parallelism": "seeds sharded, %d per GPU" % B, "final_gather_ms": gather_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(w["name"]),
-                         "kernel": {3: "k_eval3<RhsL96g,trapezoid,K=%d>"
-                                       % (info["tile_rows"] // max(1, (256 if D <= 64 else 512 if D <= 128 else 256 if D <= 256 else 512 if D <= 512 else 1024) // D)),
-                                    2: "k_eval2<RhsL96c,trapezoid>", 1: "k_eval<RhsL96,trapezoid>"}
-                                   .get(args.eval_kernel or (3 if D <= 1024 else 1)),
+                         "kernel": kernel_name(D, info["tile_rows"], args.eval_kernel),
                          "kernel_us": kern_s * 1e6, "bytes_alg_per_launch": balg},
             "cpu_baseline": None,
         }

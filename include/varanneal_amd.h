@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VA_ABI_VERSION 5
+#define VA_ABI_VERSION 6
 
 enum { VA_OK = 0, VA_EINVAL = -1, VA_ENOMEM = -2, VA_EHIP = -3, VA_EUNSUPPORTED = -4,
        VA_ESTATE = -5 };
@@ -149,14 +149,17 @@ int va_anneal(va_handle h, double *XP_inout, int64_t ld, int32_t mem, const doub
  * out[N_model*D + NP] HOST. */
 int va_get_minpath(va_handle h, int32_t seed, int32_t beta_idx, double *out);
 
-/* Measurement hook for bench.py: launches the (A, grad A) kernel `iters` times on
- * the resident paths (those of the last va_action_grad / va_anneal call),
- * bracketed by HIP events on the handle's stream; returns elapsed ms. */
+/* Measurement hook for bench.py: `iters` complete S1 evaluations (the same launch va_action_grad
+ * makes: A, me, fe and the full gradient are formed every time) on the resident paths (those of
+ * the last va_action_grad / va_anneal call), bracketed by HIP events on the handle's stream;
+ * returns elapsed ms. */
 int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms);
 
-/* Profiling hook: copy the first n doubles of the L-BFGS inner-product partial table to the
- * host.  With VA_DEBUG_EVAL=16 in the environment at create time the eval kernel records a
- * per-workgroup timeline there instead (tools/timeline.py); production runs never set it. */
+/* The outputs the last S1 evaluation (va_action_grad or va_eval_timed) left on the device:
+ * A/me/fe [B], grad [B*ldg] (any may be NULL), HOST arrays. */
+int va_read_eval_outputs(va_handle h, double *A, double *me, double *fe, double *grad, int64_t ldg);
+
+/* Profiling hook: copy the first n doubles of the L-BFGS inner-product partial table to the host. */
 int va_debug_read_partials(va_handle h, double *out, int64_t n);
 
 /* Cumulative counters since create: batched eval launches, seed-evaluations,

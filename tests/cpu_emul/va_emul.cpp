@@ -13,6 +13,7 @@
 #include "../../varanneal_amd/csrc/va_core.h"
 #include "../../varanneal_amd/csrc/va_tile2.h"
 #include "../../varanneal_amd/csrc/va_tile3.h"
+#include "../../varanneal_amd/csrc/va_tile4.h"
 #ifdef VA_USER_RHS_HEADER
 #include VA_USER_RHS_HEADER      // generated RhsUser (varanneal_amd/codegen.py)
 #endif
@@ -23,6 +24,7 @@ namespace {
 
 struct Emul {
     Dims dm;
+    Geo4 g4;
     ProblemPtrs pp;
     std::vector<int> lmap, pidx, lidx;
     std::vector<double> Y, rm, rf0, P, tm, stim;
@@ -39,8 +41,19 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     if (m.tdp) { m.ND = m.N * (m.D + m.NPe); m.NP = 0; m.NPest = 0; }
     m.ld = ((m.ND + m.NPest + 15) / 16) * 16;
     if (m.disc == DISC_SH && (T & 1)) ++T;
-    m.emode = (d->eval_kernel >= 1 && d->eval_kernel <= 3) ? d->eval_kernel : 3;
+    m.emode = (d->eval_kernel >= 1 && d->eval_kernel <= 4) ? d->eval_kernel : (tile4_ok(m.D) ? 4 : 3);
+    if (m.emode == 2) m.emode = 3;           // (the row-strided kernel of round 1 is gone)
+    if (m.emode == 4 && !tile4_ok(m.D)) m.emode = 3;
     m.RY = tile2_RY(m.D); m.NT = tile2_threads(m.D); m.maxr = 16;
+    if (m.emode == 4) {                      // wave-private column runs: T = 4 waves x RW runs x K rows
+        const int rows1 = 4 * (64 / m.D);
+        int K = (T + rows1 - 1) / rows1;
+        K = K < 4 ? 4 : (K > 8 ? 8 : K);
+        if (m.disc == DISC_SH && (K & 1)) ++K;
+        E.g4 = m.disc == DISC_SH ? tile4_geo<3>(m.D, K, RhsL96s::NE) : tile4_geo<2>(m.D, K, RhsL96s::NE);
+        if ((E.g4.XP + 63) / 64 > T4_NI_MAX || !tile4_magic_ok(E.g4)) return VA_EUNSUPPORTED;
+        m.RY = 4 * (64 / m.D); m.NT = 256; m.maxr = K; T = E.g4.T;
+    }
     if (m.emode == 3) {                      // column-run: T = RY*K, K in {4,6,8}
         m.RY = tile3_RY(m.D); m.NT = tile3_threads(m.D);
         int K = (T + m.RY - 1) / m.RY;
@@ -48,15 +61,8 @@ int setup(const va_problem_desc *d, int T, Emul &E)
         if (m.disc == DISC_SH && (K & 1)) ++K;   // Simpson-Hermite runs start on even rows
         m.maxr = K; T = m.RY * K;
     }
-    if (m.emode == 2) {                      // a lane walks at most 16 rows of the staged tile
-        const int HLR = m.disc == DISC_SH ? 3 : 2;
-        if (T + HLR > 16 * m.RY) T = 16 * m.RY - HLR;
-        if (m.disc == DISC_SH && (T & 1)) --T;
-    }
     m.T = T; m.ntiles = (m.N + T - 1) / T;
-    m.nprow = m.ntiles; m.dbg = 0;
-    m.obsmask = 0ull;
-    if (m.D <= 64) for (int l = 0; l < d->L; ++l) m.obsmask |= 1ull << d->Lidx[l];
+    m.nprow = m.ntiles;
     m.chunk = 1000; m.nchunks = (m.ld + m.chunk - 1) / m.chunk;
     m.dt = d->dt_model; m.cme = 1.0 / ((double)m.L * m.N_data); m.cfe = 1.0 / ((double)m.D * (m.N - 1));
     m.rm = d->rm; m.rf0 = d->rf0;
@@ -119,44 +125,6 @@ void eval_seed(const Emul &E, int b, const double *x, const double *d, int use_d
     }
 }
 
-// K1, column-mapped variant (va_tile2.h): emulate the (ty, tx) threads phase by phase.
-template <class RHS, int DISC>
-void eval_seed2(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
-                double rf_scale, double *gt, double *ev)
-{
-    const Dims &dm = E.dm;
-    constexpr int MAXR = 16;
-    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
-    constexpr bool FUSE = RHS::CHEAP_F && DISC != DISC_SH;
-    const int D = dm.D, R = dm.T + HL + HR, RY = dm.RY, NTH = D * RY;
-    std::vector<double> xs(R * D), fs(R * D), qs(R * D);
-    for (int k = 0; k < EP_N; ++k) ev[k] = 0.0;
-    for (int tile = 0; tile < dm.ntiles; ++tile) {
-        std::vector<Tile2> th(NTH);
-        std::vector<TRegs<MAXR>> rg(NTH);
-        std::vector<ThreadAcc> acc(NTH);
-        for (int t = 0; t < NTH; ++t) {
-            Tile2 &c = th[t];
-            c.n0 = tile * dm.T; c.R = R; c.RY = RY; c.ty = t / D; c.use_d = use_d;
-            c.col = make_cols(t % D, D); c.l = E.lmap[t % D];
-            c.stp = stp; c.c = 2.0 * rf_scale * dm.cfe;
-            c.xs = xs.data(); c.fs = fs.data(); c.qs = qs.data();
-            c.xg = x; c.dg = d; c.gtg = gt;
-            tile2_params<RHS>(dm, E.pp, b, c);
-            acc[t].clear();
-        }
-        for (int t = 0; t < NTH; ++t) tile2_load<DISC, MAXR>(dm, E.pp, th[t], rg[t]);
-        if (!FUSE) for (int t = 0; t < NTH; ++t) tile2_f<RHS, DISC, MAXR>(dm, th[t], rg[t]);
-        for (int t = 0; t < NTH; ++t) tile2_q<RHS, DISC, MAXR, FUSE>(dm, E.pp, th[t], rg[t], acc[t]);
-        for (int t = 0; t < NTH; ++t) tile2_g<RHS, DISC, MAXR>(dm, th[t], rg[t], acc[t]);
-        for (int t = 0; t < NTH; ++t)
-            for (int k = 0; k < EP_N; ++k) {
-                if (k == EP_GMAX) ev[k] = fmax(ev[k], acc[t].v[k]);
-                else ev[k] += acc[t].v[k];
-            }
-    }
-}
-
 // K1, column-run variant (va_tile3.h): ghosted + padded LDS layout, split staging
 template <class RHS, int DISC, int K>
 void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
@@ -174,7 +142,7 @@ void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_
         for (int t = 0; t < NT; ++t) {
             Tile3 &c = th[t];
             c.n0 = tile * T; c.ty = t / D; c.tx = t % D; c.r0 = c.n0 + c.ty * K; c.use_d = use_d;
-            c.l = D <= 64 ? obs_index(dm.obsmask, c.tx) : E.lmap[c.tx];
+            c.l = E.lmap[c.tx];
             c.stp = stp; c.c = 2.0 * rf_scale * dm.cfe;
             c.xs = xs.data(); c.ss = ss.data();
             c.xg = x; c.dg = d; c.gtg = gt;
@@ -218,6 +186,74 @@ void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_
     }
 }
 
+// K1, wave-private column runs (va_tile4.h): every wave stages its own image through the piece
+// map the direct-to-LDS loads use (bounds-checked here), then rows / scatter / gather
+template <class RHS, int DISC, int K>
+void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
+                double rf_scale, double *gt, double *ev)
+{
+    const Dims &dm = E.dm;
+    const Geo4 &g = E.g4;
+    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, NE = RHS::NE;
+    const int D = dm.D;
+    // the device keeps zero-filled guards around x and d (va_capi.hip: alloc_solver_state)
+    const long guard = (((long)(dm.T + 8) * D + 15) / 16) * 16;
+    std::vector<double> xg(guard + dm.ld + guard, 0.0), dgv(guard + dm.ld + guard, 0.0);
+    memcpy(&xg[guard], x, sizeof(double) * (dm.ND + dm.NPest));
+    if (use_d) memcpy(&dgv[guard], d, sizeof(double) * (dm.ND + dm.NPest));
+    // poison what lies next to the path: the kernel must mask rows that do not exist
+    for (long i = 0; i < guard; ++i) { xg[i] = 1e300; xg[guard + dm.ld + i] = -1e300; }
+    for (long i = dm.ND + dm.NPest; i < dm.ld; ++i) xg[guard + i] = 3e299;
+    std::vector<double> xs(g.XW), r2(g.R2);
+    for (int k = 0; k < EP_N; ++k) ev[k] = 0.0;
+    for (int tile = 0; tile < dm.ntiles; ++tile)
+        for (int wave = 0; wave < g.NW; ++wave) {
+            const int n0w = tile * g.T + wave * g.RW * K;
+            const long src0 = guard + (long)(n0w - HL) * D;
+            for (int q = 0; q < T4_NI_MAX * 64; ++q) {
+                const int sp = tile4_src_piece(g, q);
+                if (sp < 0) continue;
+                const long si = src0 + 2L * sp;
+                if (si < 0 || si + 1 >= (long)xg.size() || 2 * q + 1 >= g.XW) abort();      // a fault on the device
+                xs[2 * q] = xg[si]; xs[2 * q + 1] = xg[si + 1];
+                if (use_d) { xs[2 * q] = trial(xg[si], stp, dgv[si]); xs[2 * q + 1] = trial(xg[si + 1], stp, dgv[si + 1]); }
+            }
+            const bool edge = (n0w - HL < 0) || (n0w + g.RW * K + HR > dm.N);
+            const int NL = g.RW * D;
+            std::vector<Tile4> th(NL);
+            std::vector<T4Regs<K, NE>> rg(NL);
+            std::vector<ThreadAcc> acc(NL);
+            for (int l = 0; l < NL; ++l) {
+                Tile4 &c = th[l];
+                c.n0w = n0w; c.a = l / D; c.tx = l % D; c.r0 = n0w + c.a * K; c.use_d = use_d;
+                c.l = E.lmap[c.tx]; c.c = 2.0 * rf_scale * dm.cfe;
+                c.xs = xs.data(); c.es = r2.data(); c.gtg = gt;
+                Tile2 tmp; tmp.xg = x; tmp.dg = d; tmp.use_d = use_d; tmp.stp = stp;
+                tile2_params<RhsL96c>(dm, E.pp, b, tmp);
+                for (int k = 0; k < RHS_MAX_NP; ++k) c.p[k] = tmp.p[k];
+                acc[l].clear();
+                tile4_obs<K, NE>(dm, E.pp, c, rg[l]);
+                for (int k = 0; k < K; ++k) {
+                    const long gi = (long)(c.r0 + k) * D + c.tx;
+                    rg[l].dval[k] = (use_d && c.r0 + k < dm.N) ? d[gi] : 0.0;
+                }
+            }
+            for (int l = 0; l < NL; ++l) {
+                if (edge) tile4_rows<RHS, DISC, K, true, 0>(dm, E.pp, g, th[l], rg[l], acc[l]);
+                else tile4_rows<RHS, DISC, K, false, 0>(dm, E.pp, g, th[l], rg[l], acc[l]);
+            }
+            for (int l = 0; l < NL; ++l) {
+                if (edge) tile4_grad<RHS, DISC, K, true, 0>(dm, g, th[l], rg[l], acc[l]);
+                else tile4_grad<RHS, DISC, K, false, 0>(dm, g, th[l], rg[l], acc[l]);
+            }
+            for (int l = 0; l < NL; ++l)
+                for (int k = 0; k < EP_N; ++k) {
+                    if (k == EP_GMAX) ev[k] = fmax(ev[k], acc[l].v[k]);
+                    else ev[k] += acc[l].v[k];
+                }
+        }
+}
+
 template <int DISC>
 void eval_seed_rhs(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
                    double rf_scale, double *gt, double *ev)
@@ -225,14 +261,19 @@ void eval_seed_rhs(const Emul &E, int b, const double *x, const double *d, int u
 #ifdef VA_USER_RHS_HEADER
     if (E.rhs >= VA_RHS_USER_BASE) { eval_seed<RhsUser, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev); return; }
 #endif
-    if (E.dm.emode == 3) {
+    if (E.dm.emode == 4) {
+        if (E.dm.maxr == 4) eval_seed4<RhsL96s, DISC, 4>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 5) eval_seed4<RhsL96s, DISC, 5>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 6) eval_seed4<RhsL96s, DISC, 6>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 7) eval_seed4<RhsL96s, DISC, 7>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else eval_seed4<RhsL96s, DISC, 8>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+    } else if (E.dm.emode == 3) {
         if (E.dm.maxr == 4) eval_seed3<RhsL96g, DISC, 4>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
         else if (E.dm.maxr == 5) eval_seed3<RhsL96g, DISC, 5>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
         else if (E.dm.maxr == 6) eval_seed3<RhsL96g, DISC, 6>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
         else if (E.dm.maxr == 7) eval_seed3<RhsL96g, DISC, 7>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
         else eval_seed3<RhsL96g, DISC, 8>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
-    } else if (E.dm.emode == 2) eval_seed2<RhsL96c, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
-    else eval_seed<RhsL96, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+    } else eval_seed<RhsL96, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
 }
 
 void eval_dispatch(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,

@@ -21,10 +21,10 @@ def _desc(c, batch=1, eval_kernel=0):
                            merr_nskip=int(c["merr_nskip"]), eval_kernel=eval_kernel)
 
 
-@pytest.mark.parametrize("eval_kernel", [1, 2, 3])
+@pytest.mark.parametrize("eval_kernel", [1, 3, 4])
 def test_tile_phases_match_golden_for_every_tiling(golden_single, eval_kernel):
-    """flat-mapped (va_core.h), column-mapped (va_tile2.h) and column-run (va_tile3.h) tiles,
-    every discretisation, scalar/vector RM/RF, nskip 1 and 2."""
+    """flat-mapped (va_core.h), column-run (va_tile3.h) and wave-private column-run (va_tile4.h)
+    tiles, every discretisation, scalar/vector RM/RF, nskip 1 and 2."""
     for name, c in golden_single.items():
         desc, keep = _desc(c, eval_kernel=eval_kernel)
         for T in (2, 7, 50, 72, 84, 400):   # tiny tiles, ragged last tile, K = 5, 6, 7 runs, single tile
@@ -98,11 +98,26 @@ def test_other_state_sizes_against_oracle(D, disc):
     RF0 = 4e-6 * (0.5 + rng.rand(N - 1, D))
     opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, RF0, [7.3], [0], disc=disc)
     Ao, meo, feo, go = opb.action_grad(XP, 1.5 ** 20)
-    for ek in (1, 2, 3):
-        if ek == 2 and D > 256:
-            continue
+    for ek in (1, 3, 4):
         desc, keep = _capi.make_desc(1, D, N, Y, Lidx, twin.DT, 4.0, RF0, [[7.3]], [0], disc=disc, eval_kernel=ek)
         for T in (4, 10):
             A, me, fe, g = emul.action_grad(desc, T, XP[None, :], 1.5 ** 20)
             assert abs(A[0] - Ao) <= 1e-12 * abs(Ao), (ek, T)
             assert np.abs(g[0] - go).max() <= 1e-11 * np.abs(go).max(), (ek, T)
+
+
+@pytest.mark.parametrize("eval_kernel", [1, 3, 4])
+def test_lidx_in_any_order(eval_kernel):
+    """data column l pairs with state column Lidx[l] whatever the order of Lidx (va_ode.py:141)."""
+    rng = np.random.RandomState(5)
+    for D, Lidx in ((8, [5, 1, 3]), (20, [16, 0, 8, 2, 14, 4, 10])):
+        N = 50
+        Y = rng.randn(N, len(Lidx))
+        XP = np.append(2.0 * rng.randn(N * D), 7.3)
+        opb = va_oracle.Problem(D, N, Y, Lidx, 0.025, 3.0, 0.7, [7.3], [0], disc="trapezoid")
+        Ao, meo, feo, go = opb.action_grad(XP, 2.5)
+        desc, keep = _capi.make_desc(1, D, N, Y, Lidx, 0.025, 3.0, 0.7, [[7.3]], [0], disc="trapezoid",
+                                     eval_kernel=eval_kernel)
+        A, me, fe, g = emul.action_grad(desc, 20, XP[None, :], 2.5)
+        assert abs(me[0] - meo) <= 1e-12 * abs(meo) and abs(A[0] - Ao) <= 1e-12 * abs(Ao)
+        assert np.abs(g[0] - go).max() <= 1e-11 * np.abs(go).max()

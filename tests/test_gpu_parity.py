@@ -33,10 +33,10 @@ def gpu_problem(capi, c, batch=1, **kw):
                         disc=str(c["disc"]), merr_nskip=int(c["merr_nskip"]), **kw)
 
 
-@pytest.mark.parametrize("eval_kernel", [1, 2, 3])
+@pytest.mark.parametrize("eval_kernel", [1, 3, 4])
 def test_all_golden_single_evals(capi, golden_single, eval_kernel):
-    """all three tile kernels (1 flat-mapped, 2 column-mapped, 3 column-run = production),
-    auto and tiny tiles"""
+    """all three tile kernels (1 flat-mapped, 3 workgroup column runs, 4 wave-private column runs =
+    production for D = 20), auto and tiny tiles"""
     worstA = worstG = 0.0
     for name, c in golden_single.items():
         for tile_rows in (0, 6):
@@ -52,6 +52,49 @@ def test_all_golden_single_evals(capi, golden_single, eval_kernel):
                 assert eG <= RTOL_G, (name, tile_rows, eG)
                 worstG = max(worstG, eG)
     print("worst rel err A %.2e grad %.2e" % (worstA, worstG))
+
+
+@pytest.mark.parametrize("eval_kernel", [1, 3, 4])
+def test_timed_evaluation_is_a_complete_evaluation(capi, golden_single, eval_kernel):
+    """what bench.py times (va_eval_timed) is the launch va_action_grad makes: afterwards A, me, fe
+    and the gradient on the device equal va_action_grad's bit for bit (the last-arriving wave of
+    each seed formed them inside the evaluation kernel), and repeated launches keep doing so (the
+    arrival counters reset themselves)."""
+    c = golden_single["g2_c2_trapezoid"]
+    N, D = int(c["N_model"]), int(c["D"])
+    B = 7
+    rng = np.random.RandomState(11)
+    XP = np.tile(c["XP"], (B, 1)); XP[1:, :N * D] += 0.3 * rng.randn(B - 1, N * D)
+    with gpu_problem(capi, c, batch=B, eval_kernel=eval_kernel) as pb:
+        A, me, fe, g = pb.action_grad(XP, c["rf_scale"])
+        for iters in (1, 5):
+            pb.eval_timed(c["rf_scale"], iters)
+            A2, me2, fe2, g2 = pb.read_eval_outputs()
+            assert np.array_equal(A, A2) and np.array_equal(me, me2) and np.array_equal(fe, fe2)
+            assert np.array_equal(g, g2)
+    assert abs(A[0] - c["A"]) <= RTOL_A * abs(c["A"])
+
+
+@pytest.mark.parametrize("eval_kernel", [1, 3, 4])
+def test_lidx_in_any_order(capi, eval_kernel):
+    """data column l pairs with state column Lidx[l] whatever the order of Lidx (va_ode.py:141)."""
+    import va_oracle
+    rng = np.random.RandomState(5)
+    for D, Lidx in ((8, [5, 1, 3]), (20, [16, 0, 8, 2, 14, 4, 10])):
+        N, B = 50, 2
+        Y = rng.randn(N, len(Lidx))
+        XP = np.concatenate([2.0 * rng.randn(B, N * D), 7.0 + rng.rand(B, 1)], axis=1)
+        P = XP[:, -1:].copy()
+        with capi.Problem(B, D, N, Y, Lidx, 0.025, 3.0, 0.7, P, [0], disc="trapezoid", eval_kernel=eval_kernel) as pb:
+            A, me, fe, g = pb.action_grad(XP, 2.5)
+        for b in range(B):
+            opb = va_oracle.Problem(D, N, Y, Lidx, 0.025, 3.0, 0.7, P[b], [0], disc="trapezoid")
+            Ao, meo, feo, go = opb.action_grad(XP[b], 2.5)
+            assert abs(me[b] - meo) <= RTOL_A * abs(meo), (D, b, me[b], meo)
+            assert abs(A[b] - Ao) <= RTOL_A * abs(Ao)
+            assert np.abs(g[b] - go).max() <= RTOL_G * np.abs(go).max()
+    with pytest.raises(capi.VaError):
+        capi.Problem(1, 8, 10, rng.randn(10, 2), [3, 3], 0.025, 3.0, 0.7, [[7.0]], [0])
 
 
 def test_batched_eval_matches_oracle_per_seed(capi, golden_single):
@@ -248,9 +291,7 @@ def test_other_state_sizes_against_oracle(capi, D, disc):
     XP = np.concatenate([rng.randn(B, N * D) * 3.0, 6.0 + 3.0 * rng.rand(B, 1)], axis=1)
     P = XP[:, -1:].copy()
     RF0 = 4e-6 * (0.5 + rng.rand(N - 1, D))
-    for ek in (0, 1, 2):
-        if ek == 2 and D > 256:
-            continue
+    for ek in (0, 1, 3):
         pb = capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, RF0, P, [0], disc=disc, eval_kernel=ek)
         A, me, fe, g = pb.action_grad(XP, 1.5 ** 20)
         pb.close()
@@ -291,7 +332,7 @@ def test_smallest_problems(capi, D, N, disc):
     B = 2
     XP = np.concatenate([2.0 * rng.randn(B, N * D), 7.0 + rng.rand(B, 1)], axis=1)
     P = XP[:, -1:].copy()
-    for ek in (0, 1, 2):
+    for ek in (0, 1, 3):
         pb = capi.Problem(B, D, N, Y, Lidx, 0.025, 3.0, 0.7, P, [0], disc=disc, eval_kernel=ek)
         A, me, fe, g = pb.action_grad(XP, 2.5)
         r = pb.minimize_lbfgs(XP, 2.5, dict(OPTS, maxiter=5))

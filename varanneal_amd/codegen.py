@@ -228,7 +228,8 @@ def check_against(f, exprs, syms, D, NP, nstim, stim_ndim=1, trials=3, rtol=1e-1
 
 def _core_fingerprint():
     h = hashlib.sha1()
-    for fn in ("va_core.h", "va_device.h", "va_eval_flat.h", "va_tile2.h", "va_tile3.h", "va_user_rhs.hip"):
+    for fn in ("va_core.h", "va_device.h", "va_eval_flat.h", "va_epilogue.h", "va_tile2.h", "va_tile3.h", "va_tile4.h",
+               "va_user_rhs.hip"):
         with open(os.path.join(CSRC, fn), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
@@ -240,17 +241,26 @@ def build_module(header_text, verbose=False):
     key = hashlib.sha1((header_text + _core_fingerprint()).encode()).hexdigest()[:16]
     hdr = os.path.join(CACHE, "rhs_%s.h" % key)
     so = os.path.join(CACHE, "libva_rhs_%s.so" % key)
+    # Several ranks may build the same module at once (one process per GPU, each calling
+    # anneal_init): every process writes to names of its own and publishes with an atomic rename, so
+    # nobody ever compiles a half-written header or loads a half-written library.
+    tag = ".%d.tmp" % os.getpid()
     if not os.path.exists(hdr):
-        with open(hdr, "w") as fh:
+        with open(hdr + tag, "w") as fh:
             fh.write(header_text)
+        os.replace(hdr + tag, hdr)
     if not os.path.exists(so):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-Wno-unused-function", "-I", CSRC, '-DVA_USER_RHS_HEADER="%s"' % hdr,
-               "-o", so + ".tmp", os.path.join(CSRC, "va_user_rhs.hip")]
+               "-o", so + tag, os.path.join(CSRC, "va_user_rhs.hip")]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        os.replace(so + ".tmp", so)
+        try:
+            subprocess.check_call(cmd)
+            os.replace(so + tag, so)
+        finally:
+            if os.path.exists(so + tag):
+                os.remove(so + tag)
     return so, hdr
 
 

@@ -1,8 +1,8 @@
 // va_capi.hip -- host side of libvaranneal_amd.so: the C-ABI of include/varanneal_amd.h.
 //
 // Owns the device image of one annealing problem (B seeds resident in HBM), moves
-// paths in/out, and drives the kernel cycle
-//     k_eval -> k_ls -> k_update -> k_coeffs -> k_direction
+// paths in/out, and drives the three-launch kernel cycle
+//     k_eval (+ line-search / ladder step) -> k_update (+ direction coefficients) -> k_direction
 // until every seed has climbed its whole RF ladder.  No per-iteration host sync:
 // the host only polls a device counter of unfinished seeds every few cycles.
 #include <dlfcn.h>
@@ -50,6 +50,7 @@ struct UserRhs {
     std::string path;
     void *dl = nullptr;
     void (*launch)(const Dev *, void *) = nullptr;
+    int (*prepare)(const Dev *) = nullptr;
     int NP = 0, D = 0, NSTIM = 0;
 };
 std::vector<UserRhs> g_user_rhs;
@@ -61,6 +62,7 @@ struct va_problem_s {
     Dev dv;
     int device = 0, rhs = 0, keep_paths = 0;
     void (*user_launch)(const Dev *, void *) = nullptr;
+    int (*user_prepare)(const Dev *) = nullptr;
     bool is_nnet = false;              // feed-forward-network action (va_nnet.hip) instead of an ODE path
     NnetDev nn;
     hipStream_t stream = nullptr;
@@ -86,28 +88,68 @@ struct va_problem_s {
 
 namespace {
 
-void run_eval(va_handle h)
+// one batched evaluation.  epi: what the last-arriving wave of each seed does with the partial sums
+// (EPI_FINALIZE: S1 outputs; EPI_LS: one line-search / ladder step).  The network action's
+// evaluation is several kernels, so its tail stays a launch of its own.
+void run_eval(va_handle h, int epi)
 {
-    if (h->is_nnet) launch_nnet_eval(h->dv, h->nn, h->stream);
-    else if (h->user_launch) h->user_launch(&h->dv, (void *)h->stream);
+    if (h->is_nnet) {
+        h->dv.epi = EPI_NONE;
+        launch_nnet_eval(h->dv, h->nn, h->stream);
+        if (epi == EPI_FINALIZE) launch_finalize_eval(h->dv, h->stream);
+        else if (epi == EPI_LS) launch_ls(h->dv, h->stream);
+        return;
+    }
+    h->dv.epi = epi;
+    if (h->user_launch) h->user_launch(&h->dv, (void *)h->stream);
     else launch_eval(h->dv, h->rhs, h->stream);
 }
 
 // Tile geometry of the eval kernel: which mapping, rows per workgroup, threads.
-void pick_eval_geometry(const va_problem_desc *d, Dims &dm, bool user_rhs)
+void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, bool user_rhs)
 {
     user_rhs = user_rhs || d->p_time_dependent || d->rm_kind == 2;   // per-row parameters / full RM: flat kernel only
     const int D = d->D, N = d->N_model;
     const bool sh = d->disc == VA_DISC_SIMPSON_HERMITE;
     const int HLR = sh ? 3 : 2;
     dm.emode = d->eval_kernel;
-    // auto: column-run when a workgroup holds >= 4 lanes per column, row-strided columns for
-    // wider states (their short runs would be mostly halo), flat mapping beyond 256 columns
-    if (dm.emode < 1 || dm.emode > 3) dm.emode = (D <= 1024) ? 3 : 1;
+    // auto: wave-private column runs for narrow states that fill a wave, workgroup column runs up
+    // to 1024 columns, flat mapping beyond
+    if (dm.emode == 2) dm.emode = 3;                      // (the row-strided kernel of round 1 is gone)
+    if (dm.emode < 1 || dm.emode > 4) dm.emode = tile4_ok(D) ? 4 : ((D <= 1024) ? 3 : 1);
     if (user_rhs) dm.emode = 1;                           // generated modules instantiate the flat kernel
-    if (dm.emode == 2 && D > 256) dm.emode = 1;           // row-strided columns: a row per <=256 lanes
+    if (dm.emode == 4 && !tile4_ok(D)) dm.emode = 3;
     if (dm.emode == 3 && D > 1024) dm.emode = 1;          // column runs: a lane per column
     int tmin, tmax;
+    if (dm.emode == 4) {
+        // wave-private column runs: T = 4 waves x RW runs x K rows.  K is the run length that gives
+        // every CU the same number of workgroups when the grid is only a few per CU (C3: 64 seeds,
+        // N = 1000: K = 7 -> 12 tiles x 64 = 768 = 3 x 256), 6 otherwise
+        const int RW = 64 / D, rows1 = 4 * RW;
+        int K = 6;
+        auto ntl = [&](int k) { return (long)d->batch * ((N + rows1 * k - 1) / (rows1 * k)); };
+        if (ntl(K) < 256) K = 4;
+        else if (ntl(K) < 8 * 256) {
+            long best = -1;
+            for (int k = 5; k <= 8; ++k) {
+                if (sh && (k & 1)) continue;              // Simpson-Hermite runs start on even rows
+                const long cost = ((ntl(k) + 255) / 256) * (k + 2) * 4 + (k == 6 ? 0 : 1);     // ties go to 6
+                if (best < 0 || cost < best) { best = cost; K = k; }
+            }
+        }
+        if (d->tile_rows > 0) {
+            K = (d->tile_rows + rows1 - 1) / rows1;
+            K = K < 4 ? 4 : (K > 8 ? 8 : K);
+            if (sh && (K & 1)) ++K;
+        }
+        g4 = sh ? tile4_geo<3>(D, K, RhsL96s::NE) : tile4_geo<2>(D, K, RhsL96s::NE);
+        if ((g4.XP + 63) / 64 <= T4_NI_MAX && tile4_magic_ok(g4)) {
+            dm.RY = 4 * RW; dm.NT = 256; dm.maxr = K; dm.T = g4.T;
+            dm.ntiles = (N + dm.T - 1) / dm.T;
+            return;
+        }
+        dm.emode = 3;
+    }
     if (dm.emode == 3) {
         // column-run kernel: T = RY*K exactly, K rows per lane in {4, 6, 8}
         dm.RY = tile3_RY(D); dm.NT = tile3_threads(D);
@@ -192,8 +234,13 @@ int alloc_solver_state(va_handle h, int max_beta, int keep_paths)
     const size_t B = dm.B, ld = dm.ld, m = dm.m;
     int rc;
 #define TRYA(x) do { rc = (x); if (rc) return rc; } while (0)
-    TRYA(h->alloc(&dv.x, B * ld)); TRYA(h->alloc(&dv.g, B * ld));
-    TRYA(h->alloc(&dv.gt, B * ld)); TRYA(h->alloc(&dv.d, B * ld));
+    // x and d carry a zero-filled guard in front and behind: the evaluation kernels stage whole
+    // tiles (+ halo rows) without clamping, so the first / last tile of the first / last seed reads
+    // up to one tile beyond its path (such rows are masked out of the arithmetic)
+    const size_t guard = (((size_t)(dm.T + 8) * dm.D + 15) / 16) * 16;
+    TRYA(h->alloc(&dv.x, B * ld + 2 * guard)); TRYA(h->alloc(&dv.g, B * ld));
+    TRYA(h->alloc(&dv.gt, B * ld)); TRYA(h->alloc(&dv.d, B * ld + 2 * guard));
+    dv.x += guard; dv.d += guard;
     TRYA(h->alloc(&dv.S, B * m * ld)); TRYA(h->alloc(&dv.Y, B * m * ld));
     TRYA(h->alloc(&dv.st, B));
     TRYA(h->alloc(&dv.evp, B * dm.nprow * EP_N));
@@ -205,6 +252,7 @@ int alloc_solver_state(va_handle h, int max_beta, int keep_paths)
     TRYA(h->alloc(&dv.status, B * max_beta)); TRYA(h->alloc(&dv.nit, B * max_beta));
     TRYA(h->alloc(&dv.nfev, B * max_beta));
     if (keep_paths) TRYA(h->alloc(&dv.minpaths, B * max_beta * (size_t)(dm.ND + dm.NP), false));
+    TRYA(h->alloc(&dv.cnt_eval, B)); TRYA(h->alloc(&dv.cnt_upd, B)); TRYA(h->alloc(&dv.cnt_dir, B));
     TRYA(h->alloc(&dv.n_active, 1));
     TRYA(h->alloc(&dv.n_evals, 1));
     TRYA(h->alloc(&dv.outA, B)); TRYA(h->alloc(&dv.outme, B)); TRYA(h->alloc(&dv.outfe, B));
@@ -285,19 +333,17 @@ int run_ladder(va_handle h, const double *rf_scale, int nbeta)
     long long max_cycles = bound > 4e18 ? (long long)4e18 : (long long)bound;
     long long cyc = 0;
     int poll = 4;
-    // Long ladders on small problems are bound by the host's launch rate (5+ launches per cycle at
-    // ~5 us each against ~25 us of device time): once the polling interval has grown to 64 cycles,
-    // that batch is captured ONCE into a hipGraph and replayed.  The kernels take the device image
+    // Long ladders on small problems are bound by the host's launch rate (3 launches per cycle at
+    // ~4 us each against ~25 us of device time): once the polling interval has grown to 64 cycles,
+    // that batch of 192 launches is captured ONCE into a hipGraph and replayed.  The kernels take the device image
     // by value, so the graph is private to this call (ladder length, options).
     static const bool no_graph = [] { const char *e = getenv("VA_NO_GRAPH"); return e && atoi(e) != 0; }();
     hipGraphExec_t gexec = nullptr;
     bool use_graph = !no_graph;
     auto enqueue = [&](int n) {
         for (int k = 0; k < n; ++k) {
-            run_eval(h);
-            launch_ls(dv, h->stream);
+            run_eval(h, EPI_LS);
             launch_update(dv, h->stream);
-            launch_coeffs(dv, h->stream);
             launch_direction(dv, h->stream);
         }
     };
@@ -319,6 +365,7 @@ int run_ladder(va_handle h, const double *rf_scale, int nbeta)
             else enqueue(poll);
         } else enqueue(poll);
         cyc += poll;
+        HIPCHK(hipGetLastError());            // a failed launch surfaces here, with its cause, not as a stalled ladder
         HIPCHK(hipMemcpyAsync(h->h_nactive, dv.n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(h->h_nactive + 2, dv.n_evals, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -371,7 +418,8 @@ int va_rhs_load_module(const char *path, int32_t *rhs_id)
     typedef void (*info_fn)(int *);
     info_fn info = (info_fn)dlsym(u.dl, "va_user_rhs_info");
     u.launch = (void (*)(const Dev *, void *))dlsym(u.dl, "va_user_launch_eval");
-    if (!info || !u.launch) { dlclose(u.dl); return fail(VA_EINVAL, "%s lacks va_user_rhs_info / va_user_launch_eval", path); }
+    u.prepare = (int (*)(const Dev *))dlsym(u.dl, "va_user_prepare_eval");
+    if (!info || !u.launch || !u.prepare) { dlclose(u.dl); return fail(VA_EINVAL, "%s lacks va_user_rhs_info / va_user_launch_eval / va_user_prepare_eval", path); }
     int v[5] = {0, 0, 0, 0, 0};
     info(v);
     if (v[3] != (int)sizeof(Dev) || v[4] != (int)sizeof(SeedState)) {
@@ -420,8 +468,16 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     if (tdp && (int64_t)d->N_model * (d->D + d->NPest) > 2000000000LL) return fail(VA_EUNSUPPORTED, "n_var does not fit 32-bit indexing");
     if (!d->Y || (d->L > 0 && !d->Lidx) || !d->P || (d->NPest > 0 && !d->Pidx)) return fail(VA_EINVAL, "null array in desc");
     if ((d->rm_kind && !d->rm_array) || (d->rf_kind && !d->rf0_array)) return fail(VA_EINVAL, "rm/rf array kind without array");
-    for (int l = 0; l < d->L; ++l)
-        if (d->Lidx[l] < 0 || d->Lidx[l] >= d->D) return fail(VA_EINVAL, "Lidx[%d]=%d outside [0,D)", l, d->Lidx[l]);
+    {
+        std::vector<char> seen(d->D, 0);
+        for (int l = 0; l < d->L; ++l) {
+            if (d->Lidx[l] < 0 || d->Lidx[l] >= d->D) return fail(VA_EINVAL, "Lidx[%d]=%d outside [0,D)", l, d->Lidx[l]);
+            // any order is fine (data column l pairs with state column Lidx[l], va_ode.py:141); a state
+            // column observed twice has no slot in the column -> data-column map the kernels use
+            if (seen[d->Lidx[l]] && d->rm_kind != 2) return fail(VA_EUNSUPPORTED, "Lidx lists state column %d twice", d->Lidx[l]);
+            seen[d->Lidx[l]] = 1;
+        }
+    }
     for (int k = 0; k < d->NPest; ++k)
         if (d->Pidx[k] < 0 || d->Pidx[k] >= d->NP) return fail(VA_EINVAL, "Pidx[%d]=%d outside [0,NP)", k, d->Pidx[k]);
     const int m = d->lbfgs_m > 0 ? d->lbfgs_m : 10;
@@ -436,6 +492,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     va_handle h = new va_problem_s();
     h->device = d->device; h->rhs = d->rhs; h->keep_paths = d->keep_paths;
     h->user_launch = user ? user->launch : nullptr;
+    h->user_prepare = user ? user->prepare : nullptr;
     if (d->stream) h->stream = (hipStream_t)d->stream;
     else {
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -451,11 +508,8 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dm.tdp = tdp ? 1 : 0; dm.NPt = d->NP; dm.NPe = d->NPest;
     if (tdp) { dm.ND = dm.N * (dm.D + dm.NPe); dm.NP = 0; dm.NPest = 0; }   // one flat run for the L-BFGS kernels
     dm.ld = ((dm.ND + dm.NPest + 15) / 16) * 16;
-    pick_eval_geometry(d, dm, user != nullptr);
-    dm.nprow = dm.emode == 3 ? dm.ntiles * (dm.NT / 64) : dm.ntiles;
-    dm.obsmask = 0ull;
-    if (dm.D <= 64) for (int l = 0; l < d->L; ++l) dm.obsmask |= 1ull << d->Lidx[l];
-    { const char *e = getenv("VA_DEBUG_EVAL"); dm.dbg = e ? atoi(e) : 0; }   // profiling ablations only
+    pick_eval_geometry(d, dm, dv.g4, user != nullptr);
+    dm.nprow = dm.emode >= 3 ? dm.ntiles * (dm.NT / 64) : dm.ntiles;      // one partial row per wave / per workgroup
     dm.chunk = VEC_CHUNK; dm.nchunks = (dm.ld + VEC_CHUNK - 1) / VEC_CHUNK;
     dm.dt = d->dt_model;
     dm.cme = d->L > 0 ? 1.0 / ((double)dm.L * dm.N_data) : 0.0;
@@ -466,13 +520,19 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
 
     {
         // the flat kernel keeps 3 staged arrays of (T + halo) rows: up to the CU's 160 KiB
-        const size_t need = dm.emode == 1 ? eval_flat_lds_bytes(dm) : eval_lds_bytes(dm);
-        const size_t cap = (dm.emode == 2 ? 64 : 160) * 1024;
+        const size_t need = eval_lds_bytes(dv);
+        const size_t cap = 160 * 1024;
         if (need > cap) {
             const int T = dm.T, D = dm.D;
             va_problem_destroy(h);
             return fail(VA_EUNSUPPORTED, "a tile of %d rows x D=%d needs %zu B of LDS (> %zu): state too wide for this kernel",
                         T, D, need, cap);
+        }
+        // more than 64 KiB of dynamic LDS is an opt-in per kernel AND per device: once per handle
+        const hipError_t e = h->user_prepare ? (hipError_t)h->user_prepare(&dv) : prepare_eval(dv, h->rhs);
+        if (e != hipSuccess) {
+            va_problem_destroy(h);
+            return fail(VA_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(e));
         }
     }
 
@@ -701,8 +761,7 @@ int va_action_grad(va_handle h, const double *XP, int64_t ld, int32_t mem, doubl
     Dev &dv = h->dv;
     if ((rc = copy_in(h, XP, ld, mem))) return rc;
     launch_init_states(dv, PH_START, rf_scale, h->stream);
-    run_eval(h);
-    launch_finalize_eval(dv, h->stream);
+    run_eval(h, EPI_FINALIZE);
     const hipMemcpyKind k = mem == VA_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     HIPCHK(hipMemcpyAsync(A, dv.outA, sizeof(double) * dv.dm.B, k, h->stream));
     HIPCHK(hipMemcpyAsync(me, dv.outme, sizeof(double) * dv.dm.B, k, h->stream));
@@ -777,13 +836,29 @@ int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms
     Dev &dv = h->dv;
     launch_init_states(dv, PH_START, rf_scale, h->stream);
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    for (int i = 0; i < iters; ++i) run_eval(h);
+    for (int i = 0; i < iters; ++i) run_eval(h, EPI_FINALIZE);     // each launch forms A, me, fe and the full gradient
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventSynchronize(h->ev1));
     HIPCHK(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
     HIPCHK(hipGetLastError());
     h->n_eval_launch += iters; h->n_seed_evals += (int64_t)iters * dv.dm.B;
     h->n_seed_evals_direct += (int64_t)iters * dv.dm.B;
+    return VA_OK;
+}
+
+int va_read_eval_outputs(va_handle h, double *A, double *me, double *fe, double *grad, int64_t ldg)
+{
+    if (!h) return fail(VA_EINVAL, "null handle");
+    const Dev &dv = h->dv;
+    if (grad && ldg < dv.dm.ND + dv.dm.NPest) return fail(VA_EINVAL, "ldg < n_var");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t nb = sizeof(double) * dv.dm.B;
+    if (A) HIPCHK(hipMemcpyAsync(A, dv.outA, nb, hipMemcpyDeviceToHost, h->stream));
+    if (me) HIPCHK(hipMemcpyAsync(me, dv.outme, nb, hipMemcpyDeviceToHost, h->stream));
+    if (fe) HIPCHK(hipMemcpyAsync(fe, dv.outfe, nb, hipMemcpyDeviceToHost, h->stream));
+    int rc;
+    if (grad && (rc = copy_out(h, dv.gt, grad, ldg, VA_MEM_HOST))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
     return VA_OK;
 }
 

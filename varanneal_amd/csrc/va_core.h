@@ -50,11 +50,8 @@ enum { DP_GD = 0, DP_DD = 1, DP_N = 2 };
 
 struct Dims {
     int D, N, ND, ld, L, N_data, nskip, NP, NPest, T, ntiles, B, m, disc, nchunks, chunk;
-    int emode, RY, NT, maxr;   // eval kernel: 1 = flat-mapped, 2 = column-mapped (va_tile2.h), 3 = column-run (va_tile3.h)
+    int emode, RY, NT, maxr;   // eval kernel: 1 = flat-mapped, 3 = column-run (va_tile3.h), 4 = wave-private column runs (va_tile4.h)
     int nprow;                 // eval partial rows per seed (ntiles, or ntiles*4 when every wave writes its own)
-    unsigned long long obsmask; // bit i set <=> state column i is observed (valid when D <= 64)
-    int dbg;                   // profiling builds only (env VA_DEBUG_EVAL; 0 in production): 2 = copy only (skip
-                               // phases B/C), 8 = return right after dispatch, 16 = per-workgroup timeline into upp
     // time-dependent parameters (va_ode.py:170-188): P is (N, NPt) per seed and the vector is
     // [X (N*D) | p_est (N*NPe), time-major].  Then ND = N*D + N*NPe and NP = NPest = 0 for the
     // L-BFGS kernels (one flat run), and the flat tile kernel uses NPt / NPe.  Static: tdp = 0,
@@ -100,6 +97,7 @@ struct SeedHot {
     double stp_upd;         // accepted step the update kernel applies (stp is the NEXT trial step)
     LsState ls;
     double cg;
+    double gd_dir;          // g.d of the direction in use (left by k_direction's last arriver)
 };
 static_assert(sizeof(SeedHot) <= 512 && sizeof(SeedHot) % 8 == 0, "SeedHot must fit one wave-wide 8-byte load");
 

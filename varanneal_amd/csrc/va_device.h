@@ -5,6 +5,7 @@
 #include "va_core.h"
 #include "va_tile2.h"
 #include "va_tile3.h"
+#include "va_tile4.h"
 
 namespace va {
 
@@ -12,9 +13,14 @@ constexpr int EVAL_THREADS = 256;    // 4 waves per workgroup
 constexpr int VEC_THREADS = 256;
 constexpr int VEC_CHUNK = 1024;      // elements of a seed's vector per workgroup (2 x double2 per lane)
 
+// what the last-arriving wave of an evaluation does with the seed's partial sums (va_epilogue.h)
+enum { EPI_NONE = 0, EPI_FINALIZE = 1, EPI_LS = 2 };
+
 // Everything a kernel needs, passed by value as the kernel argument.
 struct Dev {
     Dims dm;
+    Geo4 g4;                       // wave-private column-run geometry (emode 4)
+    int epi;                       // EPI_*: tail folded into the evaluation kernel
     ProblemPtrs pp;
     Opts o;
     // per-seed vectors, stride dm.ld (multiple of 16 doubles -> 128-byte aligned rows)
@@ -34,6 +40,7 @@ struct Dev {
     long long *nfev;               // [B][max_beta]
     double *minpaths;              // NULL or [B][max_beta][ND+NP]
     int *n_active;
+    unsigned *cnt_eval, *cnt_upd, *cnt_dir;   // [B] arrival counters of the three kernels of a cycle (zero between launches)
     unsigned long long *n_evals;   // seed-evaluations consumed by k_ls since create
     // S1 outputs
     double *outA, *outme, *outfe;  // [B]
@@ -43,11 +50,12 @@ struct Dev {
 void launch_eval(const Dev &dv, int rhs, hipStream_t s);
 void launch_ls(const Dev &dv, hipStream_t s);
 void launch_update(const Dev &dv, hipStream_t s);
-void launch_coeffs(const Dev &dv, hipStream_t s);
 void launch_direction(const Dev &dv, hipStream_t s);
 void launch_init_states(const Dev &dv, int phase, double rf_scale_or_neg, hipStream_t s);
 void launch_finalize_eval(const Dev &dv, hipStream_t s);
-size_t eval_lds_bytes(const Dims &dm);
+size_t eval_lds_bytes(const Dev &dv);
+size_t update_lds_bytes(const Dims &dm);
+hipError_t prepare_eval(const Dev &dv, int rhs);   // once per handle: opt the kernel in to > 64 KiB of LDS on this device
 int eval_grid(const Dims &dm);
 
 }  // namespace va

@@ -8,6 +8,14 @@
 namespace va {
 
 // ------------------------------------------------------------------ helpers
+// order LDS accesses of ONE wave (its lanes exchange data through LDS; LDS is in order within a wave)
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Cross-lane reductions without LDS round trips.  Inside a row of 16 lanes the exchanges are DPP
 // moves (row_mirror: i <-> 15-i, row_half_mirror: i <-> 7-i, quad_perm for xor 2 / xor 1): every
 // step pairs groups that were disjoint so far, so after four steps each lane holds its row's
@@ -60,11 +68,15 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwork)
     return (bid & 7) * per + (bid >> 3);
 }
 
+}  // namespace va
+#include "va_epilogue.h"
+namespace va {
+
 // ------------------------------------------------------------------ K1: eval
 template <class RHS, int DISC>
 __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
 {
-    extern __shared__ double smem[];
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     const Dims &dm = dv.dm;
     const int nwork = dm.B * dm.ntiles;
     const int w = xcd_swizzle(blockIdx.x, nwork);
@@ -111,12 +123,16 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
         if (lane == 0) red[wave * K + k] = v;
     }
     __syncthreads();
+    if (wave != 0) return;
     if (tid < K) {
         double v = red[tid];
         for (int ww = 1; ww < nw; ++ww)
             v = (tid == EP_GMAX) ? fmax(v, red[ww * K + tid]) : v + red[ww * K + tid];
-        dv.evp[((size_t)b * dm.ntiles + tile) * EP_N + tid] = v;
+        st_sc1(dv.evp + ((size_t)b * dm.ntiles + tile) * EP_N + tid, v);
     }
+    // the workgroup that completes the seed's partial rows forms A / runs the line-search step
+    if (dv.epi != EPI_NONE && arrive_last(dv.cnt_eval + b, (unsigned)dm.nprow, lane))
+        eval_epilogue<true>(dv, b, lane, reinterpret_cast<SeedHot *>(red), dv.epi);
 }
 
 // LDS bytes / grid of the flat-mapped kernel
@@ -128,21 +144,27 @@ inline size_t eval_flat_lds_bytes(const Dims &dm)
 }
 inline int eval_flat_grid(const Dims &dm) { return ((dm.B * dm.ntiles + 7) / 8) * 8; }
 
+// wide states: opt the kernel in to the CU's full LDS on the CURRENT device (the attribute is per
+// device; called once per problem handle, va_problem_create)
+template <class RHS>
+inline hipError_t prepare_eval_rhs(const Dev &dv)
+{
+    if (eval_flat_lds_bytes(dv.dm) <= 64 * 1024) return hipSuccess;
+    const void *k = nullptr;
+    switch (dv.dm.disc) {
+    case DISC_EULER: k = (const void *)k_eval<RHS, DISC_EULER>; break;
+    case DISC_TRAPEZOID: k = (const void *)k_eval<RHS, DISC_TRAPEZOID>; break;
+    case DISC_SH: k = (const void *)k_eval<RHS, DISC_SH>; break;
+    default: k = (const void *)k_eval<RHS, DISC_FWDMAP>; break;
+    }
+    return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 template <class RHS>
 inline void launch_eval_rhs(const Dev &dv, hipStream_t s)
 {
     const dim3 grid(eval_flat_grid(dv.dm)), block(EVAL_THREADS);
     const size_t lds = eval_flat_lds_bytes(dv.dm);
-    if (lds > 64 * 1024) {                                   // wide states: opt in to the CU's full LDS
-        static bool done = false;                            // per RHS instantiation
-        if (!done) {
-            (void)hipFuncSetAttribute((const void *)k_eval<RHS, DISC_EULER>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_eval<RHS, DISC_TRAPEZOID>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_eval<RHS, DISC_SH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_eval<RHS, DISC_FWDMAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            done = true;
-        }
-    }
     switch (dv.dm.disc) {
     case DISC_EULER: hipLaunchKernelGGL((k_eval<RHS, DISC_EULER>), grid, block, lds, s, dv); break;
     case DISC_TRAPEZOID: hipLaunchKernelGGL((k_eval<RHS, DISC_TRAPEZOID>), grid, block, lds, s, dv); break;

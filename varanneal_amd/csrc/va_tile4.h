@@ -1,0 +1,286 @@
+// va_tile4.h -- "wave-private column runs": the production mapping of the evaluation kernel for
+// narrow states (even D <= 64 that fill a wave well, e.g. Lorenz-96 D = 20 of the reference's
+// example and of BASELINE configs 1-3).
+//
+// A wave owns RW = floor(64 / D) column runs: lane = a*D + tx holds state column tx of the K
+// consecutive time rows r0 = n0w + a*K .. r0+K-1.  Nothing is shared between the waves of a
+// workgroup -- no workgroup barrier anywhere in the kernel:
+//   stage    the wave copies ITS rows [n0w-HL, n0w+RW*K+HR) of x global -> LDS with direct-to-LDS
+//            loads (global_load_lds_dwordx4: no VGPRs, no ds_write pass).  The LDS image is the
+//            global row-major layout with P doubles of padding after every K-row run, placed by
+//            the per-lane SOURCE address (the LDS side of such a load is lane-linear); with
+//            (K*D + P) == D (mod 32) lane l reads LDS double-bank l (mod 32): conflict-free;
+//   rows     each lane pulls its column and the stencil's neighbour columns (cyclic wrap folded
+//            into three per-lane base addresses: no ghost columns) for K+HL+HR rows, evaluates f,
+//            the residuals, q, direct_m and s_m in registers;
+//   scatter  instead of handing s to the neighbours (who would need x again), the lane forms the
+//            adjoint PRODUCTS s_i * df_i/dx_j of its own element and publishes those (va_core.h
+//            header: dA/dx_m = direct_m + J_m^T s_m); Lorenz-96 needs two per element
+//            (u = s (x_{i+1} - x_{i-2}), v = s x_{i-1});
+//   gather   (J^T s)_j = -s_j + u_{j+1} + v_{j-1} - v_{j+2} from the same wave's products (LDS is
+//            in order within a wave: no barrier), measurement term, gradient store, partial sums.
+// Arithmetic restated from the reference: see va_core.h.  Shared with tests/cpu_emul.
+#pragma once
+#include "va_tile3.h"
+
+namespace va {
+
+// Lorenz-96 in scatter form: f_i = x_{i-1}(x_{i+1} - x_{i-2}) - x_i + k  (cyclic)
+// (examples/Lorenz96_D20/Lorenz96_anneal.py:15-16)
+struct RhsL96s {
+    static constexpr int NP = 1;
+    static constexpr int NB = 3;                       // neighbour columns f reads
+    static VA_HD constexpr int nb_off(int k) { return k == 0 ? -2 : (k == 1 ? -1 : 1); }
+    static constexpr int NE = 2;                       // products published per element
+    static constexpr int NG = 3;                       // products gathered per element
+    static VA_HD constexpr int g_e(int t) { return t == 0 ? 0 : 1; }                   // which product
+    static VA_HD constexpr int g_off(int t) { return t == 0 ? 1 : (t == 1 ? -1 : 2); } // sender column - own column
+    static VA_HD double f(double x0, const double *xn, const double *p, double, const double *)
+    {
+        return xn[1] * (xn[2] - xn[0]) - x0 + p[0];
+    }
+    // e[0] = s df_i/dx_{i-1},  e[1] = s df_i/dx_{i+1} = -s df_i/dx_{i-2}
+    static VA_HD void scatter(double s, double, const double *xn, const double *, double, const double *, double *e)
+    {
+        e[0] = s * (xn[2] - xn[0]);
+        e[1] = s * xn[1];
+    }
+    // sum_i s_i df_i/dx_j for the own column j: diagonal term + received products r[0..NG)
+    static VA_HD double gather(double s, double, const double *, const double *, double, const double *, const double *r)
+    {
+        return (r[0] - s) + (r[1] - r[2]);
+    }
+    static VA_HD void pgrad(double s, double, const double *, const double *, double, const double *, double *acc) { acc[0] += s; }
+};
+
+// ------------------------------------------------------------------ geometry
+struct Geo4 {
+    int D, K, RW, NW, T;          // T = rows per workgroup = NW*RW*K
+    int P, PITCH;                 // doubles of padding per run, run pitch
+    int PP, KDP;                  // pieces (16 B) per run pitch / per K rows
+    int XP;                       // pieces of one wave's x image
+    int XW, EW1, R2;              // doubles: x image, one product array, second region (products / d image)
+    int WAVE;                     // doubles of LDS per wave (x image + second region + reduction strip)
+    unsigned magic;               // floor(q / PP) == (q * magic) >> 20 for q < 4096
+};
+constexpr int T4_STRIP = 4 * 32;  // [4 rows of 16 lanes][up to 32 values]
+constexpr int T4_NI_MAX = 6;      // direct-to-LDS instructions per wave image when D is a run-time value
+
+VA_HD constexpr bool tile4_ok(int D) { return D >= 4 && D <= 64 && (D & 1) == 0 && (64 / D) * D >= 48; }
+
+template <int HLR>
+VA_HD constexpr Geo4 tile4_geo(int D, int K, int NE, int NW = 4)
+{
+    Geo4 g{};
+    g.D = D; g.K = K; g.RW = 64 / D; g.NW = NW; g.T = NW * g.RW * K;
+    g.P = ((D - K * D) % 32 + 32) % 32;
+    g.PITCH = K * D + g.P;
+    g.PP = g.PITCH / 2; g.KDP = K * D / 2;
+    g.XP = g.RW * g.PP + HLR * D / 2;
+    g.XW = ((2 * g.XP + 15) / 16) * 16;
+    g.EW1 = g.RW * g.PITCH;
+    const int e = NE * g.EW1;
+    g.R2 = (((e > g.XW ? e : g.XW) + 15) / 16) * 16;
+    g.WAVE = g.XW + g.R2 + T4_STRIP;
+    g.magic = (unsigned)((1u << 20) / (unsigned)g.PP + 1u);
+    return g;
+}
+// (host) the magic multiplier must reproduce the division for every piece index the kernel forms
+inline bool tile4_magic_ok(const Geo4 &g)
+{
+    for (unsigned q = 0; q < 4096; ++q)
+        if (((q * g.magic) >> 20) != q / (unsigned)g.PP) return false;
+    return true;
+}
+
+// LDS piece q of a wave's image -> source piece relative to the wave's first staged row
+// (n0w - HL), or -1 beyond the image.  Pad pieces repeat the run's last piece.
+VA_HD int tile4_src_piece(const Geo4 &g, int q)
+{
+    if (q >= g.XP) return -1;
+    const int blk = (int)(((unsigned)q * g.magic) >> 20);
+    const int rem = q - blk * g.PP;
+    const int in = (blk < g.RW && rem > g.KDP - 1) ? g.KDP - 1 : rem;
+    return blk * g.KDP + in;
+}
+// double offset of staged row R (0 = n0w - HL) of a wave's image, column 0
+VA_HD constexpr int tile4_row(const Geo4 &g, int R) { return (R / g.K) * g.PITCH + (R % g.K) * g.D; }
+
+template <int K, int NE> struct T4Regs {
+    double direct[K], sown[K], xown[K], yv[K], wv[K], dval[K];
+};
+
+struct Tile4 {
+    int n0w, a, tx, r0, use_d, l;   // first owned row of the wave, run, column, first owned row of the lane
+    double c;
+    const double *xs;               // LDS: the wave's x image
+    double *es;                     // LDS: the wave's product arrays [NE][RW*PITCH]
+    double *gtg;
+    double p[RHS_MAX_NP];
+};
+
+VA_HD int wrap_col(int c, int D) { c += c < 0 ? D : 0; c -= c >= D ? D : 0; return c; }
+
+// observations / weights of the lane's own rows (as tile3_obs, with the observed index from lmap:
+// Lidx may come in any order, va_ode.py:141)
+template <int K, int NE>
+VA_HD void tile4_obs(const Dims &dm, const ProblemPtrs &pp, const Tile4 &t, T4Regs<K, NE> &rg)
+{
+    if (dm.nskip == 1) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int m = t.r0 + k;
+            const bool ok = t.l >= 0 && m < dm.N;
+            const size_t idx = ok ? (size_t)m * dm.L + t.l : 0;
+            rg.yv[k] = pp.Y[idx];
+            rg.wv[k] = ok ? dm.rm : 0.0;
+        }
+        if (pp.rm_arr) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int m = t.r0 + k;
+                const bool ok = t.l >= 0 && m < dm.N;
+                rg.wv[k] = ok ? pp.rm_arr[(size_t)m * dm.L + t.l] : 0.0;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        rg.yv[k] = 0.0; rg.wv[k] = 0.0;
+        const int m = t.r0 + k;
+        if (t.l >= 0 && m < dm.N) {
+            const int nd = m / dm.nskip;
+            if (nd * dm.nskip == m && nd < dm.N_data) {
+                rg.yv[k] = pp.Y[(size_t)nd * dm.L + t.l];
+                rg.wv[k] = pp.rm_arr ? pp.rm_arr[(size_t)nd * dm.L + t.l] : dm.rm;
+            }
+        }
+    }
+}
+
+// rows + scatter: f, residuals, q, direct, s for the lane's run in registers; publishes the products
+template <class RHS, int DISC, int K, bool EDGE, int DC>
+VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, const Tile4 &t,
+                      T4Regs<K, RHS::NE> &rg, ThreadAcc &acc)
+{
+    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, NR = K + HL + HR, NQ = K + HL, NB = RHS::NB, NE = RHS::NE;
+    const int D = DC > 0 ? DC : g.D, N = dm.N, PITCH = g.PITCH;
+    const double dt = dm.dt;
+    // the lane's first needed row r0-HL is staged row a*K of the wave's image
+    const double *x0p = t.xs + t.a * PITCH + t.tx;
+    const double *xnp[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) xnp[k] = t.xs + t.a * PITCH + wrap_col(t.tx + RHS::nb_off(k), D);
+    double xo[NR], fo[NR], q[NQ], w[NQ];
+    double xnb[K][NB];                                   // neighbour values of the own rows (for the products)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int off = j < K ? j * D : PITCH + (j - K) * D;
+        double xn[NB];
+        xo[j] = x0p[off];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) xn[k] = xnp[k][off];
+        const int row = t.r0 - HL + j;
+        const bool ok = !EDGE || (row >= 0 && row < N);
+        // staged rows that do not exist hold whatever lies next to the path in memory: never let it through
+        if (EDGE && !ok) { xo[j] = 0.0; for (int k = 0; k < NB; ++k) xn[k] = 0.0; }
+        fo[j] = RHS::f(xo[j], xn, t.p, 0.0, nullptr);
+        if (EDGE && !ok) fo[j] = 0.0;
+        if (j >= HL && j < HL + K) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) xnb[j - HL][k] = xn[k];
+        }
+    }
+    if (pp.rf0_arr) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            int row = t.r0 - HL + j;
+            row = row < 0 ? 0 : (row > N - 2 ? N - 2 : row);            // clamped; r = 0 there anyway
+            w[j] = pp.rf0_arr[(size_t)row * D + t.tx];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) w[j] = dm.rf0;
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int row = t.r0 - HL + j;
+        double r = 0.0;
+        bool have = true;
+        if constexpr (DISC == DISC_SH) {
+            const int je = (j & 1) ? j - 1 : j;
+            if ((j & 1) == 0) {
+                if (EDGE) have = row >= 0 && row + 2 <= N - 1;
+                r = xo[je + 2] - xo[je] - (fo[je] + 4.0 * fo[je + 1] + fo[je + 2]) * (dt / 3.0);
+            } else {
+                if (EDGE) have = row >= 1 && row + 1 <= N - 1;
+                r = xo[je + 1] - (0.5 * (xo[je] + xo[je + 2]) + (fo[je] - fo[je + 2]) * (dt / 4.0));
+            }
+        } else {
+            if (EDGE) have = row >= 0 && row <= N - 2;
+            if constexpr (DISC == DISC_TRAPEZOID) r = xo[j + 1] - xo[j] - (0.5 * dt) * (fo[j] + fo[j + 1]);
+            else if constexpr (DISC == DISC_EULER) r = xo[j + 1] - xo[j] - dt * fo[j];
+            else r = xo[j + 1] - fo[j];
+        }
+        if (EDGE && !have) r = 0.0;
+        const double wr = w[j] * r;
+        q[j] = t.c * wr;
+        if (j >= HL) acc.v[EP_FE] += wr * r;
+    }
+    double *ep = t.es + t.a * PITCH + t.tx;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int j = k + HL;
+        double direct, s;
+        if constexpr (DISC == DISC_TRAPEZOID) { direct = q[j - 1] - q[j]; s = -0.5 * dt * (q[j - 1] + q[j]); }
+        else if constexpr (DISC == DISC_EULER) { direct = q[j - 1] - q[j]; s = -dt * q[j]; }
+        else if constexpr (DISC == DISC_FWDMAP) { direct = q[j - 1]; s = -q[j]; }
+        else {
+            const int je = (k & 1) ? j - 1 : j;
+            if ((k & 1) == 0) {
+                direct = -q[je] - 0.5 * q[je + 1] + q[je - 2] - 0.5 * q[je - 1];
+                s = -(dt / 3.0) * (q[je] + q[je - 2]) - (dt / 4.0) * (q[je + 1] - q[je - 1]);
+            } else { direct = q[je + 1]; s = -(4.0 * dt / 3.0) * q[je]; }
+        }
+        if (EDGE && t.r0 + k >= N) { direct = 0.0; s = 0.0; }
+        rg.direct[k] = direct; rg.sown[k] = s; rg.xown[k] = xo[j];
+        double e[NE];
+        RHS::scatter(s, xo[j], xnb[k], t.p, 0.0, nullptr, e);
+        RHS::pgrad(s, xo[j], xnb[k], t.p, 0.0, nullptr, acc.v + EP_GP);
+#pragma unroll
+        for (int u = 0; u < NE; ++u) ep[u * g.EW1 + k * D] = e[u];
+    }
+}
+
+// gather: gradient rows of the lane's run
+template <class RHS, int DISC, int K, bool EDGE, int DC>
+VA_HD void tile4_grad(const Dims &dm, const Geo4 &g, const Tile4 &t, const T4Regs<K, RHS::NE> &rg, ThreadAcc &acc)
+{
+    constexpr int NG = RHS::NG;
+    const int D = DC > 0 ? DC : g.D;
+    const double *rp[NG];
+#pragma unroll
+    for (int u = 0; u < NG; ++u) rp[u] = t.es + RHS::g_e(u) * g.EW1 + t.a * g.PITCH + wrap_col(t.tx + RHS::g_off(u), D);
+    const double two_cme = 2.0 * dm.cme;
+    double gmax = acc.v[EP_GMAX];
+    double *gout = t.gtg + (long)t.r0 * D + t.tx;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double r[NG];
+#pragma unroll
+        for (int u = 0; u < NG; ++u) r[u] = rp[u][k * D];
+        double gv = rg.direct[k] + RHS::gather(rg.sown[k], rg.xown[k], nullptr, t.p, 0.0, nullptr, r);
+        const double diff = rg.xown[k] - rg.yv[k];
+        const double wd = rg.wv[k] * diff;
+        acc.v[EP_ME] += wd * diff;
+        gv += two_cme * wd;
+        if (!EDGE || t.r0 + k < dm.N) gout[k * D] = gv; else gv = 0.0;
+        acc.v[EP_GTD] += gv * rg.dval[k];
+        acc.v[EP_GN2] += gv * gv;
+        gmax = __builtin_fmax(gmax, __builtin_fabs(gv));
+    }
+    acc.v[EP_GMAX] = gmax;
+}
+
+}  // namespace va

@@ -28,4 +28,10 @@ void va_user_launch_eval(const va::Dev *dv, void *stream)
     va::launch_eval_rhs<va::RhsUser>(*dv, (hipStream_t)stream);
 }
 
+// once per problem handle, on the handle's device: opt the kernel in to the LDS it needs
+int va_user_prepare_eval(const va::Dev *dv)
+{
+    return (int)va::prepare_eval_rhs<va::RhsUser>(*dv);
+}
+
 }  // extern "C"
