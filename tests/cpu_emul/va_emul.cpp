@@ -50,7 +50,9 @@ int setup(const va_problem_desc *d, int T, Emul &E)
         int K = (T + rows1 - 1) / rows1;
         K = K < 4 ? 4 : (K > 8 ? 8 : K);
         if (m.disc == DISC_SH && (K & 1)) ++K;
-        E.g4 = m.disc == DISC_SH ? tile4_geo<3>(m.D, K, RhsL96s::NE) : tile4_geo<2>(m.D, K, RhsL96s::NE);
+        const char *se = getenv("VA_EMUL_SUB");            // sub-tiles per wave (the device picks 1..3, va_capi.hip)
+        const int SUB = se ? atoi(se) : 1;
+        E.g4 = m.disc == DISC_SH ? tile4_geo<3>(m.D, K, RhsL96s::NE, SUB) : tile4_geo<2>(m.D, K, RhsL96s::NE, SUB);
         if ((E.g4.XP + 63) / 64 > T4_NI_MAX || !tile4_magic_ok(E.g4)) return VA_EUNSUPPORTED;
         m.RY = 4 * (64 / m.D); m.NT = 256; m.maxr = K; T = E.g4.T;
     }
@@ -207,8 +209,8 @@ void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_
     std::vector<double> xs(g.XW), r2(g.R2);
     for (int k = 0; k < EP_N; ++k) ev[k] = 0.0;
     for (int tile = 0; tile < dm.ntiles; ++tile)
-        for (int wave = 0; wave < g.NW; ++wave) {
-            const int n0w = tile * g.T + wave * g.RW * K;
+        for (int ws_ = 0; ws_ < g.NW * g.SUB; ++ws_) {    // (wave, sub-tile): a wave's sub-tiles are consecutive
+            const int n0w = tile * g.T + ws_ * g.RW * K;
             const long src0 = guard + (long)(n0w - HL) * D;
             for (int q = 0; q < T4_NI_MAX * 64; ++q) {
                 const int sp = tile4_src_piece(g, q);
@@ -227,6 +229,7 @@ void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_
                 Tile4 &c = th[l];
                 c.n0w = n0w; c.a = l / D; c.tx = l % D; c.r0 = n0w + c.a * K; c.use_d = use_d;
                 c.l = E.lmap[c.tx]; c.c = 2.0 * rf_scale * dm.cfe;
+                c.wobs = c.l >= 0 ? dm.rm : 0.0;
                 c.xs = xs.data(); c.es = r2.data(); c.gtg = gt;
                 Tile2 tmp; tmp.xg = x; tmp.dg = d; tmp.use_d = use_d; tmp.stp = stp;
                 tile2_params<RhsL96c>(dm, E.pp, b, tmp);
@@ -238,13 +241,30 @@ void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_
                     rg[l].dval[k] = (use_d && c.r0 + k < dm.N) ? d[gi] : 0.0;
                 }
             }
+            // the device picks the scalar-weight variant exactly like this (va_kernels.hip: eval4_d)
+            const bool ws = !E.pp.rm_arr && !E.pp.rf0_arr && dm.nskip == 1;
             for (int l = 0; l < NL; ++l) {
-                if (edge) tile4_rows<RHS, DISC, K, true, 0>(dm, E.pp, g, th[l], rg[l], acc[l]);
-                else tile4_rows<RHS, DISC, K, false, 0>(dm, E.pp, g, th[l], rg[l], acc[l]);
+                if (ws) {
+                    if (edge) tile4_rows<RHS, DISC, K, true, 0, true>(dm, E.pp, g, th[l], rg[l], acc[l]);
+                    else tile4_rows<RHS, DISC, K, false, 0, true>(dm, E.pp, g, th[l], rg[l], acc[l]);
+                } else {
+                    if (edge) tile4_rows<RHS, DISC, K, true, 0, false>(dm, E.pp, g, th[l], rg[l], acc[l]);
+                    else tile4_rows<RHS, DISC, K, false, 0, false>(dm, E.pp, g, th[l], rg[l], acc[l]);
+                }
             }
             for (int l = 0; l < NL; ++l) {
-                if (edge) tile4_grad<RHS, DISC, K, true, 0>(dm, g, th[l], rg[l], acc[l]);
-                else tile4_grad<RHS, DISC, K, false, 0>(dm, g, th[l], rg[l], acc[l]);
+                double gvv[K];
+                if (ws) {
+                    if (edge) tile4_grad<RHS, DISC, K, true, 0, true, true>(dm, g, th[l], rg[l], acc[l], gvv);
+                    else tile4_grad<RHS, DISC, K, false, 0, true, true>(dm, g, th[l], rg[l], acc[l], gvv);
+                } else {
+                    if (edge) tile4_grad<RHS, DISC, K, true, 0, false, true>(dm, g, th[l], rg[l], acc[l], gvv);
+                    else tile4_grad<RHS, DISC, K, false, 0, false, true>(dm, g, th[l], rg[l], acc[l], gvv);
+                }
+                for (int k = 0; k < K; ++k) {
+                    if (th[l].r0 + k < dm.N) gt[(long)(th[l].r0 + k) * D + th[l].tx] = gvv[k];
+                    else if (gvv[k] != 0.0) abort();          // rows that do not exist must come out as exact zeros
+                }
             }
             for (int l = 0; l < NL; ++l)
                 for (int k = 0; k < EP_N; ++k) {

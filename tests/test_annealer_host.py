@@ -328,3 +328,21 @@ def test_admin_surface(fake_device, golden_ladders):
         a.hessianA_taped(XP0)
     with pytest.raises(NotImplementedError):
         a.min_lm_scipy(XP0)
+
+
+def test_integer_alpha_with_a_long_ladder(fake_device, golden_ladders, tmp_path):
+    """RF = RF0 * alpha**beta in float64 whatever the types: beta_array is uint16 (va_ode.py:644) and
+    NumPy 2 would evaluate 2 ** uint16(16) in uint16 (= 0), switching the model term off."""
+    from varanneal_amd._hipmin import alpha_pow
+    assert np.array_equal(alpha_pow(2, np.array([0, 15, 16, 30], np.uint16)), [1.0, 2.0 ** 15, 2.0 ** 16, 2.0 ** 30])
+    c = golden_ladders["g4_c1_trapezoid_N200"]
+    a = _setup(c)
+    beta = np.array([0, 16, 30])
+    a.anneal(c["X0"].copy(), c["P0"].copy(), 2, beta, 4.0, 4e-6, list(c["Lidx"]), [0],
+             dt_model=float(c["t"][1] - c["t"][0]), init_to_data=True, disc="trapezoid",
+             method="L-BFGS-B", opt_args=dict(OPTS, maxiter=3), adolcID=0, verbose=False)
+    assert np.array_equal(a._rf_scale, [1.0, 2.0 ** 16, 2.0 ** 30]) and a.RF == 4e-6 * 2.0 ** 30
+    assert np.all(a.fe_array > 0.0)
+    a.save_action_errors(str(tmp_path / "ae.npy"))
+    ae = np.load(str(tmp_path / "ae.npy"))
+    assert np.all(np.isfinite(ae)) and np.allclose(ae[:, 4], a.fe_array / (4e-6 * 2.0 ** beta))

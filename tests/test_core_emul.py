@@ -21,6 +21,19 @@ def _desc(c, batch=1, eval_kernel=0):
                            merr_nskip=int(c["merr_nskip"]), eval_kernel=eval_kernel)
 
 
+@pytest.mark.parametrize("sub", [2, 3])
+def test_wave_private_tiles_with_several_subtiles_per_wave(golden_single, sub, monkeypatch):
+    """k_eval4 with SUB sub-tiles per wave (one wave per SIMD on small grids): same results."""
+    monkeypatch.setenv("VA_EMUL_SUB", str(sub))
+    for name, c in golden_single.items():
+        desc, keep = _desc(c, eval_kernel=4)
+        for T in (72, 84):
+            A, me, fe, g = emul.action_grad(desc, T, c["XP"][None, :], c["rf_scale"])
+            assert abs(A[0] - c["A"]) <= 1e-12 * abs(c["A"]), (name, T)
+            if "grad" in c:
+                assert np.abs(g[0] - c["grad"]).max() <= 1e-11 * np.abs(c["grad"]).max(), (name, T)
+
+
 @pytest.mark.parametrize("eval_kernel", [1, 3, 4])
 def test_tile_phases_match_golden_for_every_tiling(golden_single, eval_kernel):
     """flat-mapped (va_core.h), column-run (va_tile3.h) and wave-private column-run (va_tile4.h)

@@ -75,6 +75,30 @@ def test_timed_evaluation_is_a_complete_evaluation(capi, golden_single, eval_ker
     assert abs(A[0] - c["A"]) <= RTOL_A * abs(c["A"])
 
 
+@pytest.mark.parametrize("D,N,B,disc", [(20, 1000, 64, "trapezoid"), (4, 38, 4, "forwardmap"), (20, 161, 3, "SimpsonHermite"),
+                                        (200, 300, 8, "trapezoid")])
+def test_repeated_evaluations_are_bitwise_identical(capi, D, N, B, disc):
+    """The tail of an evaluation is run by whichever workgroup of a seed arrives last, from rows the
+    others published: thousands of launches of the same evaluation must leave the same bits (a
+    stale or missing row, or a counter that did not reset, would show up here)."""
+    from varanneal_amd import twin
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    rng = np.random.RandomState(D + N)
+    XP = np.concatenate([3.0 * rng.randn(B, N * D), 6.0 + 3.0 * rng.rand(B, 1)], axis=1)
+    P = XP[:, -1:].copy()
+    with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc=disc) as pb:
+        A, me, fe, g = pb.action_grad(XP, 37.0)
+        for rep in range(40):
+            pb.eval_timed(37.0, 50)
+            A2, me2, fe2, g2 = pb.read_eval_outputs()
+            assert np.array_equal(A, A2) and np.array_equal(me, me2) and np.array_equal(fe, fe2), rep
+            assert np.array_equal(g, g2), rep
+        for rep in range(100):
+            A3, me3, fe3, g3 = pb.action_grad(XP, 37.0, want_grad=(rep % 10 == 0))
+            assert np.array_equal(A, A3) and np.array_equal(fe, fe3), rep
+            assert g3 is None or np.array_equal(g, g3), rep
+
+
 @pytest.mark.parametrize("eval_kernel", [1, 3, 4])
 def test_lidx_in_any_order(capi, eval_kernel):
     """data column l pairs with state column Lidx[l] whatever the order of Lidx (va_ode.py:141)."""

@@ -16,6 +16,6 @@ for p in sorted(glob.glob("gpurun_out/pmc_$tag/p*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(p)):
         k=r["Kernel_Name"][:40]; acc[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[(k,r["Counter_Name"])]+=1
     for k,v in acc.items():
-        if "eval" in k:
+        if "eval" in k or "update" in k or "direction" in k:
             print(p.split("/")[2], k, {c: round(x/cnt[(k,c)],1) for c,x in v.items()})
 PY

@@ -1,14 +1,16 @@
-"""Per-workgroup timeline of the C3 eval kernel (profiling only): VA_DEBUG_EVAL=16 makes every
-workgroup of k_eval3 record wall_clock64 at start / after staging / after phase B / after the
-stores are issued / after they are acknowledged, plus its HW_ID and XCC_ID."""
+"""Per-wave timeline of the C3 evaluation kernel (profiling only).  Needs the diagnostic library
+(python -m varanneal_amd._build --stamps; run with VARANNEAL_AMD_LIB=.../libvaranneal_amd_stamps.so):
+every wave of k_eval4 records wall_clock64 (100 MHz) at
+  0 start | 1 loads issued (wave 0 of a seed's last workgroup: tail done) | 2 image landed | 3 rows+scatter done
+  4 gather done, stores issued | 5 partial sums in LDS | 6 past the workgroup barrier | 7 (wave 0) arrival returned"""
 import os
 import sys
 
 import numpy as np
 
-os.environ["VA_DEBUG_EVAL"] = "16"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("VARANNEAL_AMD_LIB", os.path.join(ROOT, "varanneal_amd", "libvaranneal_amd_stamps.so"))
 import bench  # noqa: E402
 from varanneal_amd import _capi, twin  # noqa: E402
 
@@ -16,29 +18,30 @@ D, N, B = 20, 1000, 64
 Y, Lidx, XP, P = bench.make_inputs(D, N, B, 0)
 pb = _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid")
 info = pb.info()
-nwg = ((B * info["ntiles"] + 7) // 8) * 8
+nwg = ((B * info["ntiles"] + 7) // 8) * 8   # (workgroups: 256 with three sub-tiles per wave)
 pb.action_grad(XP, bench.RF_SCALE)
+pb.eval_timed(bench.RF_SCALE, 20)
+names = ["start", "issued", "landed", "rows", "gather", "sums", "barrier", "arrived"]
 for rep in range(3):
     pb.eval_timed(bench.RF_SCALE, 1)
-    raw = pb.debug_partials(nwg * 8).view(np.uint64).reshape(nwg, 8)
-    t = raw[:, :5].astype(np.int64)
-    t0 = t[:, 0].min()
-    tick = 1e-2                                   # wall_clock64: 100 MHz -> 10 ns
-    st, ld, rows, issued, done = [(t[:, k] - t0) * tick for k in range(5)]
-    hw = raw[:, 5]; cu = (hw >> 8) & 0xF; se = (hw >> 13) & 0x7; xcc = raw[:, 6] & 0xF
-    key = xcc * 1000 + se * 16 + cu
-    uniq, cnt = np.unique(key, return_counts=True)
-    print("rep %d: %d workgroups on %d distinct (xcc,se,cu); per-CU count min/max %d/%d" % (rep, nwg, len(uniq), cnt.min(), cnt.max()))
-    for name, a in (("start", st), ("staged", ld), ("rows done", rows), ("stores issued", issued), ("stores acked", done)):
-        print("   %-14s min %6.2f  median %6.2f  p90 %6.2f  max %6.2f us" % (name, a.min(), np.median(a), np.percentile(a, 90), a.max()))
-    print("   phase medians: stage %.2f  rows %.2f  grad+issue %.2f  ack %.2f us" % (
-        np.median(ld - st), np.median(rows - ld), np.median(issued - rows), np.median(done - issued)))
-    grp = (np.arange(nwg) >> 8) % 3          # a CU holds blockIdx b, b+256, b+512: dispatch order
+    raw = pb.debug_partials(nwg * 4 * 8).view(np.uint64).reshape(nwg, 4, 8).astype(np.int64)
+    t0 = raw[:, :, 0].min()
+    us = (raw - t0) * 1e-2
+    w0 = us[:, 0, :]
+    print("rep %d: %d workgroups" % (rep, nwg))
+    for k in (0, 2, 3, 4, 5, 6):
+        a = us[:, :, k]
+        print("   %-8s all waves: min %5.2f  median %5.2f  p90 %5.2f  max %5.2f us" % (names[k], a.min(), np.median(a), np.percentile(a, 90), a.max()))
+    a = w0[:, 7]
+    print("   %-8s wave 0   : min %5.2f  median %5.2f  p90 %5.2f  max %5.2f us" % (names[7], a.min(), np.median(a), np.percentile(a, 90), a.max()))
+    tail = w0[:, 1]
+    tail = tail[tail > w0[:, 7]]
+    print("   tail done (last workgroup of each seed, %d): min %5.2f median %5.2f max %5.2f us" % (len(tail), tail.min(), np.median(tail), tail.max()))
+    d = np.diff(us[:, :, [0, 2, 3, 4, 5, 6]], axis=2)
+    print("   phase medians: wait-for-image %.2f  rows %.2f  gather %.2f  sums %.2f  barrier %.2f" % tuple(np.median(d[:, :, i]) for i in range(5)))
+    grp = (np.arange(nwg) >> 8) % 3
     for gi in range(3):
         m = grp == gi
-        print("   blockIdx group %d: start %.2f  stage %.2f  rows %.2f  grad %.2f  end %.2f" % (
-            gi, np.median(st[m]), np.median((ld - st)[m]), np.median((rows - ld)[m]), np.median((issued - rows)[m]), np.median(done[m])))
-    if rep == 2:
-        for k in uniq[:4]:
-            print("   CU", k, "holds blockIdx", np.nonzero(key == k)[0])
+        print("   blockIdx group %d: start %.2f landed %.2f rows %.2f gather %.2f barrier %.2f" % (
+            gi, np.median(us[m, :, 0]), np.median(us[m, :, 2]), np.median(us[m, :, 3]), np.median(us[m, :, 4]), np.median(us[m, :, 6])))
 pb.close()

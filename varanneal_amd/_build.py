@@ -23,6 +23,16 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_stamps(verbose=True):
+    """Diagnostic library with in-kernel wall-clock stamps (tools/timeline.py); never the product."""
+    out = os.path.join(HERE, "libvaranneal_amd_stamps.so")
+    cmd = [HIPCC] + FLAGS + ["-DVA_STAMPS", "-o", out] + [os.path.join(CSRC, f) for f in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
@@ -34,4 +44,7 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--stamps" in sys.argv:
+        build_stamps()
+    else:
+        build(force="--force" in sys.argv)

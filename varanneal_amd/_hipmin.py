@@ -9,6 +9,13 @@ around the device evaluator exactly as upstream calls it."""
 import numpy as np
 
 
+def alpha_pow(alpha, beta):
+    """alpha**beta as the reference's legacy NumPy evaluated it (va_ode.py:650,782): in float64.
+    beta_array is cast to uint16 upstream (va_ode.py:644); under NumPy 2 an integer alpha raised to a
+    uint16 array stays uint16 and wraps (2**16 -> 0), which would switch the model term off."""
+    return np.power(np.float64(alpha), np.asarray(beta, dtype=np.float64))
+
+
 class HIPmin(object):
     def tape_A(self, xtrace=None):
         """_autodiffmin.py:32-49: nothing to record (RF is a kernel argument)."""

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -64,6 +65,7 @@ struct va_problem_s {
     void (*user_launch)(const Dev *, void *) = nullptr;
     int (*user_prepare)(const Dev *) = nullptr;
     bool is_nnet = false;              // feed-forward-network action (va_nnet.hip) instead of an ODE path
+    bool fold = false;                 // the evaluation kernel runs the tail itself (last arriver of each seed)
     NnetDev nn;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -93,9 +95,13 @@ namespace {
 // evaluation is several kernels, so its tail stays a launch of its own.
 void run_eval(va_handle h, int epi)
 {
-    if (h->is_nnet) {
+    if (h->is_nnet || !h->fold) {
+        // (large grids: a workgroup that waits for its arrival to come back holds its LDS and wave
+        // slots ~1 us longer, which costs more than the 64-wave tail kernel it saves)
         h->dv.epi = EPI_NONE;
-        launch_nnet_eval(h->dv, h->nn, h->stream);
+        if (h->is_nnet) launch_nnet_eval(h->dv, h->nn, h->stream);
+        else if (h->user_launch) h->user_launch(&h->dv, (void *)h->stream);
+        else launch_eval(h->dv, h->rhs, h->stream);
         if (epi == EPI_FINALIZE) launch_finalize_eval(h->dv, h->stream);
         else if (epi == EPI_LS) launch_ls(h->dv, h->stream);
         return;
@@ -142,7 +148,15 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, bool user_
             K = K < 4 ? 4 : (K > 8 ? 8 : K);
             if (sh && (K & 1)) ++K;
         }
-        g4 = sh ? tile4_geo<3>(D, K, RhsL96s::NE) : tile4_geo<2>(D, K, RhsL96s::NE);
+        // A grid of only a few wave-tiles per SIMD (1024 SIMDs) runs as ONE wave per SIMD working
+        // through SUB sub-tiles in turn (k_eval4): C3 = 3072 wave-tiles -> SUB = 3, 256 workgroups.
+        int SUB = 1;
+        const bool ws = d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1;
+        if (false && D == 20 && ws && (K == 6 || K == 7) && d->tile_rows <= 0) {      // (slower than co-resident waves: see eval4_rhs)
+            const long wtiles = (long)d->batch * ((N + RW * K - 1) / (RW * K));
+            if (wtiles > 1024 && wtiles <= 3 * 1024) SUB = (int)((wtiles + 1023) / 1024);
+        }
+        g4 = sh ? tile4_geo<3>(D, K, RhsL96s::NE, SUB) : tile4_geo<2>(D, K, RhsL96s::NE, SUB);
         if ((g4.XP + 63) / 64 <= T4_NI_MAX && tile4_magic_ok(g4)) {
             dm.RY = 4 * RW; dm.NT = 256; dm.maxr = K; dm.T = g4.T;
             dm.ntiles = (N + dm.T - 1) / dm.T;
@@ -252,7 +266,7 @@ int alloc_solver_state(va_handle h, int max_beta, int keep_paths)
     TRYA(h->alloc(&dv.status, B * max_beta)); TRYA(h->alloc(&dv.nit, B * max_beta));
     TRYA(h->alloc(&dv.nfev, B * max_beta));
     if (keep_paths) TRYA(h->alloc(&dv.minpaths, B * max_beta * (size_t)(dm.ND + dm.NP), false));
-    TRYA(h->alloc(&dv.cnt_eval, B)); TRYA(h->alloc(&dv.cnt_upd, B)); TRYA(h->alloc(&dv.cnt_dir, B));
+    TRYA(h->alloc(&dv.cnt_eval, B * CNT_STRIDE)); TRYA(h->alloc(&dv.cnt_upd, B * CNT_STRIDE)); TRYA(h->alloc(&dv.cnt_dir, B * CNT_STRIDE));
     TRYA(h->alloc(&dv.n_active, 1));
     TRYA(h->alloc(&dv.n_evals, 1));
     TRYA(h->alloc(&dv.outA, B)); TRYA(h->alloc(&dv.outme, B)); TRYA(h->alloc(&dv.outfe, B));
@@ -509,13 +523,25 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     if (tdp) { dm.ND = dm.N * (dm.D + dm.NPe); dm.NP = 0; dm.NPest = 0; }   // one flat run for the L-BFGS kernels
     dm.ld = ((dm.ND + dm.NPest + 15) / 16) * 16;
     pick_eval_geometry(d, dm, dv.g4, user != nullptr);
-    dm.nprow = dm.emode >= 3 ? dm.ntiles * (dm.NT / 64) : dm.ntiles;      // one partial row per wave / per workgroup
+    if (dm.emode == 4 && (unsigned long long)dm.B * dm.ntiles * dm.ntiles >= (1ull << 32)) {
+        va_problem_destroy(h);        // (umulhi by ntiles_magic would no longer be an exact division)
+        return fail(VA_EUNSUPPORTED, "batch x tiles too large for the wave-private kernel: pass eval_kernel=3");
+    }
+    dv.ntiles_magic = (unsigned)(((1ull << 32) + dm.ntiles - 1) / dm.ntiles);
+    {   // fold the tail into the evaluation kernel while the whole grid is resident at once (<= 8 workgroups per CU)
+        const char *e = getenv("VA_FOLD");
+        h->fold = e ? atoi(e) != 0 : (long)dm.B * dm.ntiles <= 8L * 256;
+    }
+    dm.nprow = dm.emode == 3 ? dm.ntiles * (dm.NT / 64) : dm.ntiles;      // one partial row per wave (column-run kernel) / per workgroup
     dm.chunk = VEC_CHUNK; dm.nchunks = (dm.ld + VEC_CHUNK - 1) / VEC_CHUNK;
     dm.dt = d->dt_model;
     dm.cme = d->L > 0 ? 1.0 / ((double)dm.L * dm.N_data) : 0.0;
     dm.cfe = 1.0 / ((double)dm.D * (dm.N - 1));
     dm.rm = d->rm; dm.rf0 = d->rf0;
     dv.ups = UP_OLD + 4 * m; dv.max_beta = max_beta; dv.nbeta = 1;
+    dv.evcols = EP_GP + d->NP <= 8 ? 8 : (EP_GP + d->NP <= 16 ? 16 : 32);
+    { const char *e = getenv("VA_GRAD_SC1"); dv.gaux = e ? atoi(e) : 1; }
+    { const char *e = getenv("VA_PRIO"); dv.prio = e ? atoi(e) : 1; }
     dv.o.m = m; dv.o.maxiter = 15000; dv.o.maxls = 20; dv.o.maxfun = 15000; dv.o.ftol = 2.2204460492503131e-09; dv.o.gtol = 1e-5;
 
     {
@@ -556,15 +582,34 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     if (d->n_stim > 0) TRY(h->alloc(&st_d, (size_t)dm.N * d->n_stim));
     TRY(alloc_solver_state(h, max_beta, d->keep_paths));
 
+    // On the device Lidx is ascending: data column l pairs with state column Lidx[l] in any order
+    // (va_ode.py:141), so sorting Lidx and permuting the columns of Y (and of a weight array) the same
+    // way changes nothing, and the kernels of narrow states find a column's data by counting the
+    // observed columns below it (obsmask) instead of loading a map.
+    std::vector<int> perm(dm.L), lidx_sorted(dm.L);
+    for (int l = 0; l < dm.L; ++l) perm[l] = l;
+    if (d->rm_kind != 2) std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return d->Lidx[a] < d->Lidx[b]; });
+    for (int l = 0; l < dm.L; ++l) lidx_sorted[l] = d->Lidx[perm[l]];
+    std::vector<double> Ys((size_t)dm.N_data * dm.L), rms;
+    for (int n = 0; n < dm.N_data; ++n)
+        for (int l = 0; l < dm.L; ++l) Ys[(size_t)n * dm.L + l] = d->Y[(size_t)n * dm.L + perm[l]];
+    if (d->rm_kind == 1) {
+        rms.resize((size_t)dm.N_data * dm.L);
+        for (int n = 0; n < dm.N_data; ++n)
+            for (int l = 0; l < dm.L; ++l) rms[(size_t)n * dm.L + l] = d->rm_array[(size_t)n * dm.L + perm[l]];
+    }
     std::vector<int> lmap(dm.D, -1);
-    for (int l = 0; l < dm.L; ++l) lmap[d->Lidx[l]] = l;
+    for (int l = 0; l < dm.L; ++l) lmap[lidx_sorted[l]] = l;
+    dm.obsmask = 0ull;
+    if (dm.D <= 64) for (int l = 0; l < dm.L; ++l) dm.obsmask |= 1ull << lidx_sorted[l];
+    dv.dm.obsmask = dm.obsmask;
 #define H2D(dst, src, n, T) do { hipError_t e_ = hipMemcpyAsync(dst, src, sizeof(T) * (n), hipMemcpyHostToDevice, h->stream); \
         if (e_ != hipSuccess) { va_problem_destroy(h); return fail(VA_EHIP, "H2D %s: %s", #dst, hipGetErrorString(e_)); } } while (0)
     H2D(lmap_d, lmap.data(), dm.D, int);
-    H2D(Y_d, d->Y, (size_t)dm.N_data * dm.L, double);
+    H2D(Y_d, Ys.data(), (size_t)dm.N_data * dm.L, double);
     if (dm.NPe) H2D(pidx_d, d->Pidx, dm.NPe, int);
     H2D(P_d, d->P, B * np_seed, double);
-    if (d->rm_kind) H2D(rm_d, d->rm_array, rm_elems, double);
+    if (d->rm_kind) H2D(rm_d, d->rm_kind == 1 ? rms.data() : d->rm_array, rm_elems, double);
     if (d->rm_kind == 2) H2D(lidx_d, d->Lidx, dm.L, int);
     if (d->rf_kind) H2D(rf_d, d->rf0_array, (size_t)(dm.N - 1) * dm.D, double);
     if (d->t_model) H2D(t_d, d->t_model, (size_t)dm.N, double);
@@ -650,6 +695,7 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
     dm.cfe = d->rf0 / ((double)(NDnet - s[0]) * d->M);                    /* va_nnet.py:255 */
     dm.rm = d->rm_in; dm.rf0 = d->rf0;
     dv.ups = UP_OLD + 4 * m; dv.max_beta = max_beta; dv.nbeta = 1;
+    dv.evcols = 8;                 // the network kernels fill EP_ME .. EP_GMAX only
     dv.o.m = m; dv.o.maxiter = 15000; dv.o.maxls = 20; dv.o.maxfun = 15000; dv.o.ftol = 2.2204460492503131e-09; dv.o.gtol = 1e-5;
 
     nn.NL = NL; nn.M = d->M; nn.NDnet = NDnet; nn.NDens = NDnet * d->M; nn.NP = d->NP; nn.NPest = d->NPest;
@@ -836,7 +882,9 @@ int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms
     Dev &dv = h->dv;
     launch_init_states(dv, PH_START, rf_scale, h->stream);
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    for (int i = 0; i < iters; ++i) run_eval(h, EPI_FINALIZE);     // each launch forms A, me, fe and the full gradient
+    // each launch forms A, me, fe and the full gradient (VA_TIMED_EPI=0: profiling ablation without the tail)
+    static const int timed_epi = [] { const char *e = getenv("VA_TIMED_EPI"); return e ? atoi(e) : (int)EPI_FINALIZE; }();
+    for (int i = 0; i < iters; ++i) run_eval(h, timed_epi);
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventSynchronize(h->ev1));
     HIPCHK(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));

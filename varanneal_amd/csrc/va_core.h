@@ -27,8 +27,12 @@
 
 #if defined(__HIPCC__)
 #define VA_HD __host__ __device__ inline
+// the line-search state machine runs as the tail of the evaluation kernel: a real call would give
+// every wave of that kernel a scratch frame
+#define VA_HD_FLAT __host__ __device__ __attribute__((always_inline)) inline
 #else
 #define VA_HD inline
+#define VA_HD_FLAT inline
 #endif
 
 namespace va {
@@ -51,6 +55,7 @@ enum { DP_GD = 0, DP_DD = 1, DP_N = 2 };
 struct Dims {
     int D, N, ND, ld, L, N_data, nskip, NP, NPest, T, ntiles, B, m, disc, nchunks, chunk;
     int emode, RY, NT, maxr;   // eval kernel: 1 = flat-mapped, 3 = column-run (va_tile3.h), 4 = wave-private column runs (va_tile4.h)
+    unsigned long long obsmask; // bit i set <=> state column i is observed (D <= 64; Lidx ascending on the device)
     int nprow;                 // eval partial rows per seed (ntiles, or ntiles*4 when every wave writes its own)
     // time-dependent parameters (va_ode.py:170-188): P is (N, NPt) per seed and the vector is
     // [X (N*D) | p_est (N*NPe), time-major].  Then ND = N*D + N*NPe and NP = NPest = 0 for the
@@ -410,7 +415,7 @@ VA_HD void tile_gp(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc 
 
 // ---------------------------------------------------------------- dcsrch / dcstep
 // MINPACK-2 line search (More' & Thuente 1994) as used by L-BFGS-B's lnsrlb.
-VA_HD void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy,
+VA_HD_FLAT void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy,
                   double &stp, double fp, double dp, int &brackt, double stpmin, double stpmax)
 {
     const double sgnd = dp * (dx / fabs(dx));
@@ -464,15 +469,18 @@ VA_HD void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy, 
         } else if (stp > stx) stpf = stpmax;
         else stpf = stpmin;
     }
-    if (fp > fx) { sty = stp; fy = fp; dy = dp; }
-    else {
-        if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
-        stx = stp; fx = fp; dx = dp;
+    {
+        // interval update, written as selects on values (branches that assign through the reference
+        // parameters make the device compiler keep the six of them in scratch memory)
+        const bool hi = fp > fx, flip = !hi && sgnd < 0.0;
+        const double nsty = hi ? stp : (flip ? stx : sty), nfy = hi ? fp : (flip ? fx : fy), ndy = hi ? dp : (flip ? dx : dy);
+        const double nstx = hi ? stx : stp, nfx = hi ? fx : fp, ndx = hi ? dx : dp;
+        sty = nsty; fy = nfy; dy = ndy; stx = nstx; fx = nfx; dx = ndx;
     }
     stp = stpf;
 }
 
-VA_HD int dcsrch(double f, double g, double &stp, double ftol, double gtol, double xtol,
+VA_HD_FLAT int dcsrch(double f, double g, double &stp, double ftol, double gtol, double xtol,
                  double stpmin, double stpmax, int task, LsState &st)
 {
     const double xtrapl = 1.1, xtrapu = 4.0;
@@ -493,15 +501,19 @@ VA_HD int dcsrch(double f, double g, double &stp, double ftol, double gtol, doub
     if (stp == stpmin && (f > ftest || g >= st.gtest)) out = LS_WARN;
     if (f <= ftest && fabs(g) <= gtol * (-st.ginit)) out = LS_CONV;
     if (out != LS_FG) return out;
-    if (st.stage == 1 && f <= st.fx && f > ftest) {
-        double fm = f - stp * st.gtest, fxm = st.fx - st.stx * st.gtest,
-               fym = st.fy - st.sty * st.gtest, gm = g - st.gtest, gxm = st.gx - st.gtest,
-               gym = st.gy - st.gtest;
-        dcstep(st.stx, fxm, gxm, st.sty, fym, gym, stp, fm, gm, st.brackt, st.stmin, st.stmax);
-        st.fx = fxm + st.stx * st.gtest; st.fy = fym + st.sty * st.gtest;
-        st.gx = gxm + st.gtest; st.gy = gym + st.gtest;
-    } else {
-        dcstep(st.stx, st.fx, st.gx, st.sty, st.fy, st.gy, stp, f, g, st.brackt, st.stmin, st.stmax);
+    {
+        // (one call of dcstep on local copies, for the modified function or the function itself:
+        // two calls on different storage end up behind pointers, i.e. in scratch memory on the device)
+        const bool mod = st.stage == 1 && f <= st.fx && f > ftest;
+        const double sh = mod ? st.gtest : 0.0;
+        double stx = st.stx, sty = st.sty;
+        double fxm = st.fx - stx * sh, fym = st.fy - sty * sh, gxm = st.gx - sh, gym = st.gy - sh;
+        const double fm = f - stp * sh, gm = g - sh;
+        int brackt = st.brackt;
+        dcstep(stx, fxm, gxm, sty, fym, gym, stp, fm, gm, brackt, st.stmin, st.stmax);
+        st.stx = stx; st.sty = sty; st.brackt = brackt;
+        st.fx = fxm + stx * sh; st.fy = fym + sty * sh;
+        st.gx = gxm + sh; st.gy = gym + sh;
     }
     if (st.brackt) {
         if (fabs(st.sty - st.stx) >= 0.66 * st.width1) stp = st.stx + 0.5 * (st.sty - st.stx);
@@ -528,7 +540,7 @@ struct SeedResults {
 
 // close the current beta step (va_ode.py:773-782): record, then move to the next RF
 // or finish.  `accepted`: the trial point becomes the stored minimiser.
-VA_HD void finish_step(SeedHot &s, int status, bool accepted, const double *rf_ladder, int nbeta,
+VA_HD_FLAT void finish_step(SeedHot &s, int status, bool accepted, const double *rf_ladder, int nbeta,
                        const SeedResults &r, int *n_active_dec)
 {
     const int k = s.beta_idx;
@@ -543,7 +555,7 @@ VA_HD void finish_step(SeedHot &s, int status, bool accepted, const double *rf_l
     }
 }
 
-VA_HD void begin_linesearch(SeedHot &s)
+VA_HD_FLAT void begin_linesearch(SeedHot &s)
 {
     const double big = 1e10;
     s.ifun = 0; s.iback = 0; s.ls_task = LS_START;
@@ -551,11 +563,11 @@ VA_HD void begin_linesearch(SeedHot &s)
     s.dir = 1;
 }
 
-VA_HD void reset_memory(SeedHot &s) { s.col = 0; s.head = 0; s.theta = 1.0; s.nold = 0; }
+VA_HD_FLAT void reset_memory(SeedHot &s) { s.col = 0; s.head = 0; s.theta = 1.0; s.nold = 0; }
 
 // K2: consume one evaluation.  ev[] = eval partial sums INCLUDING the parameter tail
 // contributions; dirp[] = (g.d, d.d) of the direction in use.
-VA_HD void ls_step(SeedHot &s, const double *ev, const double *dirp, const Opts &o,
+VA_HD_FLAT void ls_step(SeedHot &s, const double *ev, const double *dirp, const Opts &o,
                    const double *rf_ladder, int nbeta, const SeedResults &r, int *n_active_dec,
                    double cme, double cfe)
 {

@@ -13,6 +13,10 @@ constexpr int EVAL_THREADS = 256;    // 4 waves per workgroup
 constexpr int VEC_THREADS = 256;
 constexpr int VEC_CHUNK = 1024;      // elements of a seed's vector per workgroup (2 x double2 per lane)
 
+// Arrival counters sit one per 256-byte line: returning atomics on words of one line serialise
+// (~10 ns each: 3072 arrivals on 64 adjacent words cost 25 us), on different lines they do not.
+constexpr int CNT_STRIDE = 64;
+
 // what the last-arriving wave of an evaluation does with the seed's partial sums (va_epilogue.h)
 enum { EPI_NONE = 0, EPI_FINALIZE = 1, EPI_LS = 2 };
 
@@ -21,6 +25,10 @@ struct Dev {
     Dims dm;
     Geo4 g4;                       // wave-private column-run geometry (emode 4)
     int epi;                       // EPI_*: tail folded into the evaluation kernel
+    unsigned ntiles_magic;         // floor(w / ntiles) == umulhi(w, ntiles_magic) for w < B*ntiles
+    int gaux;                      // 1: gradient stores write through (sc1)
+    int prio;                      // 1: later-dispatched workgroups of a CU issue at higher priority
+    int evcols;                    // 8, 16 or 32 >= EP_GP + NP: columns of the eval partial rows in use
     ProblemPtrs pp;
     Opts o;
     // per-seed vectors, stride dm.ld (multiple of 16 doubles -> 128-byte aligned rows)
@@ -40,7 +48,7 @@ struct Dev {
     long long *nfev;               // [B][max_beta]
     double *minpaths;              // NULL or [B][max_beta][ND+NP]
     int *n_active;
-    unsigned *cnt_eval, *cnt_upd, *cnt_dir;   // [B] arrival counters of the three kernels of a cycle (zero between launches)
+    unsigned *cnt_eval, *cnt_upd, *cnt_dir;   // [B][CNT_STRIDE] arrival counters of the three kernels of a cycle (zero between launches)
     unsigned long long *n_evals;   // seed-evaluations consumed by k_ls since create
     // S1 outputs
     double *outA, *outme, *outfe;  // [B]

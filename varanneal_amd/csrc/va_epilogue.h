@@ -61,20 +61,35 @@ __device__ __forceinline__ double col_reduce(const double *p, int nrows, int str
     return v;
 }
 
-// reduce the eval partial rows of seed b with the whole wave: lane = (row group r, column k),
-// 2 row groups x 32 columns (EP_N <= 32); returns the column totals broadcast into ev[].
+// reduce the eval partial rows of seed b with the whole wave: lane = (row group r, column k) with
+// NC = 8, 16 or 32 columns (the smallest that holds the EP_GP + NP columns in use) and 64 / NC row
+// groups, so that a dozen rows come back in ONE round trip; the groups are then added in a fixed
+// order.  Returns the column totals broadcast into ev[].
 static_assert(EP_N <= 32, "reduce_eval assumes at most 32 partial columns");
 template <bool SC1>
 __device__ __forceinline__ void reduce_eval(const Dev &dv, int b, int lane, double *ev)
 {
-    const int k = lane & 31, r = lane >> 5;
+    const int nc = dv.evcols, ng = 64 / nc;
+    const int k = lane & (nc - 1), r = lane / nc;
     double v = 0.0;
     if (k < EP_N)
-        v = col_reduce<SC1>(dv.evp + (size_t)b * dv.dm.nprow * EP_N + k, dv.dm.nprow, EP_N, r, 2, k == EP_GMAX);
-    const double v0 = __shfl(v, k, 64), v1 = __shfl(v, k + 32, 64);
-    const double tot = (k == EP_GMAX) ? fmax(v0, v1) : (v0 + v1);
+        v = col_reduce<SC1>(dv.evp + (size_t)b * dv.dm.nprow * EP_N + k, dv.dm.nprow, EP_N, r, ng, k == EP_GMAX);
+    double tot = __shfl(v, k, 64);
+    for (int gi = 1; gi < ng; ++gi) {
+        const double o = __shfl(v, k + gi * nc, 64);
+        tot = (k == EP_GMAX) ? fmax(tot, o) : tot + o;
+    }
 #pragma unroll
-    for (int c = 0; c < EP_N; ++c) ev[c] = __shfl(tot, c, 64);
+    for (int c = 0; c < EP_N; ++c) ev[c] = c < nc ? __shfl(tot, c, 64) : 0.0;
+}
+
+// uniform, read-only-in-this-launch words through the scalar path (constant address space): such
+// loads are not ordered with the vector-memory queue and cost a fraction of a vector round trip.
+// (Only for memory written by EARLIER launches: the launch boundary invalidates the scalar cache.)
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T *as_const(const T *p)
+{
+    return (const __attribute__((address_space(4))) T *)p;
 }
 
 // parameter tail of grad A (sum over tiles of the per-tile parameter partials) and its
@@ -85,9 +100,14 @@ __device__ __forceinline__ void eval_tail(const Dev &dv, int b, int use_d, doubl
     double *gt = dv.gt + (size_t)b * dm.ld;
     const double *d = dv.d + (size_t)b * dm.ld;
     for (int k = 0; k < dm.NPest; ++k) {
-        const double g = ev[EP_GP + dv.pp.Pidx[k]];
+        // (select chain, not ev[EP_GP + idx]: a run-time index would put ev[] -- and with it every wave
+        // of the evaluation kernel -- on scratch memory)
+        const int idx = as_const(dv.pp.Pidx)[k];
+        double g = 0.0;
+#pragma unroll
+        for (int j = 0; j < RHS_MAX_NP; ++j) g = (idx == j) ? ev[EP_GP + j] : g;
         gt[dm.ND + k] = g;
-        if (use_d) ev[EP_GTD] += g * d[dm.ND + k];
+        if (use_d) ev[EP_GTD] += g * as_const(d)[dm.ND + k];
         ev[EP_GN2] += g * g;
         ev[EP_GMAX] = fmax(ev[EP_GMAX], fabs(g));
     }
@@ -95,26 +115,29 @@ __device__ __forceinline__ void eval_tail(const Dev &dv, int b, int use_d, doubl
 
 // The tail of one evaluation of seed b, run by ONE whole wave.  `sh`: 512 bytes of LDS private to
 // the calling wave.  SC1: the partial rows were written in this launch (read them around L1).
+// One memory round trip: the partial rows and the seed's state are requested together.
 template <bool SC1>
 __device__ __forceinline__ void eval_epilogue(const Dev &dv, int b, int lane, SeedHot *sh, int mode)
 {
     const Dims &dm = dv.dm;
+    constexpr int NW8 = sizeof(SeedHot) / 8;
+    double *gst = reinterpret_cast<double *>(static_cast<SeedHot *>(&dv.st[b]));
+    double hot = 0.0;
+    if (mode != EPI_FINALIZE && lane < NW8) hot = gst[lane];       // in flight beside the row loads
     double ev[EP_N];
     reduce_eval<SC1>(dv, b, lane, ev);
     if (mode == EPI_FINALIZE) {
         if (lane != 0) return;
         eval_tail(dv, b, 0, ev);
-        const double me = ev[EP_ME] * dm.cme, fe = ev[EP_FE] * dm.cfe * dv.st[b].rf_scale;
+        const double me = ev[EP_ME] * dm.cme, fe = ev[EP_FE] * dm.cfe * as_const(static_cast<const SeedHot *>(dv.st + b))->rf_scale;
         dv.outA[b] = me + fe; dv.outme[b] = me; dv.outfe[b] = fe;
         return;
     }
     // one line-search / ladder step: the seed's hot state (<= 512 B) is staged in LDS with one
     // coalesced 8-byte load per lane, lane 0 runs the (branchy, scalar) state machine on the LDS
     // copy, and the wave writes it back
-    constexpr int NW8 = sizeof(SeedHot) / 8;
-    double *gst = reinterpret_cast<double *>(static_cast<SeedHot *>(&dv.st[b]));
     double *lst = reinterpret_cast<double *>(sh);
-    if (lane < NW8) lst[lane] = gst[lane];
+    if (lane < NW8) lst[lane] = hot;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

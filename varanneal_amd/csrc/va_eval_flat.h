@@ -53,6 +53,20 @@ __device__ __forceinline__ double wave_sum(double v)
     v = row16_reduce<false>(v);
     return ((lane_scalar(v, 0) + lane_scalar(v, 16)) + lane_scalar(v, 32)) + lane_scalar(v, 48);
 }
+// The same total through the matrix pipe: two v_mfma_f64_16x16x4_f64 against a matrix of ones.
+// With A[i = l&15][k = l>>4] = v the first leaves D[i][*] = sum of the four lanes i, i+16, i+32, i+48;
+// lane l holds rows (l>>4) + 4r of it, adds its four, and the second product sums the four lane
+// groups.  6 vector instructions instead of 12 + their DPP wait states, fixed order, and the matrix
+// pipe is otherwise idle in these kernels.
+__device__ __forceinline__ double wave_sum_mfma(double v)
+{
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const v4d z = {0.0, 0.0, 0.0, 0.0};
+    const v4d d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v, 1.0, z, 0, 0, 0);
+    const double p = (d1[0] + d1[1]) + (d1[2] + d1[3]);
+    const v4d d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(p, 1.0, z, 0, 0, 0);
+    return d2[0];
+}
 __device__ __forceinline__ double wave_max(double v)
 {
     v = row16_reduce<true>(v);
@@ -131,7 +145,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
         st_sc1(dv.evp + ((size_t)b * dm.ntiles + tile) * EP_N + tid, v);
     }
     // the workgroup that completes the seed's partial rows forms A / runs the line-search step
-    if (dv.epi != EPI_NONE && arrive_last(dv.cnt_eval + b, (unsigned)dm.nprow, lane))
+    if (dv.epi != EPI_NONE && arrive_last(dv.cnt_eval + (size_t)b * CNT_STRIDE, (unsigned)dm.ntiles, lane))
         eval_epilogue<true>(dv, b, lane, reinterpret_cast<SeedHot *>(red), dv.epi);
 }
 

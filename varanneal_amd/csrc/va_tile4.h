@@ -39,28 +39,26 @@ struct RhsL96s {
     {
         return xn[1] * (xn[2] - xn[0]) - x0 + p[0];
     }
-    // e[0] = s df_i/dx_{i-1},  e[1] = s df_i/dx_{i+1} = -s df_i/dx_{i-2}
-    static VA_HD void scatter(double s, double, const double *xn, const double *, double, const double *, double *e)
+    // e[0] = s df_i/dx_{i-1},  e[1] = s df_i/dx_{i+1} = -s df_i/dx_{i-2};  diag = s df_i/dx_i
+    static VA_HD void scatter(double s, double, const double *xn, const double *, double, const double *, double *e, double &diag)
     {
         e[0] = s * (xn[2] - xn[0]);
         e[1] = s * xn[1];
+        diag = -s;
     }
-    // sum_i s_i df_i/dx_j for the own column j: diagonal term + received products r[0..NG)
-    static VA_HD double gather(double s, double, const double *, const double *, double, const double *, const double *r)
-    {
-        return (r[0] - s) + (r[1] - r[2]);
-    }
+    // sum_{i != j} s_i df_i/dx_j for the own column j from the received products r[0..NG)
+    static VA_HD double gather(const double *r) { return r[0] + (r[1] - r[2]); }
     static VA_HD void pgrad(double s, double, const double *, const double *, double, const double *, double *acc) { acc[0] += s; }
 };
 
 // ------------------------------------------------------------------ geometry
 struct Geo4 {
-    int D, K, RW, NW, T;          // T = rows per workgroup = NW*RW*K
+    int D, K, RW, NW, SUB, T;     // SUB sub-tiles (RW runs of K rows each) per wave, one after the other; T = rows per workgroup = NW*SUB*RW*K
     int P, PITCH;                 // doubles of padding per run, run pitch
     int PP, KDP;                  // pieces (16 B) per run pitch / per K rows
     int XP;                       // pieces of one wave's x image
-    int XW, EW1, R2;              // doubles: x image, one product array, second region (products / d image)
-    int WAVE;                     // doubles of LDS per wave (x image + second region + reduction strip)
+    int XW, EW1, R2;              // doubles: one x image, one product array, second region (products / d images)
+    int WAVE;                     // doubles of LDS per wave (SUB x images + second region + reduction strip)
     unsigned magic;               // floor(q / PP) == (q * magic) >> 20 for q < 4096
 };
 constexpr int T4_STRIP = 4 * 32;  // [4 rows of 16 lanes][up to 32 values]
@@ -69,19 +67,19 @@ constexpr int T4_NI_MAX = 6;      // direct-to-LDS instructions per wave image w
 VA_HD constexpr bool tile4_ok(int D) { return D >= 4 && D <= 64 && (D & 1) == 0 && (64 / D) * D >= 48; }
 
 template <int HLR>
-VA_HD constexpr Geo4 tile4_geo(int D, int K, int NE, int NW = 4)
+VA_HD constexpr Geo4 tile4_geo(int D, int K, int NE, int SUB = 1, int NW = 4)
 {
     Geo4 g{};
-    g.D = D; g.K = K; g.RW = 64 / D; g.NW = NW; g.T = NW * g.RW * K;
+    g.D = D; g.K = K; g.RW = 64 / D; g.NW = NW; g.SUB = SUB; g.T = NW * SUB * g.RW * K;
     g.P = ((D - K * D) % 32 + 32) % 32;
     g.PITCH = K * D + g.P;
     g.PP = g.PITCH / 2; g.KDP = K * D / 2;
     g.XP = g.RW * g.PP + HLR * D / 2;
     g.XW = ((2 * g.XP + 15) / 16) * 16;
     g.EW1 = g.RW * g.PITCH;
-    const int e = NE * g.EW1;
-    g.R2 = (((e > g.XW ? e : g.XW) + 15) / 16) * 16;
-    g.WAVE = g.XW + g.R2 + T4_STRIP;
+    const int e = NE * g.EW1, dimg = SUB * g.XW;           // the d images of a line-search point die before the products are written
+    g.R2 = (((e > dimg ? e : dimg) + 15) / 16) * 16;
+    g.WAVE = SUB * g.XW + g.R2 + T4_STRIP;
     g.magic = (unsigned)((1u << 20) / (unsigned)g.PP + 1u);
     return g;
 }
@@ -107,22 +105,34 @@ VA_HD int tile4_src_piece(const Geo4 &g, int q)
 VA_HD constexpr int tile4_row(const Geo4 &g, int R) { return (R / g.K) * g.PITCH + (R % g.K) * g.D; }
 
 template <int K, int NE> struct T4Regs {
-    double direct[K], sown[K], xown[K], yv[K], wv[K], dval[K];
+    double direct[K], xown[K], yv[K], wv[K], dval[K];     // direct_m + the diagonal term of J^T s; wv unused when W_SCALAR
 };
 
 struct Tile4 {
     int n0w, a, tx, r0, use_d, l;   // first owned row of the wave, run, column, first owned row of the lane
     double c;
+    double wobs;                    // W_SCALAR: RM on observed columns, 0 elsewhere
     const double *xs;               // LDS: the wave's x image
     double *es;                     // LDS: the wave's product arrays [NE][RW*PITCH]
     double *gtg;
     double p[RHS_MAX_NP];
 };
 
+// LDS reads that must stay single ds_read_b64 (2 LDS cycles per wave): merged pairs (ds_read2_b64)
+// take 8 cycles, half the bytes per clock, and the LDS pipe is what the rows / gather phases are
+// bound by.  volatile keeps them apart; the explicit address space keeps them DS (not flat) loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const volatile __attribute__((address_space(3))) double *lds_cvp;
+#define VA_LDS_CVP(p) ((lds_cvp)(p))
+#else
+typedef const volatile double *lds_cvp;
+#define VA_LDS_CVP(p) ((lds_cvp)(p))
+#endif
+
 VA_HD int wrap_col(int c, int D) { c += c < 0 ? D : 0; c -= c >= D ? D : 0; return c; }
 
-// observations / weights of the lane's own rows (as tile3_obs, with the observed index from lmap:
-// Lidx may come in any order, va_ode.py:141)
+// observations / weights of the lane's own rows (general form: data every nskip-th row, weight
+// arrays).  t.l = position of the lane's column in Lidx, or -1.
 template <int K, int NE>
 VA_HD void tile4_obs(const Dims &dm, const ProblemPtrs &pp, const Tile4 &t, T4Regs<K, NE> &rg)
 {
@@ -132,7 +142,7 @@ VA_HD void tile4_obs(const Dims &dm, const ProblemPtrs &pp, const Tile4 &t, T4Re
             const int m = t.r0 + k;
             const bool ok = t.l >= 0 && m < dm.N;
             const size_t idx = ok ? (size_t)m * dm.L + t.l : 0;
-            rg.yv[k] = pp.Y[idx];
+            rg.yv[k] = ok ? pp.Y[idx] : 0.0;
             rg.wv[k] = ok ? dm.rm : 0.0;
         }
         if (pp.rm_arr) {
@@ -159,8 +169,10 @@ VA_HD void tile4_obs(const Dims &dm, const ProblemPtrs &pp, const Tile4 &t, T4Re
     }
 }
 
-// rows + scatter: f, residuals, q, direct, s for the lane's run in registers; publishes the products
-template <class RHS, int DISC, int K, bool EDGE, int DC>
+// rows + scatter: f, residuals, q, direct, s for the lane's run in registers; publishes the products.
+// W_SCALAR: scalar RM and RF0, data at every row (the reference's Lorenz-96 example and every BASELINE
+// config): the weights factor out of the sums and the loops carry no weight registers.
+template <class RHS, int DISC, int K, bool EDGE, int DC, bool W_SCALAR>
 VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, const Tile4 &t,
                       T4Regs<K, RHS::NE> &rg, ThreadAcc &acc)
 {
@@ -168,11 +180,11 @@ VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, cons
     const int D = DC > 0 ? DC : g.D, N = dm.N, PITCH = g.PITCH;
     const double dt = dm.dt;
     // the lane's first needed row r0-HL is staged row a*K of the wave's image
-    const double *x0p = t.xs + t.a * PITCH + t.tx;
-    const double *xnp[NB];
+    lds_cvp x0p = VA_LDS_CVP(t.xs + t.a * PITCH + t.tx);
+    lds_cvp xnp[NB];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) xnp[k] = t.xs + t.a * PITCH + wrap_col(t.tx + RHS::nb_off(k), D);
-    double xo[NR], fo[NR], q[NQ], w[NQ];
+    for (int k = 0; k < NB; ++k) xnp[k] = VA_LDS_CVP(t.xs + t.a * PITCH + wrap_col(t.tx + RHS::nb_off(k), D));
+    double xo[NR], fo[NR], q[NQ];
     double xnb[K][NB];                                   // neighbour values of the own rows (for the products)
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
@@ -181,28 +193,24 @@ VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, cons
         xo[j] = x0p[off];
 #pragma unroll
         for (int k = 0; k < NB; ++k) xn[k] = xnp[k][off];
-        const int row = t.r0 - HL + j;
-        const bool ok = !EDGE || (row >= 0 && row < N);
-        // staged rows that do not exist hold whatever lies next to the path in memory: never let it through
-        if (EDGE && !ok) { xo[j] = 0.0; for (int k = 0; k < NB; ++k) xn[k] = 0.0; }
-        fo[j] = RHS::f(xo[j], xn, t.p, 0.0, nullptr);
-        if (EDGE && !ok) fo[j] = 0.0;
+        if (EDGE) {
+            // staged rows that do not exist hold whatever lies next to the path in memory: zero them
+            // (selects), so that everything computed from them below is an exact zero
+            const int row = t.r0 - HL + j;
+            const bool ok = row >= 0 && row < N;
+            xo[j] = ok ? xo[j] : 0.0;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) xn[k] = ok ? xn[k] : 0.0;
+            fo[j] = RHS::f(xo[j], xn, t.p, 0.0, nullptr);
+            fo[j] = ok ? fo[j] : 0.0;
+        } else fo[j] = RHS::f(xo[j], xn, t.p, 0.0, nullptr);
         if (j >= HL && j < HL + K) {
 #pragma unroll
             for (int k = 0; k < NB; ++k) xnb[j - HL][k] = xn[k];
         }
     }
-    if (pp.rf0_arr) {
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            int row = t.r0 - HL + j;
-            row = row < 0 ? 0 : (row > N - 2 ? N - 2 : row);            // clamped; r = 0 there anyway
-            w[j] = pp.rf0_arr[(size_t)row * D + t.tx];
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) w[j] = dm.rf0;
-    }
+    const double cw = t.c * dm.rf0;
+    double fe = 0.0;
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const int row = t.r0 - HL + j;
@@ -223,11 +231,22 @@ VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, cons
             else if constexpr (DISC == DISC_EULER) r = xo[j + 1] - xo[j] - dt * fo[j];
             else r = xo[j + 1] - fo[j];
         }
-        if (EDGE && !have) r = 0.0;
-        const double wr = w[j] * r;
-        q[j] = t.c * wr;
-        if (j >= HL) acc.v[EP_FE] += wr * r;
+        if (EDGE) r = have ? r : 0.0;
+        if constexpr (W_SCALAR) {
+            q[j] = cw * r;
+            if (j >= HL) fe = fma(r, r, fe);
+        } else {
+            double w = dm.rf0;
+            if (pp.rf0_arr) {
+                int rc = row < 0 ? 0 : (row > N - 2 ? N - 2 : row);    // clamped; r = 0 there anyway
+                w = pp.rf0_arr[(size_t)rc * D + t.tx];
+            }
+            const double wr = w * r;
+            q[j] = t.c * wr;
+            if (j >= HL) fe = fma(wr, r, fe);
+        }
     }
+    acc.v[EP_FE] += W_SCALAR ? dm.rf0 * fe : fe;
     double *ep = t.es + t.a * PITCH + t.tx;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -243,44 +262,57 @@ VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, cons
                 s = -(dt / 3.0) * (q[je] + q[je - 2]) - (dt / 4.0) * (q[je + 1] - q[je - 1]);
             } else { direct = q[je + 1]; s = -(4.0 * dt / 3.0) * q[je]; }
         }
-        if (EDGE && t.r0 + k >= N) { direct = 0.0; s = 0.0; }
-        rg.direct[k] = direct; rg.sown[k] = s; rg.xown[k] = xo[j];
-        double e[NE];
-        RHS::scatter(s, xo[j], xnb[k], t.p, 0.0, nullptr, e);
+        // (rows >= N: every q that enters is an exact zero already, see above)
+        double e[NE], diag;
+        RHS::scatter(s, xo[j], xnb[k], t.p, 0.0, nullptr, e, diag);
         RHS::pgrad(s, xo[j], xnb[k], t.p, 0.0, nullptr, acc.v + EP_GP);
+        rg.direct[k] = direct + diag; rg.xown[k] = xo[j];
 #pragma unroll
         for (int u = 0; u < NE; ++u) ep[u * g.EW1 + k * D] = e[u];
     }
 }
 
-// gather: gradient rows of the lane's run
-template <class RHS, int DISC, int K, bool EDGE, int DC>
-VA_HD void tile4_grad(const Dims &dm, const Geo4 &g, const Tile4 &t, const T4Regs<K, RHS::NE> &rg, ThreadAcc &acc)
+// gather: gradient rows of the lane's run.  LSQ: also the sums the line search needs (g.d, g.g, max|g|).
+// The K gradient values of the lane's run come back in gvv[]; the caller stores them (rows >= N of an
+// edge tile hold exact zeros and must not be stored).
+template <class RHS, int DISC, int K, bool EDGE, int DC, bool W_SCALAR, bool LSQ>
+VA_HD void tile4_grad(const Dims &dm, const Geo4 &g, const Tile4 &t, const T4Regs<K, RHS::NE> &rg, ThreadAcc &acc,
+                      double (&gvv)[K])
 {
     constexpr int NG = RHS::NG;
     const int D = DC > 0 ? DC : g.D;
-    const double *rp[NG];
+    lds_cvp rp[NG];
 #pragma unroll
-    for (int u = 0; u < NG; ++u) rp[u] = t.es + RHS::g_e(u) * g.EW1 + t.a * g.PITCH + wrap_col(t.tx + RHS::g_off(u), D);
+    for (int u = 0; u < NG; ++u) rp[u] = VA_LDS_CVP(t.es + RHS::g_e(u) * g.EW1 + t.a * g.PITCH + wrap_col(t.tx + RHS::g_off(u), D));
     const double two_cme = 2.0 * dm.cme;
-    double gmax = acc.v[EP_GMAX];
-    double *gout = t.gtg + (long)t.r0 * D + t.tx;
+    const double c2 = two_cme * t.wobs;
+    double gmax = 0.0, me = 0.0, gtd = 0.0, gn2 = 0.0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         double r[NG];
 #pragma unroll
         for (int u = 0; u < NG; ++u) r[u] = rp[u][k * D];
-        double gv = rg.direct[k] + RHS::gather(rg.sown[k], rg.xown[k], nullptr, t.p, 0.0, nullptr, r);
+        double gv = rg.direct[k] + RHS::gather(r);
         const double diff = rg.xown[k] - rg.yv[k];
-        const double wd = rg.wv[k] * diff;
-        acc.v[EP_ME] += wd * diff;
-        gv += two_cme * wd;
-        if (!EDGE || t.r0 + k < dm.N) gout[k * D] = gv; else gv = 0.0;
-        acc.v[EP_GTD] += gv * rg.dval[k];
-        acc.v[EP_GN2] += gv * gv;
-        gmax = __builtin_fmax(gmax, __builtin_fabs(gv));
+        if constexpr (W_SCALAR) {
+            me = fma(diff, diff, me);
+            gv = fma(c2, diff, gv);
+        } else {
+            const double wd = rg.wv[k] * diff;
+            me = fma(wd, diff, me);
+            gv = fma(two_cme, wd, gv);
+        }
+        // rows >= N of an edge tile: every term above is an exact zero (inputs zeroed in tile4_rows,
+        // observation loads return 0 there)
+        gvv[k] = gv;
+        if constexpr (LSQ) {
+            gtd = fma(gv, rg.dval[k], gtd);
+            gn2 = fma(gv, gv, gn2);
+            gmax = __builtin_fmax(gmax, __builtin_fabs(gv));
+        }
     }
-    acc.v[EP_GMAX] = gmax;
+    acc.v[EP_ME] += W_SCALAR ? t.wobs * me : me;
+    if constexpr (LSQ) { acc.v[EP_GTD] += gtd; acc.v[EP_GN2] += gn2; acc.v[EP_GMAX] = __builtin_fmax(acc.v[EP_GMAX], gmax); }
 }
 
 }  // namespace va

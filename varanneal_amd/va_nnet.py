@@ -33,7 +33,7 @@ import time
 import numpy as np
 
 from . import _capi
-from ._hipmin import HIPmin
+from ._hipmin import HIPmin, alpha_pow as _alpha_pow
 
 ACT_IMPL = {
     "sigmoid": lambda x, W, b: 1.0 / (1.0 + np.exp(-(np.dot(W, x) + b))),
@@ -195,8 +195,8 @@ class Annealer(HIPmin):
         self.Nbeta = len(self.beta_array)
         if RF0 is not None:
             self.RF0 = RF0
-        self.RF = self.RF0 * self.alpha ** self.beta
-        self._rf_scale = np.asarray(self.alpha ** np.asarray(self.beta_array, dtype=np.float64))
+        self.RF = self.RF0 * _alpha_pow(self.alpha, self.beta)
+        self._rf_scale = _alpha_pow(self.alpha, self.beta_array)
 
         if init_to_data:                                               # va_nnet.py:423-430
             Xv = Xf.reshape(self.B, self.M, self.NDnet)
@@ -272,7 +272,7 @@ class Annealer(HIPmin):
         if self.betaidx < len(self.beta_array) - 1:                    # va_nnet.py:508-511
             self.betaidx += 1
             self.beta = self.beta_array[self.betaidx]
-            self.RF = self.RF0 * self.alpha ** self.beta
+            self.RF = self.RF0 * _alpha_pow(self.alpha, self.beta)
         self.taped = False
 
     def _anneal_fused(self):
@@ -294,7 +294,7 @@ class Annealer(HIPmin):
             self.P[self.Pidx] = self._Pfull[0, self.Pidx]
         self.betaidx = self.Nbeta - 1
         self.beta = self.beta_array[self.betaidx]
-        self.RF = self.RF0 * self.alpha ** self.beta
+        self.RF = self.RF0 * _alpha_pow(self.alpha, self.beta)
         if self.verbose:
             print("Ladder of %d steps x %d seed(s): %.3f s, %d action+gradient evaluations"
                   % (nb, self.B, time.time() - t0, int(self._nfev[:, k0:].sum())))
@@ -436,7 +436,7 @@ class Annealer(HIPmin):
         savearray[:, 1] = self._A[0]
         savearray[:, 2] = self._me[0]
         savearray[:, 3] = self._fe[0]
-        savearray[:, 4] = self._fe[0] / (self.RF0 * self.alpha ** np.asarray(self.beta_array, dtype=np.float64))
+        savearray[:, 4] = self._fe[0] / (self.RF0 * _alpha_pow(self.alpha, self.beta_array))
         if filename.endswith('.npy'):
             np.save(filename, savearray.astype(dtype))
         else:

@@ -45,7 +45,7 @@ import time
 import numpy as np
 
 from . import _capi, rhs as _rhs
-from ._hipmin import HIPmin
+from ._hipmin import HIPmin, alpha_pow as _alpha_pow
 
 _DISCS = ("euler", "trapezoid", "SimpsonHermite", "forwardmap")
 
@@ -245,10 +245,10 @@ class Annealer(HIPmin):
         self.alpha = alpha
         self.beta_array = np.array(beta_array, dtype=np.uint16)
         self.Nbeta = len(self.beta_array)
-        self._rf_scale = np.asarray(self.alpha ** self.beta_array, dtype=np.float64)
+        self._rf_scale = _alpha_pow(self.alpha, self.beta_array)
         self.betaidx = 0
         self.beta = self.beta_array[0]
-        self.RF = self.RF0 * self.alpha ** self.beta
+        self.RF = self.RF0 * _alpha_pow(self.alpha, self.beta)
 
         # bounds (va_ode.py:582-605): expanded exactly as upstream, used by the SciPy route
         if bounds is not None:
@@ -366,7 +366,7 @@ class Annealer(HIPmin):
         if self.betaidx < len(self.beta_array) - 1:                   # va_ode.py:779-782
             self.betaidx += 1
             self.beta = self.beta_array[self.betaidx]
-            self.RF = self.RF0 * self.alpha ** self.beta
+            self.RF = self.RF0 * _alpha_pow(self.alpha, self.beta)
         self.taped = False
 
     def _anneal_fused(self):
@@ -391,7 +391,7 @@ class Annealer(HIPmin):
         self._write_back_P()
         self.betaidx = self.Nbeta - 1
         self.beta = self.beta_array[self.betaidx]
-        self.RF = self.RF0 * self.alpha ** self.beta
+        self.RF = self.RF0 * _alpha_pow(self.alpha, self.beta)
         if self.verbose:
             dt = time.time() - t0
             for j in range(nb):
@@ -480,7 +480,7 @@ class Annealer(HIPmin):
         sav[:, :, 0] = self.beta_array
         sav[:, :, 1] = self._A; sav[:, :, 2] = self._me; sav[:, :, 3] = self._fe
         rf0 = float(np.ravel(self.RF0)[0])            # RF0[0, 0] for array-valued RF0 (va_ode.py:861)
-        sav[:, :, 4] = self._fe / (rf0 * self.alpha ** self.beta_array)
+        sav[:, :, 4] = self._fe / (rf0 * _alpha_pow(self.alpha, self.beta_array))
         sav = sav if self._batched else sav[0]
         if filename.endswith('.npy'):
             np.save(filename, sav.astype(dtype))
