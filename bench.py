@@ -4,9 +4,11 @@ on MI355X, against the HBM roofline, with the CPU oracle timed beside it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c4|c2] [--no-cpu]
 
-A "step" is ONE batched evaluation (one k_eval launch): the action A(X,p) and its
-full gradient for all B resident seeds.  Paths are resident in HBM before the
-timed region.  N>1: one process per GPU (torch.distributed over RCCL), B seeds per
+A "step" is ONE complete batched evaluation -- the launch va_action_grad makes: the action
+A(X,p) (me + fe formed on the device by the last-arriving workgroup of each seed) and its full
+gradient for all B resident seeds.  Paths are resident in HBM before the timed region.
+The default run (1 GPU) also reports, in `extra`: the C4 shape, the end-to-end C3 ladder with
+the two L-BFGS vector kernels priced against the roofline, and the CPU oracle on all host cores.  N>1: one process per GPU (torch.distributed over RCCL), B seeds per
 GPU (weak scaling), no data-path collective; the job's one all_gather of the per-seed
 actions is issued after the K timed steps and timed separately (config.final_gather_ms).
 
@@ -70,16 +72,32 @@ def kernel_name(D, tile_rows, eval_kernel):
     return "k_eval<RhsL96,trapezoid>"
 
 
+def kernel_source_hash():
+    """content hash of the device sources: stamps a counter measurement with the code it was taken on"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "varanneal_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".h", ".hip")):
+            with open(os.path.join(d, fn), "rb") as fh:
+                h.update(fn.encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(workload_name):
     """HBM bytes per k_eval launch from the rocprofv3 --pmc passes recorded under profiles/
     (FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE; own
     runs with --kernel-trace only).  Counters cannot be collected inside this process, so this
-    is the committed measurement for the same kernel and workload, or None."""
+    is the committed measurement for the same workload -- valid only for the kernel sources it
+    was taken on: None when csrc/ has changed since (tools/pmc.sh + tools/pmc_traffic.py redo it)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            return json.load(fh).get(workload_name, {}).get("hbm_bytes_per_launch")
+            rec = json.load(fh).get(workload_name, {})
     except (OSError, ValueError):
         return None
+    if rec.get("kernel_source_hash") != kernel_source_hash():
+        return None
+    return rec.get("hbm_bytes_per_launch")
 
 
 def make_inputs(D, N, B, rank):
@@ -110,6 +128,77 @@ def cpu_baseline(D, N, Y, Lidx, XP, P, budget_s=10.0):
     return {"value": n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
             "sample": "%d (A,gradA) evaluations of the same D=%d N=%d paths in %.1f s on 1 of %d host cores"
                       % (n, D, N, dt, os.cpu_count() or 0)}
+
+
+def cpu_baseline_all(D, N, Y, Lidx, XP, P, budget_s=8.0):
+    """the same C restatement, OpenMP over the seeds, every host core."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import va_oracle
+    from varanneal_amd import twin
+    nt = va_oracle.num_threads()
+    nb = min(len(P), max(nt, 8) * 2)
+    pbs = [va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[b], [0], disc="trapezoid") for b in range(nb)]
+    va_oracle.action_grad_batch(pbs, XP[:nb], RF_SCALE)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        va_oracle.action_grad_batch(pbs, XP[:nb], RF_SCALE)
+        n += nb
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "evals/s", "cores": nt, "kind": "port",
+            "sample": "%d (A,gradA) evaluations of the same D=%d N=%d paths in %.1f s, OpenMP over seeds on %d "
+                      "threads (%d host cores)" % (n, D, N, dt, nt, os.cpu_count() or 0)}
+
+
+def extra_c4(device, steps=60):
+    """BASELINE config 4 as one GPU's shard: D=200, N=5000, L=80, 64 seeds; complete evaluations."""
+    from varanneal_amd import _capi, twin
+    w = WORKLOADS["c4"]
+    D, N, B = w["D"], w["N"], w["B"]
+    Y, Lidx, XP, P = make_inputs(D, N, B, 0)
+    with _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", device=device) as pb:
+        info = pb.info()
+        pb.action_grad(XP, RF_SCALE)
+        pb.eval_timed(RF_SCALE, 10)
+        ks = pb.eval_timed(RF_SCALE, steps) * 1e-3 / steps
+    balg = bytes_alg(B, N, D, 1, N, len(Lidx))
+    return {"workload": w["name"], "kernel": kernel_name(D, info["tile_rows"], 0) + " + k_finalize_eval",
+            "us_per_eval_launch": ks * 1e6, "evals_per_s": B / ks, "bytes_alg_per_launch": balg,
+            "achieved_GBs": balg / ks / 1e9, "frac": balg / ks / 1e9 / HBM_PEAK_GBS}
+
+
+def extra_ladder(device, D, N, B, Y, Lidx, XP, P, nbeta=30):
+    """The C3 ladder end to end (alpha = 1.5, beta = 0..nbeta-1, SciPy-equal stopping rules): every
+    kernel of the three-launch L-BFGS cycle counted; then the two vector kernels alone with full
+    histories (va_lbfgs_timed), priced by the bytes they must move."""
+    from varanneal_amd import _capi, twin
+    rf = 1.5 ** np.arange(nbeta)
+    opts = {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000000, 'maxiter': 1000000}
+    m = 10
+    with _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", device=device,
+                       max_beta=nbeta) as pb:
+        ld = pb.info()["ld"]
+        pb.anneal(XP, rf[:2], opts)                                   # warm-up
+        c0 = pb.counters()
+        t0 = time.perf_counter()
+        r = pb.anneal(XP, rf, opts)
+        dt = time.perf_counter() - t0
+        cyc = pb.counters()["cycles"] - c0["cycles"]
+        it = 200
+        ms_u, ms_d = pb.lbfgs_timed(it)
+    nfev = int(r["nfev"].sum())
+    # per element and launch: k_update reads d, g, gt, x + 2(m-1) old history vectors and writes g, S_new,
+    # Y_new (x only on acceptance: counted); k_direction reads g + 2m history vectors and writes d
+    b_upd = 8 * B * ld * (4 + 2 * (m - 1) + 4)
+    b_dir = 8 * B * ld * (1 + 2 * m + 1)
+    us_u, us_d = ms_u * 1e3 / it, ms_d * 1e3 / it
+    return {"workload": "lorenz96_D%d_N%d_B%d_trapezoid_ladder%d" % (D, N, B, nbeta),
+            "seconds": dt, "seed_evals": nfev, "seed_evals_per_s": nfev / dt, "cycles": cyc,
+            "us_per_cycle": dt * 1e6 / max(1, cyc), "launches_per_cycle": 3,
+            "A_final_median": float(np.median(r["A"][:, -1])), "k_final_median": float(np.median(r["pest"][:, -1, 0])),
+            "k_update": {"us": us_u, "bytes": b_upd, "GBs": b_upd / us_u / 1e3, "frac_of_8TBs": b_upd / us_u / 1e3 / HBM_PEAK_GBS},
+            "k_direction": {"us": us_d, "bytes": b_dir, "GBs": b_dir / us_d / 1e3, "frac_of_8TBs": b_dir / us_d / 1e3 / HBM_PEAK_GBS},
+            "note": "k_update / k_direction timed alone with full histories (m = 10); the 246 MB they stream per "
+                    "seed batch sit in the 256 MiB Infinity Cache, so rates above the HBM figure are possible"}
 
 
 def timed_steps(pb, rf, steps, A, dist, world, torch, barrier):
@@ -251,6 +340,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS) + sorted(NNET_WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra sub-records (C4 shape, C3 ladder)")
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--mode", default="eval", choices=["eval", "ladder"],
                     help="eval: the contract line (batched A/gradA launches); ladder: a whole "
@@ -310,6 +400,7 @@ def main():
                        "disc": "trapezoid", "tile_rows": info["tile_rows"], "ntiles": info["ntiles"],
                        "parallelism": "seeds sharded, %d per GPU" % B, "final_gather_ms": gather_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "step": "complete S1 evaluation: A, me, fe formed in the same launch (va_epilogue.h)",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(w["name"]),
                          "kernel": kernel_name(D, info["tile_rows"], args.eval_kernel),
                          "kernel_us": kern_s * 1e6, "bytes_alg_per_launch": balg},
@@ -317,6 +408,11 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(D, N, Y, Lidx, XP, P)
+            out["cpu_baseline_all"] = cpu_baseline_all(D, N, Y, Lidx, XP, P)
+        if world == 1 and args.workload == "c3" and not args.no_extra:
+            pb.close()
+            out["extra"] = {"ladder": extra_ladder(local_rank, D, N, B, Y, Lidx, XP, P),
+                            "c4": extra_c4(local_rank)}
         print(json.dumps(out), flush=True)
     pb.close()
     if dist is not None:

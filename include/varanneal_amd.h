@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VA_ABI_VERSION 6
+#define VA_ABI_VERSION 7
 
 enum { VA_OK = 0, VA_EINVAL = -1, VA_ENOMEM = -2, VA_EHIP = -3, VA_EUNSUPPORTED = -4,
        VA_ESTATE = -5 };
@@ -154,6 +154,12 @@ int va_get_minpath(va_handle h, int32_t seed, int32_t beta_idx, double *out);
  * the last va_action_grad / va_anneal call), bracketed by HIP events on the handle's stream;
  * returns elapsed ms. */
 int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms);
+
+/* Measurement hook for bench.py: `iters` launches each of the two L-BFGS vector kernels (k_update,
+ * k_direction) with every seed's history full (lbfgs_m pairs), bracketed by HIP events; returns the
+ * elapsed ms of each.  Overwrites the resident paths and the L-BFGS state: evaluate / anneal again
+ * from host data afterwards. */
+int va_lbfgs_timed(va_handle h, int32_t iters, float *ms_update, float *ms_direction);
 
 /* The outputs the last S1 evaluation (va_action_grad or va_eval_timed) left on the device:
  * A/me/fe [B], grad [B*ldg] (any may be NULL), HOST arrays. */

@@ -30,6 +30,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 /* ------------------------------------------------------------------ RHS */
 /* f_i = x_{i-1} (x_{i+1} - x_{i-2}) - x_i + k, cyclic in i.
  * np.roll(x,1,1)[i] = x[i-1]; np.roll(x,-1,1)[i] = x[i+1]; np.roll(x,2,1)[i] = x[i-2]. */
@@ -431,5 +435,32 @@ int vao_anneal(const vao_problem *pb0, const double *XP0, double alpha,
         out_status[b] = st; out_nit[b] = nit; out_nfev[b] = nfev;
     }
     free(P); free(xp);
+    return rc;
+}
+
+
+/* ------------------------------------------------------- batch of seeds */
+int vao_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int vao_action_grad_batch(const vao_problem *const *pb, int nseeds, const double *XP, double rf_scale,
+                          double *A, double *me, double *fe, double *grad)
+{
+    int rc = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int s = 0; s < nseeds; ++s) {
+        const size_t nv = (size_t)pb[s]->N_model * pb[s]->D + pb[s]->NPest;
+        int r = vao_action_grad(pb[s], XP + s * nv, rf_scale, A + s, me + s, fe + s, grad ? grad + s * nv : NULL);
+        if (r) {
+#pragma omp critical
+            if (!rc) rc = r;
+        }
+    }
     return rc;
 }

@@ -55,6 +55,14 @@ typedef struct {
  * unconstrained path (what scipy.optimize.minimize(method='L-BFGS-B',
  * bounds=None) executes; reference call site _autodiffmin.py:85-86).
  * status: 0 converged, 1 maxiter/maxfun, 2 abnormal (SciPy warnflag).   */
+/* The same evaluation for `nseeds` independent seeds that share Y, Lidx, RM, RF0 (pb[s] differ in P
+ * only), one seed per OpenMP thread: the all-host-cores CPU baseline of bench.py.
+ * XP: [nseeds][n_var], A/me/fe: [nseeds], grad: [nseeds][n_var] or NULL.  Returns the first error. */
+int vao_action_grad_batch(const vao_problem *const *pb, int nseeds, const double *XP, double rf_scale,
+                          double *A, double *me, double *fe, double *grad);
+/* threads an OpenMP region of this library runs on */
+int vao_num_threads(void);
+
 int vao_minimize_lbfgs(const vao_problem *pb, double *XP_inout, double rf_scale,
                        const vao_lbfgs_opts *o, double *Amin, int32_t *status,
                        int32_t *nit, int64_t *nfev);

@@ -65,7 +65,30 @@ def lib():
                                     C.c_int32, C.POINTER(_Opts), dp, dp, C.POINTER(C.c_int32),
                                     C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
         _lib.vao_anneal.restype = C.c_int
+        _lib.vao_action_grad_batch.argtypes = [C.POINTER(C.POINTER(_Problem)), C.c_int32, dp, C.c_double, dp, dp, dp, dp]
+        _lib.vao_action_grad_batch.restype = C.c_int
+        _lib.vao_num_threads.restype = C.c_int
     return _lib
+
+
+def num_threads():
+    """threads the batch evaluation runs on (OpenMP; OMP_NUM_THREADS or every host core)"""
+    return lib().vao_num_threads()
+
+
+def action_grad_batch(problems, XP, rf_scale=1.0, want_grad=True):
+    """(A, me, fe, grad) of len(problems) seeds, one per OpenMP thread (vao_action_grad_batch)."""
+    n = len(problems)
+    XP = np.ascontiguousarray(XP, dtype=np.float64)
+    assert XP.shape == (n, problems[0].n_var)
+    arr = (C.POINTER(_Problem) * n)(*[C.pointer(p._s) for p in problems])
+    A = np.empty(n); me = np.empty(n); fe = np.empty(n)
+    g = np.empty_like(XP) if want_grad else None
+    rc = lib().vao_action_grad_batch(arr, n, _dp(XP), float(rf_scale), _dp(A), _dp(me), _dp(fe),
+                                     _dp(g) if want_grad else None)
+    if rc:
+        raise ValueError("vao_action_grad_batch rc=%d" % rc)
+    return A, me, fe, g
 
 
 def _dp(a):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/kbench.sh "<bench args>" [env assignments...]  -- one line: kernel, kernel_us, frac
 args=$1; shift
-env "$@" python bench.py --no-cpu --steps 500 --warmup 50 $args 2>/dev/null | python -c "
+env "$@" python bench.py --no-cpu --no-extra --steps 500 --warmup 50 $args 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -3,7 +3,7 @@
 tag=$1; shift
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc_$tag
-run() { n=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag/p$n -- python3 bench.py --steps 40 --warmup 10 --no-cpu $BENCH_ARGS > gpurun_out/pmc_$tag/p$n.log 2>&1; echo "pass $n rc=$?"; }
+run() { n=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag/p$n -- python3 bench.py --steps 40 --warmup 10 --no-cpu --no-extra $BENCH_ARGS > gpurun_out/pmc_$tag/p$n.log 2>&1; echo "pass $n rc=$?"; }
 BENCH_ARGS="$*"
 run 1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM GRBM_GUI_ACTIVE
 run 2 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT

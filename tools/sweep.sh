@@ -2,7 +2,7 @@
 # usage: tools/sweep.sh <workload> <steps> "<tile rows list>" [eval_kernel]
 w=$1; steps=$2; ek=${4:-0}
 for T in $3; do
-  python bench.py --workload $w --steps $steps --warmup 50 --no-cpu --tile-rows $T --eval-kernel $ek 2>/dev/null | python -c "
+  python bench.py --workload $w --steps $steps --warmup 50 --no-cpu --no-extra --tile-rows $T --eval-kernel $ek 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     l=l.strip()

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VARANNEAL_AMD_LIB", os.path.join(_HERE, "libvaranneal_amd.so"))   # (env: diagnostic builds)
 
 VA_OK = 0
-ABI_VERSION = 6          # VA_ABI_VERSION of include/varanneal_amd.h
+ABI_VERSION = 7          # VA_ABI_VERSION of include/varanneal_amd.h
 ERRNAMES = {-1: "VA_EINVAL", -2: "VA_ENOMEM", -3: "VA_EHIP", -4: "VA_EUNSUPPORTED", -5: "VA_ESTATE"}
 DISC = {"euler": 0, "trapezoid": 1, "SimpsonHermite": 2, "forwardmap": 3}
 RHS = {"lorenz96": 0}
@@ -184,12 +184,13 @@ def lib():
     L.va_get_minpath.argtypes = [h, C.c_int32, C.c_int32, c_dp]
     L.va_eval_timed.argtypes = [h, C.c_double, C.c_int32, C.POINTER(C.c_float)]
     L.va_get_counters.argtypes = [h, c_lp, c_lp, c_lp]
+    L.va_lbfgs_timed.argtypes = [h, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.va_read_eval_outputs.argtypes = [h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.va_debug_read_partials.argtypes = [h, c_dp, C.c_int64]
     for fn in ("va_device_count", "va_rhs_load_module", "va_problem_create", "va_nnet_problem_create",
                "va_problem_info", "va_action_grad",
                "va_minimize_lbfgs", "va_anneal", "va_get_minpath", "va_eval_timed",
-               "va_get_counters", "va_debug_read_partials", "va_read_eval_outputs"):
+               "va_get_counters", "va_debug_read_partials", "va_read_eval_outputs", "va_lbfgs_timed"):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -198,7 +199,7 @@ def lib():
 EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_problem_create",
            "va_problem_destroy", "va_problem_info", "va_action_grad", "va_minimize_lbfgs",
            "va_anneal", "va_get_minpath", "va_eval_timed", "va_get_counters", "va_nnet_problem_create", "va_debug_read_partials",
-           "va_read_eval_outputs"]
+           "va_read_eval_outputs", "va_lbfgs_timed"]
 
 
 def check(rc):
@@ -311,6 +312,13 @@ class Problem(object):
         ms = C.c_float()
         check(self._L.va_eval_timed(self._h, float(rf_scale), int(iters), C.byref(ms)))
         return ms.value
+
+    def lbfgs_timed(self, iters):
+        """(ms of `iters` k_update launches, ms of `iters` k_direction launches) with full histories;
+        destroys the resident state."""
+        a, b = C.c_float(), C.c_float()
+        check(self._L.va_lbfgs_timed(self._h, int(iters), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def read_eval_outputs(self, want_grad=True):
         """(A, me, fe, grad) as the last S1 evaluation (action_grad / eval_timed) left them on the device."""

@@ -894,6 +894,31 @@ int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms
     return VA_OK;
 }
 
+int va_lbfgs_timed(va_handle h, int32_t iters, float *ms_update, float *ms_direction)
+{
+    if (!h || !ms_update || !ms_direction || iters < 1) return fail(VA_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    Dev &dv = h->dv;
+    dv.sticky = 1;
+    launch_arm_full_history(dv, h->stream);
+    launch_update(dv, h->stream); launch_direction(dv, h->stream);           // warm-up
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < iters; ++i) launch_update(dv, h->stream);
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(ms_update, h->ev0, h->ev1));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < iters; ++i) launch_direction(dv, h->stream);
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(ms_direction, h->ev0, h->ev1));
+    dv.sticky = 0;
+    launch_init_states(dv, PH_IDLE, 1.0, h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    return VA_OK;
+}
+
 int va_read_eval_outputs(va_handle h, double *A, double *me, double *fe, double *grad, int64_t ldg)
 {
     if (!h) return fail(VA_EINVAL, "null handle");

@@ -28,6 +28,7 @@ struct Dev {
     unsigned ntiles_magic;         // floor(w / ntiles) == umulhi(w, ntiles_magic) for w < B*ntiles
     int gaux;                      // 1: gradient stores write through (sc1)
     int prio;                      // 1: later-dispatched workgroups of a CU issue at higher priority
+    int sticky;                    // measurement only (va_lbfgs_timed): last arrivers leave upd / dir set
     int evcols;                    // 8, 16 or 32 >= EP_GP + NP: columns of the eval partial rows in use
     ProblemPtrs pp;
     Opts o;
@@ -60,6 +61,7 @@ void launch_ls(const Dev &dv, hipStream_t s);
 void launch_update(const Dev &dv, hipStream_t s);
 void launch_direction(const Dev &dv, hipStream_t s);
 void launch_init_states(const Dev &dv, int phase, double rf_scale_or_neg, hipStream_t s);
+void launch_arm_full_history(const Dev &dv, hipStream_t s);
 void launch_finalize_eval(const Dev &dv, hipStream_t s);
 size_t eval_lds_bytes(const Dev &dv);
 size_t update_lds_bytes(const Dims &dm);

@@ -564,6 +564,24 @@ void launch_init_states(const Dev &dv, int phase, double rf, hipStream_t s)
     hipLaunchKernelGGL(k_init_states, dim3((dv.dm.B + 63) / 64), dim3(64), 0, s, dv, phase, rf);
 }
 
+// measurement only (va_lbfgs_timed): every seed as if in the middle of a long minimisation -- history
+// full, a pair to store, a direction to form -- so that k_update / k_direction move the bytes they
+// move in the steady state of a ladder
+__global__ void k_arm_full_history(const Dev dv)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= dv.dm.B) return;
+    SeedState &s = dv.st[b];
+    const int m = dv.o.m;
+    s.phase = PH_IDLE; s.col = m; s.head = 1 % m; s.nold = m - 1; s.slot = 0;
+    for (int j = 0; j < m; ++j) s.order[j] = (j + 1) % m;
+    s.upd = UPD_G | UPD_HIST; s.dir = 1; s.stp_upd = 1.0; s.dr = 1.0; s.theta = 1.0; s.store_idx = -1;
+}
+void launch_arm_full_history(const Dev &dv, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_arm_full_history, dim3((dv.dm.B + 63) / 64), dim3(64), 0, s, dv);
+}
+
 // ------------------------------------------------------------------ K3: update + inner products + coefficients
 // wave-uniform broadcast of lane i's double through SGPRs (v_readlane), i uniform
 __device__ __forceinline__ double bcast_lane(double x, int i)
@@ -794,7 +812,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_update(const Dev dv)
     // request is consumed -- a finished seed must not have it applied again next cycle
     if (!arrive_last(dv.cnt_upd + (size_t)b * CNT_STRIDE, (unsigned)dm.nchunks, lane)) return;
     if (dir) coeffs_wave(dv, b, lane, red);
-    if (lane == 0) dv.st[b].upd = 0;
+    if (lane == 0 && !dv.sticky) dv.st[b].upd = 0;
 }
 void launch_update(const Dev &dv, hipStream_t s)
 {
@@ -864,7 +882,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_direction(const Dev dv)
     double v = col_reduce<true>(dv.dpp + (size_t)b * dm.nchunks * DP_N + k, dm.nchunks, DP_N, r, 32, false);
 #pragma unroll
     for (int o = 32; o >= 2; o >>= 1) v += __shfl_down(v, o, 64);         // lanes 0 and 1 hold the totals
-    if (lane == 0) { dv.st[b].gd_dir = v; dv.st[b].dir = 0; }
+    if (lane == 0) { dv.st[b].gd_dir = v; if (!dv.sticky) dv.st[b].dir = 0; }
 }
 void launch_direction(const Dev &dv, hipStream_t s)
 {
