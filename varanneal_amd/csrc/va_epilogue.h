@@ -92,6 +92,32 @@ __device__ __forceinline__ const __attribute__((address_space(4))) T *as_const(c
     return (const __attribute__((address_space(4))) T *)p;
 }
 
+// The same for a whole workgroup of NW waves (tail kernels of large grids: thousands of rows per
+// seed): wave w takes the rows w, w+NW, ... of every row group, leaves its column totals in LDS,
+// and after the barrier every wave adds the NW wave totals in wave order.  `part`: NW*32 doubles.
+__device__ __forceinline__ void reduce_eval_block(const Dev &dv, int b, int lane, int wave, int nw, double *part, double *ev)
+{
+    const int nc = dv.evcols, ng = 64 / nc;
+    const int k = lane & (nc - 1), r = lane / nc;
+    double v = 0.0;
+    if (k < EP_N)
+        v = col_reduce<false>(dv.evp + (size_t)b * dv.dm.nprow * EP_N + k, dv.dm.nprow, EP_N, r + wave * ng, ng * nw, k == EP_GMAX);
+    double tot = __shfl(v, k, 64);
+    for (int gi = 1; gi < ng; ++gi) {
+        const double o = __shfl(v, k + gi * nc, 64);
+        tot = (k == EP_GMAX) ? fmax(tot, o) : tot + o;
+    }
+    if (lane < nc) part[wave * 32 + lane] = tot;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < EP_N; ++c) {
+        double t = 0.0;
+        if (c < nc)
+            for (int w = 0; w < nw; ++w) t = (c == EP_GMAX) ? fmax(t, part[w * 32 + c]) : t + part[w * 32 + c];
+        ev[c] = t;
+    }
+}
+
 // parameter tail of grad A (sum over tiles of the per-tile parameter partials) and its
 // share of the line-search sums.
 __device__ __forceinline__ void eval_tail(const Dev &dv, int b, int use_d, double *ev)
@@ -117,7 +143,8 @@ __device__ __forceinline__ void eval_tail(const Dev &dv, int b, int use_d, doubl
 // the calling wave.  SC1: the partial rows were written in this launch (read them around L1).
 // One memory round trip: the partial rows and the seed's state are requested together.
 template <bool SC1>
-__device__ __forceinline__ void eval_epilogue(const Dev &dv, int b, int lane, SeedHot *sh, int mode)
+__device__ __forceinline__ void eval_epilogue(const Dev &dv, int b, int lane, SeedHot *sh, int mode,
+                                              const double *ev_ready = nullptr)
 {
     const Dims &dm = dv.dm;
     constexpr int NW8 = sizeof(SeedHot) / 8;
@@ -125,7 +152,10 @@ __device__ __forceinline__ void eval_epilogue(const Dev &dv, int b, int lane, Se
     double hot = 0.0;
     if (mode != EPI_FINALIZE && lane < NW8) hot = gst[lane];       // in flight beside the row loads
     double ev[EP_N];
-    reduce_eval<SC1>(dv, b, lane, ev);
+    if (ev_ready) {
+#pragma unroll
+        for (int c = 0; c < EP_N; ++c) ev[c] = ev_ready[c];
+    } else reduce_eval<SC1>(dv, b, lane, ev);
     if (mode == EPI_FINALIZE) {
         if (lane != 0) return;
         eval_tail(dv, b, 0, ev);

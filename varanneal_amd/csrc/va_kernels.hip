@@ -183,7 +183,38 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : (K <= 7 ? 3 : 2)) void k_eval4(c
             for (int k = 0; k < K; ++k) rg[s].dval[k] = 0.0;
     }
     const bool lsq = dv.epi != EPI_FINALIZE;                                  // launch-uniform
+    unsigned old = 0;
     double gvv[SUB][K];                       // the gradient stays in registers until the partial sums are out
+    // The workgroup's row of partial sums: every wave reduces through the matrix pipe (max|g| through
+    // DPP row moves) and lane 0 leaves the totals in the wave's LDS strip; after a workgroup barrier
+    // wave 0 adds the four waves' values in a fixed order and stores ONE row (write-through).
+    auto publish = [&]() {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if ((k == EP_GTD || k == EP_GN2 || k == EP_GMAX) && !lsq) continue;
+            if (k == EP_GTD && !use_d) continue;
+            const double r = (k == EP_GMAX) ? wave_max(acc.v[k]) : wave_sum_mfma(acc.v[k]);
+            if (lane == 0) strip[k] = r;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        STAMP(5);
+        __builtin_amdgcn_s_barrier();
+        STAMP(6);
+        if (wave == 0) {
+            if (lane < NV) {
+                const double r0 = strip[lane], r1 = strip[g.WAVE + lane], r2 = strip[2 * g.WAVE + lane], r3 = strip[3 * g.WAVE + lane];
+                double v = (lane == EP_GMAX) ? fmax(fmax(r0, r1), fmax(r2, r3)) : ((r0 + r1) + r2) + r3;
+                if ((lane == EP_GTD && !use_d) || ((lane == EP_GTD || lane == EP_GN2 || lane == EP_GMAX) && !lsq)) v = 0.0;
+                st_sc1(dv.evp + ((size_t)b * dm.ntiles + tile) * EP_N + lane, v);
+            }
+            if (dv.epi != EPI_NONE) {
+                // the wave has nothing else in flight: the row is acknowledged quickly, and the count
+                // is on its way while the wave goes on (gather phase / gradient stores)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) old = __hip_atomic_fetch_add(dv.cnt_eval + (size_t)b * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
 #pragma unroll
     for (int s = 0; s < SUB; ++s) {
         const int n0s = n0w + s * RK;
@@ -195,6 +226,11 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : (K <= 7 ? 3 : 2)) void k_eval4(c
         }
         wave_sync_lds();          // products are read by the same wave only: LDS is in order within a wave
         if (s == SUB - 1) STAMP(3);
+        // A plain S1 evaluation needs A = me + fe and dA/dp from the sums: all known once the rows are
+        // done.  The row goes out now, and the three dependent round trips of the tail (row
+        // acknowledged, arrival counted, rows of the seed read back) run beside the gather phase and
+        // the gradient stores instead of after them.
+        if (!lsq && s == SUB - 1) publish();
 #pragma unroll
         for (int k = 0; k < K; ++k) gvv[s][k] = 0.0;
         if (active) {
@@ -208,41 +244,9 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : (K <= 7 ? 3 : 2)) void k_eval4(c
         }
         if (s + 1 < SUB) wave_sync_lds();     // the next sub-tile overwrites the product arrays
     }
-
     STAMP(4);
-    // partial sums of the wave through the matrix pipe (max|g| through DPP row moves); lane 0 leaves
-    // them in the wave's LDS strip; after the kernel's only workgroup barrier wave 0 adds the four
-    // waves' values in a fixed order and publishes ONE row per workgroup (write-through store); the
-    // other waves are done.  A plain S1 evaluation has no use for g.d, g.g and max|g|.
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if ((k == EP_GTD || k == EP_GN2 || k == EP_GMAX) && !lsq) continue;
-        if (k == EP_GTD && !use_d) continue;
-        const double r = (k == EP_GMAX) ? wave_max(acc.v[k]) : wave_sum_mfma(acc.v[k]);
-        if (lane == 0) strip[k] = r;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    STAMP(5);
-    __builtin_amdgcn_s_barrier();
-    STAMP(6);
-    // Order of the tail: the workgroup's row of partial sums and its arrival go out BEFORE the
-    // gradient (the wave has nothing else in flight, so the store is acknowledged and the arrival is
-    // on its way while 10 MB of gradient stores from the whole chip queue up behind them); the tail of
-    // the seed's last workgroup -- three dependent memory round trips -- then runs beside the store
-    // phase instead of after it.
-    unsigned old = 0;
-    if (wave == 0) {
-        if (lane < NV) {
-            const double r0 = strip[lane], r1 = strip[g.WAVE + lane], r2 = strip[2 * g.WAVE + lane], r3 = strip[3 * g.WAVE + lane];
-            double v = (lane == EP_GMAX) ? fmax(fmax(r0, r1), fmax(r2, r3)) : ((r0 + r1) + r2) + r3;
-            if ((lane == EP_GTD && !use_d) || ((lane == EP_GTD || lane == EP_GN2 || lane == EP_GMAX) && !lsq)) v = 0.0;
-            st_sc1(dv.evp + ((size_t)b * dm.ntiles + tile) * EP_N + lane, v);
-        }
-        if (dv.epi != EPI_NONE) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the row is in memory
-            if (lane == 0) old = __hip_atomic_fetch_add(dv.cnt_eval + (size_t)b * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    // a line-search evaluation also needs g.d, g.g and max|g|: its row waits for the gradient
+    if (lsq) publish();
     {
         // gradient stores, 16 bytes per lane: the even lane of a column pair takes its neighbour's value
         // (DPP inside the quad) and writes both.  Write-through (sc1): the lines leave L2 as they are
@@ -268,15 +272,19 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : (K <= 7 ? 3 : 2)) void k_eval4(c
             }
         }
     }
-    if (wave != 0 || dv.epi == EPI_NONE) return;
-    // the last workgroup of the seed runs the tail (and resets the counter for the next launch)
-    old = __builtin_amdgcn_readfirstlane(old);
-    asm volatile("" ::: "memory");
-    const bool last = old == (unsigned)dm.ntiles - 1u;
-    STAMP(7);
-    if (last) {
-        if (lane == 0) __hip_atomic_store(dv.cnt_eval + (size_t)b * CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        eval_epilogue<true>(dv, b, lane, reinterpret_cast<SeedHot *>(xsw), dv.epi);
+    // The last workgroup of the seed runs the tail (and resets the counter for the next launch).
+    // (Measured at C3: running it before wave 0's own gradient stores, so that its loads do not retire
+    // behind seven write-through stores, is slower -- 10.2 vs 9.6 us: those stores then end the kernel.)
+    bool last = false;
+    if (wave == 0 && dv.epi != EPI_NONE) {
+        old = __builtin_amdgcn_readfirstlane(old);
+        asm volatile("" ::: "memory");
+        last = old == (unsigned)dm.ntiles - 1u;
+        STAMP(7);
+        if (last) {
+            if (lane == 0) __hip_atomic_store(dv.cnt_eval + (size_t)b * CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            eval_epilogue<true>(dv, b, lane, reinterpret_cast<SeedHot *>(xsw), dv.epi);
+        }
     }
 #ifdef VA_STAMPS
     if (last) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tl[1] = wall_clock64(); }    // (wave 0 re-uses slot 1)
@@ -520,30 +528,43 @@ hipError_t prepare_eval(const Dev &dv, int rhs)
     return op.err;
 }
 
-// ------------------------------------------------------------------ K2: line search / ladder (network action only)
-// One wave per seed.
-__global__ __launch_bounds__(64) void k_ls(const Dev dv)
+// ------------------------------------------------------------------ K2: tails as kernels of their own
+// (the network action, whose evaluation is several kernels, and grids too large to fold the tail
+// into the evaluation kernel).  One workgroup per seed; up to 16 waves share the row reduction
+// (C4: 2500 partial rows per seed), wave 0 runs the tail.
+constexpr int TAIL_MAX_WAVES = 16;
+static int tail_waves(const Dims &dm) { const int w = (dm.nprow + 127) / 128; return w < 1 ? 1 : (w > TAIL_MAX_WAVES ? TAIL_MAX_WAVES : w); }
+
+__global__ __launch_bounds__(64 * TAIL_MAX_WAVES) void k_ls(const Dev dv)
 {
     __shared__ SeedHot sh;
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const SeedState &st = dv.st[b];
-    const int phase = st.phase;
+    __shared__ double part[TAIL_MAX_WAVES * 32];
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int phase = dv.st[b].phase;
     if (phase != PH_START && phase != PH_LS) return;
-    eval_epilogue<false>(dv, b, lane, &sh, EPI_LS);
+    double ev[EP_N];
+    reduce_eval_block(dv, b, lane, wave, nw, part, ev);
+    if (wave == 0) eval_epilogue<false>(dv, b, lane, &sh, EPI_LS, ev);
 }
 void launch_ls(const Dev &dv, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_ls, dim3(dv.dm.B), dim3(64), 0, s, dv);
+    hipLaunchKernelGGL(k_ls, dim3(dv.dm.B), dim3(64 * tail_waves(dv.dm)), 0, s, dv);
 }
 
-// S1 epilogue (network action only): A, me, fe and the parameter tail for a plain evaluation.
-__global__ __launch_bounds__(64) void k_finalize_eval(const Dev dv)
+// S1 tail: A, me, fe and the parameter tail for a plain evaluation.
+__global__ __launch_bounds__(64 * TAIL_MAX_WAVES) void k_finalize_eval(const Dev dv)
 {
-    eval_epilogue<false>(dv, blockIdx.x, threadIdx.x, nullptr, EPI_FINALIZE);
+    __shared__ double part[TAIL_MAX_WAVES * 32];
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    double ev[EP_N];
+    reduce_eval_block(dv, b, lane, wave, nw, part, ev);
+    if (wave == 0) eval_epilogue<false>(dv, b, lane, nullptr, EPI_FINALIZE, ev);
 }
 void launch_finalize_eval(const Dev &dv, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_finalize_eval, dim3(dv.dm.B), dim3(64), 0, s, dv);
+    hipLaunchKernelGGL(k_finalize_eval, dim3(dv.dm.B), dim3(64 * tail_waves(dv.dm)), 0, s, dv);
 }
 
 // reset every seed: phase, ladder position, RF.  rf < 0 -> take rf_ladder[0].

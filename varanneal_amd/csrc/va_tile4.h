@@ -247,6 +247,17 @@ VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, cons
         }
     }
     acc.v[EP_FE] += W_SCALAR ? dm.rf0 * fe : fe;
+    {   // measurement error of the own rows (A needs nothing from the gather phase: a plain S1
+        // evaluation publishes its partial sums right after this function)
+        double me = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double diff = xo[k + HL] - rg.yv[k];
+            if constexpr (W_SCALAR) me = fma(diff, diff, me);
+            else me = fma(rg.wv[k] * diff, diff, me);
+        }
+        acc.v[EP_ME] += W_SCALAR ? t.wobs * me : me;
+    }
     double *ep = t.es + t.a * PITCH + t.tx;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -286,7 +297,7 @@ VA_HD void tile4_grad(const Dims &dm, const Geo4 &g, const Tile4 &t, const T4Reg
     for (int u = 0; u < NG; ++u) rp[u] = VA_LDS_CVP(t.es + RHS::g_e(u) * g.EW1 + t.a * g.PITCH + wrap_col(t.tx + RHS::g_off(u), D));
     const double two_cme = 2.0 * dm.cme;
     const double c2 = two_cme * t.wobs;
-    double gmax = 0.0, me = 0.0, gtd = 0.0, gn2 = 0.0;
+    double gmax = 0.0, gtd = 0.0, gn2 = 0.0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         double r[NG];
@@ -294,14 +305,8 @@ VA_HD void tile4_grad(const Dims &dm, const Geo4 &g, const Tile4 &t, const T4Reg
         for (int u = 0; u < NG; ++u) r[u] = rp[u][k * D];
         double gv = rg.direct[k] + RHS::gather(r);
         const double diff = rg.xown[k] - rg.yv[k];
-        if constexpr (W_SCALAR) {
-            me = fma(diff, diff, me);
-            gv = fma(c2, diff, gv);
-        } else {
-            const double wd = rg.wv[k] * diff;
-            me = fma(wd, diff, me);
-            gv = fma(two_cme, wd, gv);
-        }
+        if constexpr (W_SCALAR) gv = fma(c2, diff, gv);
+        else gv = fma(two_cme, rg.wv[k] * diff, gv);
         // rows >= N of an edge tile: every term above is an exact zero (inputs zeroed in tile4_rows,
         // observation loads return 0 there)
         gvv[k] = gv;
@@ -311,7 +316,6 @@ VA_HD void tile4_grad(const Dims &dm, const Geo4 &g, const Tile4 &t, const T4Reg
             gmax = __builtin_fmax(gmax, __builtin_fabs(gv));
         }
     }
-    acc.v[EP_ME] += W_SCALAR ? t.wobs * me : me;
     if constexpr (LSQ) { acc.v[EP_GTD] += gtd; acc.v[EP_GN2] += gn2; acc.v[EP_GMAX] = __builtin_fmax(acc.v[EP_GMAX], gmax); }
 }
 
