@@ -10,6 +10,25 @@ all-gather of the per-seed result table at the end (latency-bound: KBs).
 import numpy as np
 
 
+def rank_world(group=None):
+    """(rank, world) of the torch.distributed job this process belongs to, or (0, 1)."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return 0, 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def local_device(devices=None, rank=0):
+    """device ordinal of this rank: devices[rank % len(devices)], else LOCAL_RANK, else 0"""
+    import os
+    if devices:
+        return int(devices[rank % len(devices)])
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
 def seed_range(n_seeds, rank, world):
     """Static block partition: rank r of R gets [r*n/R, (r+1)*n/R)."""
     lo = (n_seeds * rank) // world

@@ -92,9 +92,51 @@ class Annealer(HIPmin):
                init_to_data=True, action='A_gaussian', disc='trapezoid',
                method='L-BFGS-B', bounds=None, opt_args=None, adolcID=0,
                track_paths=None, track_params=None, track_action_errors=None,
-               *, device=0, verbose=True, fused=None):
+               *, device=None, verbose=True, fused=None, n_seeds=None, devices=None, gather=True):
         """Full ladder (va_ode.py:459-528).  With no per-step tracking and the device
-        minimiser, the whole ladder runs in one C-ABI call (`fused`)."""
+        minimiser, the whole ladder runs in one C-ABI call (`fused`).
+
+        Keyword-only additions (reference scripts run unchanged without them):
+          n_seeds  X0 / P0 carry `n_seeds` independent initial guesses on their leading axis.  Under an
+                   initialised torch.distributed job (one process per GPU; backend "nccl" is RCCL) every
+                   rank anneals the block [r*n/R, (r+1)*n/R) of them -- the reference's SGE array job
+                   (examples/nnet_barimages/SGEcluster/submit_multiM.sh:14-30) without the cluster -- and
+                   ONE all-gather leaves the per-seed tables of all seeds in `self.gathered` on every
+                   rank.  A seed's results do not depend on how many ranks share the work.
+          devices  device ordinals to use (rank r takes devices[r % len]); default LOCAL_RANK
+          gather   False: skip the collective (`self.gathered` then holds this rank's seeds only)"""
+        if n_seeds is not None:
+            from . import parallel
+            X0 = np.asarray(X0); P0 = np.asarray(P0, dtype=np.float64)
+            if X0.ndim != 3 or X0.shape[0] != n_seeds or P0.shape[0] != n_seeds:
+                raise ValueError("n_seeds=%d needs X0 of shape (n_seeds, N_model, D) and P0 with n_seeds rows" % n_seeds)
+            rank, world = parallel.rank_world()
+            lo, hi = parallel.seed_range(n_seeds, rank, world)
+            self.n_seeds, self.seed_lo, self.seed_hi = n_seeds, lo, hi
+            if device is None:
+                device = parallel.local_device(devices, rank)
+            local = None
+            if hi > lo:
+                # (views: init_to_data and the parameter write-back still reach the caller's arrays)
+                self.anneal(X0[lo:hi], P0[lo:hi], alpha, beta_array, RM, RF0, Lidx, Pidx, dt_model,
+                            init_to_data, action, disc, method, bounds, opt_args, adolcID,
+                            track_paths, track_params, track_action_errors,
+                            device=device, verbose=verbose, fused=fused)
+                ND = self.N_model * self.D
+                local = {"A": self._A, "me": self._me, "fe": self._fe, "params": self._mp[:, :, ND:],
+                         "exitflags": self._flags, "nit": self._nit, "nfev": self._nfev}
+            if world > 1 and gather:
+                if local is None:                     # more ranks than seeds: an empty block still joins the collective
+                    nb, npw = len(beta_array), P0.reshape(n_seeds, -1).shape[1]
+                    local = {"A": np.zeros((0, nb)), "me": np.zeros((0, nb)), "fe": np.zeros((0, nb)),
+                             "params": np.zeros((0, nb, npw)), "exitflags": np.zeros((0, nb), np.int8),
+                             "nit": np.zeros((0, nb), np.int32), "nfev": np.zeros((0, nb), np.int64)}
+                self.gathered = parallel.gather_tables(local, n_seeds)
+            else:
+                self.gathered = local
+            return
+        if device is None:
+            device = 0
         if self.annealing_initialized is False:       # reference: flag is never set (va_ode.py:468,705)
             self.anneal_init(X0, P0, alpha, beta_array, RM, RF0, Lidx, Pidx, dt_model,
                              init_to_data, action, disc, method, bounds, opt_args, adolcID,
