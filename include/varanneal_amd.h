@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VA_ABI_VERSION 7
+#define VA_ABI_VERSION 8
 
 enum { VA_OK = 0, VA_EINVAL = -1, VA_ENOMEM = -2, VA_EHIP = -3, VA_EUNSUPPORTED = -4,
        VA_ESTATE = -5 };
@@ -171,6 +171,27 @@ int va_debug_read_partials(va_handle h, double *out, int64_t n);
 /* Cumulative counters since create: batched eval launches, seed-evaluations,
  * L-BFGS cycles. */
 int va_get_counters(va_handle h, int64_t *eval_launches, int64_t *seed_evals, int64_t *cycles);
+
+/* ---- the single collective of a multi-GPU job -------------------------------
+ * Independent annealing runs are sharded over the GPUs of a node, one process per GPU; the reference's
+ * counterpart is an SGE array job whose tasks leave their results in files
+ * (examples/nnet_barimages/SGEcluster/submit_multiM.sh:14-30, SGE_bardata_anneal.py:129-132).  Nothing is
+ * exchanged while the ladders run; at the end ONE RCCL all-gather over xGMI collects the per-seed result
+ * tables (KBs: latency-bound).  librccl.so is loaded on first use (dlopen); a job that never gathers
+ * does not need it.  The Python host normally issues the same collective through torch.distributed
+ * (varanneal_amd/parallel.py: backend "nccl" is RCCL); these entry points serve callers without torch. */
+typedef struct va_comm_s *va_comm;
+#define VA_COMM_ID_BYTES 128
+/* rank 0 calls this once and hands the 128 bytes to the other ranks (file, socket, MPI, ...) */
+int va_comm_unique_id(char id[VA_COMM_ID_BYTES]);
+/* every rank: join the communicator of `world` ranks on `device` (blocks until all have joined) */
+int va_comm_create(const char id[VA_COMM_ID_BYTES], int32_t world, int32_t rank, int32_t device, va_comm *out);
+void va_comm_destroy(va_comm c);
+/* After va_anneal(h, ..., nbeta, ...): all-gather the result tables of every rank's B seeds (the same B
+ * on all ranks) on h's stream.  HOST outputs, rank-major then seed-major:
+ *   table  [world*B][nbeta][3 + NPest] = (A, me, fe, estimated parameters) per seed and ladder step
+ *   status [world*B][nbeta]            (may be NULL) */
+int va_gather_results(va_handle h, va_comm c, int32_t nbeta, double *table, int32_t *status);
 
 /* ---- feed-forward-network action (reference: varanneal/va_nnet.py) -------------------
  * va_nnet.Annealer estimates the neuron states of M training examples and (a subset of)

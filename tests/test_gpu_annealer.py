@@ -71,3 +71,24 @@ def test_batched_seeds_independent():
     s.anneal(X0[4].copy(), P0[4].copy(), 1.5, np.arange(nb), 4.0, 4e-6, Lidx, [0], opt_args=OPTS, verbose=False)
     assert np.array_equal(a.A_array[4], s.A_array) and np.array_equal(a.minpaths[4], s.minpaths)
     a.close(); s.close()
+
+
+def test_c_abi_gather_of_result_tables():
+    """va_gather_results (the RCCL all-gather of SURVEY.md 8(b)/(e)) on a one-rank communicator: the
+    gathered table is the table va_anneal returned.  (More ranks need more GPUs than this box has;
+    the multi-rank layout is covered on CPU by tests/test_parallel_gloo.py.)"""
+    from varanneal_amd import _capi, twin
+    D, N, B, nb = 20, 120, 5, 4
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    XP = np.empty((B, N * D + 1)); P = np.empty((B, 1))
+    for b in range(B):
+        X0, P0 = twin.initial_guess(N, D, b, Y, Lidx)
+        XP[b, :-1] = X0.ravel(); XP[b, -1] = P0[0]; P[b] = P0
+    with _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", max_beta=nb) as pb:
+        r = pb.anneal(XP, 1.5 ** np.arange(nb), {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 100000, 'maxiter': 20})
+        comm = _capi.Comm(_capi.Comm.unique_id(), 1, 0, device=0)
+        table, st = pb.gather_results(comm, nb)
+        comm.close()
+    assert table.shape == (B, nb, 4) and np.array_equal(table[:, :, 0], r["A"]) and np.array_equal(table[:, :, 1], r["me"])
+    assert np.array_equal(table[:, :, 2], r["fe"]) and np.array_equal(table[:, :, 3], r["pest"][:, :, 0])
+    assert np.array_equal(st, r["status"])

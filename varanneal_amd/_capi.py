@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VARANNEAL_AMD_LIB", os.path.join(_HERE, "libvaranneal_amd.so"))   # (env: diagnostic builds)
 
 VA_OK = 0
-ABI_VERSION = 7          # VA_ABI_VERSION of include/varanneal_amd.h
+ABI_VERSION = 8          # VA_ABI_VERSION of include/varanneal_amd.h
 ERRNAMES = {-1: "VA_EINVAL", -2: "VA_ENOMEM", -3: "VA_EHIP", -4: "VA_EUNSUPPORTED", -5: "VA_ESTATE"}
 DISC = {"euler": 0, "trapezoid": 1, "SimpsonHermite": 2, "forwardmap": 3}
 RHS = {"lorenz96": 0}
@@ -184,13 +184,19 @@ def lib():
     L.va_get_minpath.argtypes = [h, C.c_int32, C.c_int32, c_dp]
     L.va_eval_timed.argtypes = [h, C.c_double, C.c_int32, C.POINTER(C.c_float)]
     L.va_get_counters.argtypes = [h, c_lp, c_lp, c_lp]
+    L.va_comm_unique_id.argtypes = [C.c_char_p]
+    L.va_comm_create.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(h)]
+    L.va_comm_destroy.argtypes = [h]
+    L.va_comm_destroy.restype = None
+    L.va_gather_results.argtypes = [h, h, C.c_int32, c_dp, c_ip]
     L.va_lbfgs_timed.argtypes = [h, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.va_read_eval_outputs.argtypes = [h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.va_debug_read_partials.argtypes = [h, c_dp, C.c_int64]
     for fn in ("va_device_count", "va_rhs_load_module", "va_problem_create", "va_nnet_problem_create",
                "va_problem_info", "va_action_grad",
                "va_minimize_lbfgs", "va_anneal", "va_get_minpath", "va_eval_timed",
-               "va_get_counters", "va_debug_read_partials", "va_read_eval_outputs", "va_lbfgs_timed"):
+               "va_get_counters", "va_debug_read_partials", "va_read_eval_outputs", "va_lbfgs_timed",
+               "va_comm_unique_id", "va_comm_create", "va_gather_results"):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -199,7 +205,8 @@ def lib():
 EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_problem_create",
            "va_problem_destroy", "va_problem_info", "va_action_grad", "va_minimize_lbfgs",
            "va_anneal", "va_get_minpath", "va_eval_timed", "va_get_counters", "va_nnet_problem_create", "va_debug_read_partials",
-           "va_read_eval_outputs", "va_lbfgs_timed"]
+           "va_read_eval_outputs", "va_lbfgs_timed", "va_comm_unique_id", "va_comm_create", "va_comm_destroy",
+           "va_gather_results"]
 
 
 def check(rc):
@@ -218,6 +225,30 @@ def load_rhs_module(path):
         check(lib().va_rhs_load_module(path.encode(), C.byref(rid)))
         _modules[path] = rid.value
     return _modules[path]
+
+
+class Comm(object):
+    """RCCL communicator of the job's one collective (va_comm_*): rank 0 makes the id with
+    Comm.unique_id() and hands the 128 bytes to the other ranks."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib().va_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, uid, world, rank, device=0):
+        self._L = lib()
+        self.world, self.rank = world, rank
+        self._c = C.c_void_p()
+        check(self._L.va_comm_create(uid, world, rank, device, C.byref(self._c)))
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c.value:
+            self._L.va_comm_destroy(self._c)
+            self._c = C.c_void_p()
+
+    __del__ = close
 
 
 class Problem(object):
@@ -312,6 +343,13 @@ class Problem(object):
         ms = C.c_float()
         check(self._L.va_eval_timed(self._h, float(rf_scale), int(iters), C.byref(ms)))
         return ms.value
+
+    def gather_results(self, comm, nbeta):
+        """va_gather_results: (table [world*B, nbeta, 3+NPest], status [world*B, nbeta]) on every rank"""
+        n = comm.world * self.B
+        table = np.empty((n, nbeta, 3 + self.NPest)); st = np.empty((n, nbeta), np.int32)
+        check(self._L.va_gather_results(self._h, comm._c, nbeta, table.ctypes.data_as(c_dp), st.ctypes.data_as(c_ip)))
+        return table, st
 
     def lbfgs_timed(self, iters):
         """(ms of `iters` k_update launches, ms of `iters` k_direction launches) with full histories;

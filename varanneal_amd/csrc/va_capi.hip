@@ -894,6 +894,128 @@ int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms
     return VA_OK;
 }
 
+// ---------------------------------------------------------------- the job's one collective (RCCL)
+namespace {
+
+typedef struct ncclComm *ncclComm_t;
+struct NcclId { char internal[VA_COMM_ID_BYTES]; };
+struct Rccl {
+    void *dl = nullptr;
+    int (*GetUniqueId)(NcclId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, NcclId, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+
+int rccl_load()
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.dl) return VA_OK;
+    void *dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!dl) dl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!dl) return fail(VA_EUNSUPPORTED, "librccl.so not found: %s", dlerror());
+    Rccl r;
+    r.GetUniqueId = (int (*)(NcclId *))dlsym(dl, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(ncclComm_t *, int, NcclId, int))dlsym(dl, "ncclCommInitRank");
+    r.AllGather = (int (*)(const void *, void *, size_t, int, ncclComm_t, hipStream_t))dlsym(dl, "ncclAllGather");
+    r.CommDestroy = (int (*)(ncclComm_t))dlsym(dl, "ncclCommDestroy");
+    r.GetErrorString = (const char *(*)(int))dlsym(dl, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString)
+        return fail(VA_EUNSUPPORTED, "librccl.so lacks an expected symbol");
+    r.dl = dl;
+    g_rccl = r;
+    return VA_OK;
+}
+
+// [seed][step] rows of (A, me, fe, p_est..., status) in one buffer: what a rank contributes
+__global__ void k_pack_results(const Dev dv, int nbeta, double *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = 4 + dv.dm.NPest;
+    if (i >= dv.dm.B * nbeta) return;
+    const int b = i / nbeta, k = i - b * nbeta;
+    double *o = out + (size_t)i * w;
+    const double *a = dv.ame + ((size_t)b * dv.max_beta + k) * 3;
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2];
+    for (int j = 0; j < dv.dm.NPest; ++j) o[3 + j] = dv.pest[((size_t)b * dv.max_beta + k) * dv.dm.NPest + j];
+    o[3 + dv.dm.NPest] = (double)dv.status[(size_t)b * dv.max_beta + k];
+}
+
+}  // namespace
+
+struct va_comm_s {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0, device = 0;
+};
+
+int va_comm_unique_id(char id[VA_COMM_ID_BYTES])
+{
+    if (!id) return fail(VA_EINVAL, "id is NULL");
+    int rc = rccl_load();
+    if (rc) return rc;
+    NcclId nid;
+    const int e = g_rccl.GetUniqueId(&nid);
+    if (e) return fail(VA_EHIP, "ncclGetUniqueId: %s", g_rccl.GetErrorString(e));
+    memcpy(id, nid.internal, VA_COMM_ID_BYTES);
+    return VA_OK;
+}
+
+int va_comm_create(const char id[VA_COMM_ID_BYTES], int32_t world, int32_t rank, int32_t device, va_comm *out)
+{
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return fail(VA_EINVAL, "bad argument");
+    *out = nullptr;
+    int rc = rccl_load();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device));
+    NcclId nid;
+    memcpy(nid.internal, id, VA_COMM_ID_BYTES);
+    va_comm c = new va_comm_s();
+    c->world = world; c->rank = rank; c->device = device;
+    const int e = g_rccl.CommInitRank(&c->comm, world, nid, rank);
+    if (e) { delete c; return fail(VA_EHIP, "ncclCommInitRank: %s", g_rccl.GetErrorString(e)); }
+    *out = c;
+    return VA_OK;
+}
+
+void va_comm_destroy(va_comm c)
+{
+    if (!c) return;
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+}
+
+int va_gather_results(va_handle h, va_comm c, int32_t nbeta, double *table, int32_t *status)
+{
+    if (!h || !c || !table) return fail(VA_EINVAL, "null argument");
+    const Dev &dv = h->dv;
+    if (nbeta < 1 || nbeta > dv.max_beta) return fail(VA_EINVAL, "nbeta=%d outside [1, max_beta=%d]", nbeta, dv.max_beta);
+    if (c->device != h->device) return fail(VA_EINVAL, "communicator lives on device %d, the problem on %d", c->device, h->device);
+    HIPCHK(hipSetDevice(h->device));
+    const int B = dv.dm.B, w = 4 + dv.dm.NPest;
+    const size_t mine = (size_t)B * nbeta * w;
+    double *send = nullptr, *recv = nullptr;
+    HIPCHK(hipMalloc((void **)&send, sizeof(double) * mine));
+    hipError_t e1 = hipMalloc((void **)&recv, sizeof(double) * mine * c->world);
+    if (e1 != hipSuccess) { (void)hipFree(send); return fail(VA_ENOMEM, "hipMalloc: %s", hipGetErrorString(e1)); }
+    hipLaunchKernelGGL(k_pack_results, dim3((B * nbeta + 255) / 256), dim3(256), 0, h->stream, dv, nbeta, send);
+    const int e = g_rccl.AllGather(send, recv, mine, /* ncclFloat64 */ 8, c->comm, h->stream);      // the single collective
+    std::vector<double> host(mine * c->world);
+    hipError_t e2 = e ? hipSuccess : hipMemcpyAsync(host.data(), recv, sizeof(double) * host.size(), hipMemcpyDeviceToHost, h->stream);
+    hipError_t e3 = hipStreamSynchronize(h->stream);
+    (void)hipFree(send); (void)hipFree(recv);
+    if (e) return fail(VA_EHIP, "ncclAllGather: %s", g_rccl.GetErrorString(e));
+    if (e2 != hipSuccess || e3 != hipSuccess) return fail(VA_EHIP, "gather copy: %s", hipGetErrorString(e2 != hipSuccess ? e2 : e3));
+    const size_t rows = (size_t)c->world * B * nbeta;
+    for (size_t i = 0; i < rows; ++i) {
+        memcpy(table + i * (w - 1), host.data() + i * w, sizeof(double) * (w - 1));
+        if (status) status[i] = (int32_t)host[i * w + w - 1];
+    }
+    return VA_OK;
+}
+
 int va_lbfgs_timed(va_handle h, int32_t iters, float *ms_update, float *ms_direction)
 {
     if (!h || !ms_update || !ms_direction || iters < 1) return fail(VA_EINVAL, "bad argument");
