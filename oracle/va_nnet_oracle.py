@@ -118,6 +118,17 @@ class NnetProblem(object):
         grad = np.concatenate([gX.ravel(), gp[self.Pidx]])
         return me + fe, me, fe, grad
 
+    def minimize_lbfgs(self, XP0, rf_scale, opt_args=None):
+        """The arbiter of trajectory-level parity: this action under the
+        oracle's OWN L-BFGS (va_oracle.c: vao_lbfgs_generic -- the optimiser the device restates), from
+        a given start point.  Returns (x, A, status, nit, nfev)."""
+        import va_oracle
+
+        def fg(x):
+            A, me, fe, g = self.action_grad(x, rf_scale)
+            return A, g
+        return va_oracle.lbfgs_generic(fg, XP0, opt_args)
+
     def reference_loop_action(self, XP, rf_scale=1.0, f=None):
         """The reference's own double loop (va_nnet.py:209-255) with a user activation
         f(x, W, b): the slow form, used to check the vectorised one."""

@@ -314,23 +314,25 @@ static double ddot(int n, const double *a, const double *b)
     return s;
 }
 
-int vao_minimize_lbfgs(const vao_problem *pb, double *x, double rf_scale,
-                       const vao_lbfgs_opts *o, double *Amin, int32_t *status,
-                       int32_t *nit_out, int64_t *nfev_out)
+/* The minimiser on any objective: fg(ctx, x, &f, g) returns non-zero on failure.  (The arbiter for
+ * actions other than the ODE one -- oracle/va_nnet_oracle.py drives it through a ctypes callback.) */
+int vao_lbfgs_generic(int32_t n, double *x, vao_fg_t fg, void *ctx,
+                      const vao_lbfgs_opts *o, double *Amin, int32_t *status,
+                      int32_t *nit_out, int64_t *nfev_out)
 {
-    const int n = pb->N_model * pb->D + pb->NPest, m = o->m;
+    const int m = o->m;
     const double epsmch = DBL_EPSILON, big = 1e10;
     double *g = (double *)malloc(sizeof(double) * n), *d = (double *)malloc(sizeof(double) * n);
     double *t = (double *)malloc(sizeof(double) * n), *r = (double *)malloc(sizeof(double) * n);
     double *S = (double *)malloc(sizeof(double) * (size_t)m * n);
     double *Y = (double *)malloc(sizeof(double) * (size_t)m * n);
     double *rho = (double *)malloc(sizeof(double) * m), *al = (double *)malloc(sizeof(double) * m);
-    double f, me, fe, fold = 0.0, theta = 1.0;
+    double f, fold = 0.0, theta = 1.0;
     int col = 0, head = 0;   /* circular history: slot (head+j)%m, j=0 oldest */
     int iter = 0, rc = 0, warn = 2;
     int64_t nfev = 0;
 
-    if (vao_action_grad(pb, x, rf_scale, &f, &me, &fe, g)) { rc = -1; goto done; }
+    if (fg(ctx, x, &f, g)) { rc = -1; goto done; }
     nfev = 1;
     {
         double sb = 0.0;
@@ -369,7 +371,7 @@ int vao_minimize_lbfgs(const vao_problem *pb, double *x, double rf_scale,
             if (iback >= o->maxls) break;
             ++nfev;
             for (int i = 0; i < n; ++i) x[i] = stp * d[i] + t[i];
-            if (vao_action_grad(pb, x, rf_scale, &f, &me, &fe, g)) { rc = -1; goto done; }
+            if (fg(ctx, x, &f, g)) { rc = -1; goto done; }
         }
         if (info != 0 || iback >= o->maxls) {
             memcpy(x, t, sizeof(double) * n); memcpy(g, r, sizeof(double) * n); f = fold;
@@ -406,6 +408,22 @@ done:
     *Amin = f; *status = warn; *nit_out = iter; *nfev_out = nfev;
     free(g); free(d); free(t); free(r); free(S); free(Y); free(rho); free(al);
     return rc;
+}
+
+typedef struct { const vao_problem *pb; double rf_scale; } ode_ctx;
+static int ode_fg(void *c, const double *x, double *f, double *g)
+{
+    const ode_ctx *k = (const ode_ctx *)c;
+    double me, fe;
+    return vao_action_grad(k->pb, x, k->rf_scale, f, &me, &fe, g);
+}
+
+int vao_minimize_lbfgs(const vao_problem *pb, double *x, double rf_scale,
+                       const vao_lbfgs_opts *o, double *Amin, int32_t *status,
+                       int32_t *nit_out, int64_t *nfev_out)
+{
+    ode_ctx c = {pb, rf_scale};
+    return vao_lbfgs_generic(pb->N_model * pb->D + pb->NPest, x, ode_fg, &c, o, Amin, status, nit_out, nfev_out);
 }
 
 /* --------------------------------------------------------------- ladder */

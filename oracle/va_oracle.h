@@ -63,6 +63,11 @@ int vao_action_grad_batch(const vao_problem *const *pb, int nseeds, const double
 /* threads an OpenMP region of this library runs on */
 int vao_num_threads(void);
 
+/* objective callback of vao_lbfgs_generic: value and gradient at x; non-zero return = failure */
+typedef int (*vao_fg_t)(void *ctx, const double *x, double *f, double *g);
+int vao_lbfgs_generic(int32_t n, double *x, vao_fg_t fg, void *ctx,
+                      const vao_lbfgs_opts *o, double *Amin, int32_t *status,
+                      int32_t *nit_out, int64_t *nfev_out);
 int vao_minimize_lbfgs(const vao_problem *pb, double *XP_inout, double rf_scale,
                        const vao_lbfgs_opts *o, double *Amin, int32_t *status,
                        int32_t *nit, int64_t *nfev);

@@ -71,6 +71,35 @@ def lib():
     return _lib
 
 
+_FG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
+def lbfgs_generic(fg, x0, opt_args=None):
+    """The oracle's L-BFGS (restated L-BFGS-B 3.0 unconstrained path + dcsrch, va_oracle.c) on any
+    objective `fg(x) -> (f, grad)`: the arbiter for actions other than the ODE one.
+    Returns (x, f, status, nit, nfev)."""
+    x = np.array(x0, dtype=np.float64)
+    n = x.size
+    L = lib()
+    L.vao_lbfgs_generic.argtypes = [C.c_int32, C.POINTER(C.c_double), _FG, C.c_void_p, C.POINTER(_Opts),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_int64)]
+    L.vao_lbfgs_generic.restype = C.c_int
+
+    def cb(ctx, xp, fp, gp):
+        xv = np.ctypeslib.as_array(xp, shape=(n,))
+        f, g = fg(xv.copy())
+        fp[0] = float(f)
+        np.ctypeslib.as_array(gp, shape=(n,))[:] = g
+        return 0
+    o = Problem._opts(opt_args)
+    A, st, nit, nfev = C.c_double(), C.c_int32(), C.c_int32(), C.c_int64()
+    rc = L.vao_lbfgs_generic(n, _dp(x), _FG(cb), None, C.byref(o), C.byref(A), C.byref(st), C.byref(nit), C.byref(nfev))
+    if rc:
+        raise ValueError("vao_lbfgs_generic rc=%d" % rc)
+    return x, A.value, st.value, nit.value, nfev.value
+
+
 def num_threads():
     """threads the batch evaluation runs on (OpenMP; OMP_NUM_THREADS or every host core)"""
     return lib().vao_num_threads()

@@ -92,28 +92,28 @@ def test_twin_ladder_on_device(gold):
     a.anneal(c["X0"].copy(), c["P0"].copy(), float(c["alpha"]), c["beta"], float(c["RM"]), float(c["RF0"]),
              list(c["Pidx"]), Lidx=[np.arange(10), np.arange(10)], method='L-BFGS-B', opt_args=OPTS, adolcID=0,
              verbose=False)
-    # Trajectory-level parity is not available on this problem: at rung 0 the device and SciPy
-    # agree to 1e-16 after iteration 1, to 1e-11 after iteration 2 (a 10-evaluation line search)
-    # and have separated by iteration 3; the NumPy oracle under SciPy leaves the reference's
-    # trajectory the same way (tests/test_oracle_nnet.py).  What must hold:
-    # every rung converges, the well-conditioned bottom of the ladder reaches the reference's
-    # minima, the top lands in a basin of comparable depth ...
-    assert np.all(np.abs(a.A_array[:8] - c["A_array"][:8]) <= 1e-2 * c["A_array"][:8])
-    assert abs(a.A_array[0] - c["A_array"][0]) <= 1e-3 * c["A_array"][0]
-    assert abs(a.A_array[-1] - c["A_array"][-1]) <= 1e-1 * c["A_array"][-1]
-    # ... and from the SAME start point the device minimiser and SciPy L-BFGS-B (around the
-    # device evaluator) find the same minimum
-    import scipy.optimize as opt
-    for k in (0, 5, 26):
+    # Arbitration: trajectories of long minimisations are chaotic in the
+    # last bits -- at rung 0 the device and SciPy agree to 1e-16 after iteration 1, to 1e-11 after
+    # iteration 2 (a 10-evaluation line search) and have separated by iteration 3.  So every rung is
+    # judged from ITS OWN start point (the device's previous minimiser) against the arbiter: the NumPy
+    # oracle of the action under the oracle's own L-BFGS (the optimiser the device restates).
+    worst = 0.0
+    for k in range(len(c["beta"])):
         xp0 = a._xp0(k); rf = float(a._rf_scale[k])
-
-        def fg(z):
-            A, me, fe, g = a._pb.action_grad(z[None, :], rf)
-            return A[0], g[0]
-        rs = opt.minimize(fg, xp0[0], method='L-BFGS-B', jac=True, options=OPTS)
-        r = a._pb.minimize_lbfgs(xp0, rf, OPTS)
-        assert r["status"][0] == 0 and rs.status == 0
-        assert abs(r["A"][0] - rs.fun) <= 1e-3 * rs.fun
+        pbo = vno.NnetProblem(c["structure"], c["din"], c["dout"], [np.arange(10), np.arange(10)], float(c["RM"]),
+                              float(c["RF0"]), a._mp[0, k - 1 if k else 0, a.NDens:], list(c["Pidx"]))
+        xo, Ao, sto, nito, nfevo = pbo.minimize_lbfgs(xp0[0], rf, OPTS)
+        dev = abs(a.A_array[k] - Ao) / Ao
+        worst = max(worst, dev)
+        assert sto == 0 and dev <= 1e-3, (k, a.A_array[k], Ao, a.nit_array[k], nito)
+    print("twin ladder: worst device-vs-arbiter deviation over %d rungs %.2e" % (len(c["beta"]), worst))
+    # against the reference's own anneal() + SciPy (one long trajectory from rung 0): the
+    # well-conditioned bottom of the ladder reaches the reference's minima; further up the two
+    # trajectories sit in neighbouring minima of comparable depth -- recorded, not asserted tightly
+    assert abs(a.A_array[0] - c["A_array"][0]) <= 1e-3 * c["A_array"][0]
+    rel = np.abs(a.A_array - c["A_array"]) / c["A_array"]
+    print("twin ladder vs reference goldens: rel. deviation per rung", np.array2string(rel, precision=2))
+    assert np.all(rel[:8] <= 1e-2) and rel[-1] <= 1e-1
     assert np.all(a.exitflags == 0)
     assert np.allclose(a.A_array, a.me_array + a.fe_array, rtol=1e-12)
     A, g = a.A_gradA_taped(np.append(a.minpaths[-1][:400], a.P[c["Pidx"]]))
@@ -134,11 +134,16 @@ def test_stepwise_equals_fused_and_batch_independent(gold):
     one = _annealer(c, act); one.anneal(X0[1].copy(), P0[1].copy(), *args, opt_args=OPTS, verbose=False)
     assert np.array_equal(f.A_array, st.A_array) and np.array_equal(f.minpaths, st.minpaths)
     assert np.array_equal(f.A_array[1], one.A_array) and np.array_equal(f.minpaths[1], one.minpaths)
-    # seed 1 of the golden run is this seed: the reference's first rungs
-    # (rung 1 takes ~200 iterations and its end point already depends on summation order:
-    # the two device paths agree on (nit, nfev) for 40 iterations and then part ways)
+    # seed 1 of the golden run is this seed.  Rung 0 reproduces the reference; rung 1 takes ~200
+    # iterations and its end point depends on summation order (the two device paths agree on (nit, nfev)
+    # for 40 iterations and then part ways), so it is arbitrated: from rung 1's own start point the
+    # device and the NumPy oracle under the oracle's L-BFGS must find the same minimum
     assert abs(f.A_array[1, 0] - c["A_array"][0]) <= 1e-3 * c["A_array"][0]
-    assert 0.5 * c["A_array"][1] <= f.A_array[1, 1] <= 2.0 * c["A_array"][1]
+    pbo = vno.NnetProblem(s, c["din"], c["dout"], [np.arange(s[0]), np.arange(s[-1])], float(c["RM"]), float(c["RF0"]),
+                          f._mp[1, 0, f.NDens:], Pidx, act="tanh")
+    xo, Ao, sto, nito, nfevo = pbo.minimize_lbfgs(f._xp0(1)[1], float(f._rf_scale[1]), OPTS)
+    print("small tanh ladder rung 1: device %.6e arbiter %.6e reference %.6e" % (f.A_array[1, 1], Ao, c["A_array"][1]))
+    assert sto == 0 and abs(f.A_array[1, 1] - Ao) <= 1e-3 * Ao, (f.A_array[1, 1], Ao, c["A_array"][1])
     for x in (f, st, one):
         x.close()
 

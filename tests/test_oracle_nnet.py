@@ -64,3 +64,28 @@ def test_ladder_restatement_follows_reference(gold):
     assert np.all(np.abs(r["A"][:2] - c["A_array"][:2]) <= 1e-8 * c["A_array"][:2])
     assert np.all(np.abs(r["A"][:4] - c["A_array"][:4]) <= 1e-4 * c["A_array"][:4])
     assert abs(r["A"][-1] - c["A_array"][-1]) <= 1e-4 * c["A_array"][-1]
+
+
+def test_arbiter_agrees_with_scipy_from_the_same_start(gold):
+    """The arbiter of the network ladders -- this oracle under the C oracle's own L-BFGS
+    (vno.NnetProblem.minimize_lbfgs -> va_oracle.c: vao_lbfgs_generic) -- against SciPy's L-BFGS-B
+    around the same function: identical iteration / evaluation counts on short runs, the same
+    minimum on converged ones."""
+    import scipy.optimize as opt
+    c = gold["g7_twin_ladder"]
+    Lidx = [np.arange(10), np.arange(10)]
+    pb = vno.NnetProblem(c["structure"], c["din"], c["dout"], Lidx, float(c["RM"]), float(c["RF0"]), c["P0"].copy(),
+                         c["Pidx"])
+    X0 = c["X0"].copy()
+    XP0 = np.append(X0.ravel(), c["P0"][c["Pidx"]])
+    for rf, maxiter in ((1.0, 3), (1.1 ** 30, 6)):
+        o = {'gtol': 1e-12, 'ftol': 1e-12, 'maxfun': 100000, 'maxiter': maxiter}
+        x, A, st, nit, nfev = pb.minimize_lbfgs(XP0, rf, o)
+        rs = opt.minimize(lambda z: (lambda r: (r[0], r[3]))(pb.action_grad(z, rf)), XP0, method='L-BFGS-B', jac=True,
+                          options=o)
+        # (a 10-evaluation line search in iteration 2 amplifies last-bit differences to ~1e-7 by iteration 3, ~1e-5 by iteration 6)
+        assert (nit, nfev) == (rs.nit, rs.nfev) and abs(A - rs.fun) <= 1e-3 * rs.fun, (rf, nit, rs.nit, A, rs.fun)
+    o = {'gtol': 1e-12, 'ftol': 1e-12, 'maxfun': 100000, 'maxiter': 100000}
+    x, A, st, nit, nfev = pb.minimize_lbfgs(XP0, 1.0, o)
+    rs = opt.minimize(lambda z: (lambda r: (r[0], r[3]))(pb.action_grad(z, 1.0)), XP0, method='L-BFGS-B', jac=True, options=o)
+    assert st == 0 and rs.status == 0 and abs(A - rs.fun) <= 1e-3 * rs.fun
