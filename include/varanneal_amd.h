@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VA_ABI_VERSION 8
+#define VA_ABI_VERSION 9
 
 enum { VA_OK = 0, VA_EINVAL = -1, VA_ENOMEM = -2, VA_EHIP = -3, VA_EUNSUPPORTED = -4,
        VA_ESTATE = -5 };
@@ -90,6 +90,13 @@ typedef struct va_problem_desc {
                                * n_var = N_model*(D+NPest); trapezoid and SimpsonHermite only (upstream's
                                * euler/forwardmap branches slice p one row short, va_ode.py:345-349) */
     void *stream;             /* hipStream_t to run on; NULL = library-owned stream  */
+    const double *lower;      /* NULL, or [n_var] box bounds of the path vector [X | p_est] shared by all seeds     */
+    const double *upper;      /* (va_ode.py:582-605 expands `bounds` to this order); -/+HUGE_VAL = no bound.        */
+                              /* With bounds va_minimize_lbfgs / va_anneal run the device minimiser's active-set    */
+                              /* form (csrc/va_core.h: components of the direction that would leave the box from a  */
+                              /* bound are dropped, the line search stops at the box, convergence is tested on the  */
+                              /* projected gradient) -- not L-BFGS-B's generalised Cauchy point; the reference's    */
+                              /* exact L-BFGS-B route remains SciPy around va_action_grad (one seed).               */
 } va_problem_desc;
 
 /* SciPy option names (reference passes opt_args through, _autodiffmin.py:85-86) */

@@ -315,12 +315,29 @@ static double ddot(int n, const double *a, const double *b)
 }
 
 /* The minimiser on any objective: fg(ctx, x, &f, g) returns non-zero on failure.  (The arbiter for
- * actions other than the ODE one -- oracle/va_nnet_oracle.py drives it through a ctypes callback.) */
-int vao_lbfgs_generic(int32_t n, double *x, vao_fg_t fg, void *ctx,
+ * actions other than the ODE one -- oracle/va_nnet_oracle.py drives it through a ctypes callback.)
+ *
+ * lo / hi (NULL, or n entries each, +-HUGE_VAL for "none"): box bounds, handled the way the DEVICE
+ * minimiser handles them (csrc/va_core.h, ls_step / k_direction) -- an active-set truncation of the
+ * same L-BFGS, NOT L-BFGS-B's generalised Cauchy point + subspace minimisation:
+ *   - x0 is projected onto the box; convergence is tested on the projected gradient (L-BFGS-B's projgr);
+ *   - components of d = -H g that would leave the box from a bound they sit on are set to zero;
+ *   - the line search runs up to stpmx, the largest step that keeps x + stp d inside the box
+ *     (trial points are clamped, so every iterate is feasible to the last bit);
+ *   - first trial step min(1/|d|, stpmx) at iteration 0, min(1, stpmx) afterwards;
+ *   - the ftol test is skipped after a step that ended on a bound (it was cut short).
+ * With no bound active it takes the steps of the unbounded code. */
+static double proj_grad(double x, double g, double l, double u)
+{
+    if (g < 0.0) return fmax(x - u, g);      /* (x - u = -inf without an upper bound) */
+    return fmin(x - l, g);
+}
+
+int vao_lbfgs_bounded(int32_t n, double *x, vao_fg_t fg, void *ctx, const double *lo, const double *hi,
                       const vao_lbfgs_opts *o, double *Amin, int32_t *status,
                       int32_t *nit_out, int64_t *nfev_out)
 {
-    const int m = o->m;
+    const int m = o->m, bnd = lo && hi;
     const double epsmch = DBL_EPSILON, big = 1e10;
     double *g = (double *)malloc(sizeof(double) * n), *d = (double *)malloc(sizeof(double) * n);
     double *t = (double *)malloc(sizeof(double) * n), *r = (double *)malloc(sizeof(double) * n);
@@ -332,11 +349,12 @@ int vao_lbfgs_generic(int32_t n, double *x, vao_fg_t fg, void *ctx,
     int iter = 0, rc = 0, warn = 2;
     int64_t nfev = 0;
 
+    if (bnd) for (int i = 0; i < n; ++i) x[i] = fmin(fmax(x[i], lo[i]), hi[i]);
     if (fg(ctx, x, &f, g)) { rc = -1; goto done; }
     nfev = 1;
     {
         double sb = 0.0;
-        for (int i = 0; i < n; ++i) sb = fmax(sb, fabs(g[i]));
+        for (int i = 0; i < n; ++i) sb = fmax(sb, fabs(bnd ? proj_grad(x[i], g[i], lo[i], hi[i]) : g[i]));
         if (sb <= o->gtol) { warn = 0; goto done; }
     }
     for (;;) {
@@ -353,9 +371,17 @@ int vao_lbfgs_generic(int32_t n, double *x, vao_fg_t fg, void *ctx,
             double be = rho[s] * ddot(n, Y + (size_t)s * n, d);
             for (int i = 0; i < n; ++i) d[i] += (al[j] - be) * S[(size_t)s * n + i];
         }
+        double stpmx = big;
+        if (bnd) {
+            for (int i = 0; i < n; ++i) {
+                if ((x[i] <= lo[i] && d[i] < 0.0) || (x[i] >= hi[i] && d[i] > 0.0)) d[i] = 0.0;
+                if (d[i] > 0.0) stpmx = fmin(stpmx, (hi[i] - x[i]) / d[i]);
+                else if (d[i] < 0.0) stpmx = fmin(stpmx, (lo[i] - x[i]) / d[i]);
+            }
+        }
         /* line search (lnsrlb) */
-        double dtd = ddot(n, d, d), dnorm = sqrt(dtd), stpmx = big, stp;
-        stp = (iter == 0) ? fmin(1.0 / dnorm, stpmx) : 1.0;
+        double dtd = ddot(n, d, d), dnorm = sqrt(dtd), stp;
+        stp = (iter == 0) ? fmin(1.0 / dnorm, stpmx) : fmin(1.0, stpmx);
         memcpy(t, x, sizeof(double) * n); memcpy(r, g, sizeof(double) * n);
         fold = f;
         int ifun = 0, iback = 0, info = 0, task = LS_START;
@@ -371,6 +397,7 @@ int vao_lbfgs_generic(int32_t n, double *x, vao_fg_t fg, void *ctx,
             if (iback >= o->maxls) break;
             ++nfev;
             for (int i = 0; i < n; ++i) x[i] = stp * d[i] + t[i];
+            if (bnd) for (int i = 0; i < n; ++i) x[i] = fmin(fmax(x[i], lo[i]), hi[i]);
             if (fg(ctx, x, &f, g)) { rc = -1; goto done; }
         }
         if (info != 0 || iback >= o->maxls) {
@@ -384,9 +411,9 @@ int vao_lbfgs_generic(int32_t n, double *x, vao_fg_t fg, void *ctx,
         if (iter >= o->maxiter) { warn = 1; goto done; }      /* SciPy wrapper order */
         if (nfev > o->maxfun) { warn = 1; goto done; }
         double sb = 0.0;
-        for (int i = 0; i < n; ++i) sb = fmax(sb, fabs(g[i]));
+        for (int i = 0; i < n; ++i) sb = fmax(sb, fabs(bnd ? proj_grad(x[i], g[i], lo[i], hi[i]) : g[i]));
         if (sb <= o->gtol) { warn = 0; goto done; }
-        {
+        if (!(bnd && stp >= stpmx)) {       /* (a step that ended on a bound was cut short: no verdict on progress) */
             double dd = fmax(fmax(fabs(fold), fabs(f)), 1.0);
             if (fold - f <= o->ftol * dd) { warn = 0; goto done; }
         }
@@ -408,6 +435,13 @@ done:
     *Amin = f; *status = warn; *nit_out = iter; *nfev_out = nfev;
     free(g); free(d); free(t); free(r); free(S); free(Y); free(rho); free(al);
     return rc;
+}
+
+int vao_lbfgs_generic(int32_t n, double *x, vao_fg_t fg, void *ctx,
+                      const vao_lbfgs_opts *o, double *Amin, int32_t *status,
+                      int32_t *nit_out, int64_t *nfev_out)
+{
+    return vao_lbfgs_bounded(n, x, fg, ctx, NULL, NULL, o, Amin, status, nit_out, nfev_out);
 }
 
 typedef struct { const vao_problem *pb; double rf_scale; } ode_ctx;

@@ -68,6 +68,11 @@ typedef int (*vao_fg_t)(void *ctx, const double *x, double *f, double *g);
 int vao_lbfgs_generic(int32_t n, double *x, vao_fg_t fg, void *ctx,
                       const vao_lbfgs_opts *o, double *Amin, int32_t *status,
                       int32_t *nit_out, int64_t *nfev_out);
+/* with box bounds lo / hi (n entries each, +-HUGE_VAL = none), handled as the device minimiser handles
+ * them: active-set truncation of the same L-BFGS (see va_oracle.c) */
+int vao_lbfgs_bounded(int32_t n, double *x, vao_fg_t fg, void *ctx, const double *lo, const double *hi,
+                      const vao_lbfgs_opts *o, double *Amin, int32_t *status,
+                      int32_t *nit_out, int64_t *nfev_out);
 int vao_minimize_lbfgs(const vao_problem *pb, double *XP_inout, double rf_scale,
                        const vao_lbfgs_opts *o, double *Amin, int32_t *status,
                        int32_t *nit, int64_t *nfev);

@@ -74,17 +74,23 @@ def lib():
 _FG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
-def lbfgs_generic(fg, x0, opt_args=None):
+def lbfgs_generic(fg, x0, opt_args=None, bounds=None):
     """The oracle's L-BFGS (restated L-BFGS-B 3.0 unconstrained path + dcsrch, va_oracle.c) on any
-    objective `fg(x) -> (f, grad)`: the arbiter for actions other than the ODE one.
+    objective `fg(x) -> (f, grad)`: the arbiter for actions other than the ODE one.  `bounds`: list of
+    (lo, hi) per variable (None = none), handled as the device handles them (vao_lbfgs_bounded).
     Returns (x, f, status, nit, nfev)."""
     x = np.array(x0, dtype=np.float64)
     n = x.size
     L = lib()
-    L.vao_lbfgs_generic.argtypes = [C.c_int32, C.POINTER(C.c_double), _FG, C.c_void_p, C.POINTER(_Opts),
-                                    C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-                                    C.POINTER(C.c_int64)]
-    L.vao_lbfgs_generic.restype = C.c_int
+    dp = C.POINTER(C.c_double)
+    L.vao_lbfgs_bounded.argtypes = [C.c_int32, dp, _FG, C.c_void_p, dp, dp, C.POINTER(_Opts),
+                                    dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    L.vao_lbfgs_bounded.restype = C.c_int
+    lo = hi = None
+    if bounds is not None:
+        lo = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=np.float64)
+        hi = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=np.float64)
+        assert lo.size == n
 
     def cb(ctx, xp, fp, gp):
         xv = np.ctypeslib.as_array(xp, shape=(n,))
@@ -94,9 +100,11 @@ def lbfgs_generic(fg, x0, opt_args=None):
         return 0
     o = Problem._opts(opt_args)
     A, st, nit, nfev = C.c_double(), C.c_int32(), C.c_int32(), C.c_int64()
-    rc = L.vao_lbfgs_generic(n, _dp(x), _FG(cb), None, C.byref(o), C.byref(A), C.byref(st), C.byref(nit), C.byref(nfev))
+    rc = L.vao_lbfgs_bounded(n, _dp(x), _FG(cb), None, _dp(lo) if lo is not None else None,
+                             _dp(hi) if hi is not None else None, C.byref(o), C.byref(A), C.byref(st), C.byref(nit),
+                             C.byref(nfev))
     if rc:
-        raise ValueError("vao_lbfgs_generic rc=%d" % rc)
+        raise ValueError("vao_lbfgs_bounded rc=%d" % rc)
     return x, A.value, st.value, nit.value, nfev.value
 
 
@@ -184,7 +192,10 @@ class Problem(object):
                      float(o.get("gtol", 1e-5)), int(min(o.get("maxiter", 15000), 2**31 - 1)),
                      int(o.get("maxfun", 15000)), int(o.get("maxls", 20)))
 
-    def minimize_lbfgs(self, XP0, rf_scale, opt_args=None):
+    def minimize_lbfgs(self, XP0, rf_scale, opt_args=None, bounds=None):
+        if bounds is not None:       # the device's active-set form (vao_lbfgs_bounded)
+            fg = lambda z: (lambda r: (r[0], r[3]))(self.action_grad(z, rf_scale))
+            return lbfgs_generic(fg, XP0, opt_args, bounds)
         x = np.array(XP0, dtype=np.float64)
         o = self._opts(opt_args)
         A, st, nit, nfev = C.c_double(), C.c_int32(), C.c_int32(), C.c_int64()

@@ -81,6 +81,7 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     E.pp.rm_full = d->rm_kind == 2 ? E.rm.data() : nullptr; E.pp.Lidx = E.lidx.data();
     E.pp.rf0_arr = d->rf_kind ? E.rf0.data() : nullptr;
     E.pp.Pidx = E.pidx.data(); E.pp.Pfull = E.P.data();
+    E.pp.lo = E.pp.hi = nullptr; m.bounded = 0;
     if (d->t_model) E.tm.assign(d->t_model, d->t_model + m.N);
     if (d->n_stim > 0) E.stim.assign(d->stim, d->stim + (size_t)m.N * d->n_stim);
     E.pp.tmodel = d->t_model ? E.tm.data() : nullptr;
@@ -112,7 +113,7 @@ void eval_seed(const Emul &E, int b, const double *x, const double *d, int use_d
         if (!dm.tdp) tile_params<RHS>(dm, E.pp, b, c);
         std::vector<ThreadAcc> acc(NT);
         for (auto &a : acc) a.clear();
-        for (int t = 0; t < NT; ++t) tile_load<DISC>(dm, c, t, NT);
+        for (int t = 0; t < NT; ++t) tile_load<DISC>(dm, E.pp, c, t, NT);
         if (dm.tdp) for (int t = 0; t < NT; ++t) tile_load_p<DISC>(dm, E.pp, b, c, t, NT);
         for (int t = 0; t < NT; ++t) tile_f<RHS, DISC>(dm, c, t, NT);
         for (int t = 0; t < NT; ++t) tile_q<DISC>(dm, E.pp, c, acc[t], t, NT);

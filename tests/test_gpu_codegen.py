@@ -108,3 +108,60 @@ def test_nakl_bounded_ladder_matches_reference(gold):
     assert np.all(a.P >= lo - 1e-12) and np.all(a.P <= hi + 1e-12)
     assert np.allclose(a.A_array, a.me_array + a.fe_array, rtol=1e-12)
     a.close()
+
+
+def test_nakl_bounded_ladder_on_the_device_batched(gold):
+    """Box bounds on the device (bounded_minimiser='device'): 16 seeds of the tutorial's bounded NaKL
+    ladder anneal in ONE call, nothing leaves HBM.  The device runs the active-set form of its L-BFGS
+    (not L-BFGS-B's Cauchy point: iterates differ from SciPy's), so what is asserted is: every stored
+    iterate inside the box to the last bit, all rungs converged, the unperturbed seed's actions close
+    to the reference's bounded ladder, and A = me + fe."""
+    c = gold["g5_nakl_ladder_SH_N101"]
+    N, D, B = int(c["N"]), 4, 16
+    rng = np.random.RandomState(3)
+    X0 = np.tile(c["X0"], (B, 1, 1)); P0 = np.tile(c["P0"], (B, 1))
+    X0[1:] += 1e-2 * rng.randn(B - 1, N, D); P0[1:] *= 1.0 + 1e-2 * rng.randn(B - 1, P0.shape[1])
+    bnds = [tuple(b) for b in c["bounds"]]
+    lo = np.array([b[0] for b in bnds]); hi = np.array([b[1] for b in bnds])
+    P0 = np.clip(P0, lo[4:], hi[4:])
+    a = va_ode.Annealer()
+    a.set_model(nakl, 4)
+    a.set_data(c["Y"], stim=c["stim"], t=c["t"])
+    a.anneal(X0, P0, float(c["alpha"]), c["beta"], 1.0, list(c["RF0"]), [0], list(range(18)), dt_model=None,
+             init_to_data=True, disc="SimpsonHermite", method='L-BFGS-B', bounds=bnds,
+             opt_args={'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000000, 'maxiter': 1000000}, adolcID=0, verbose=False)
+    assert a._device_bounds and a.A_array.shape == (B, len(c["beta"]))
+    X = a.minpaths[:, :, :N * D].reshape(B, -1, N, D); P = a.minpaths[:, :, N * D:]
+    assert np.all(X >= lo[:4]) and np.all(X <= hi[:4]) and np.all(P >= lo[4:]) and np.all(P <= hi[4:])
+    assert np.all(a.exitflags == 0)
+    assert np.allclose(a.A_array, a.me_array + a.fe_array, rtol=1e-12)
+    rel = np.abs(a.A_array[0] - c["A_array"]) / c["A_array"]
+    print("bounded NaKL ladder on the device, seed 0 vs the reference's SciPy ladder: rel. deviation per rung",
+          np.array2string(rel, precision=2), " iterations", a.nit_array[0], "reference", c["nit"])
+    assert np.all(rel[:4] <= 1e-3) and np.all(rel <= 5e-2)
+    a.close()
+
+
+def test_bounded_device_minimiser_follows_the_oracle_step_for_step():
+    """The device's bounded minimiser against the oracle's restatement of the same active-set form
+    (vao_lbfgs_bounded): identical (nit, nfev, status), same minimiser, on boxes that bind."""
+    import va_oracle
+    from varanneal_amd import twin
+    D, N, B = 20, 60, 3
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    XP = np.empty((B, N * D + 1)); P = np.empty((B, 1))
+    for b in range(B):
+        X0, P0 = twin.initial_guess(N, D, b, Y, Lidx)
+        XP[b, :-1] = X0.ravel(); XP[b, -1] = P0[0]; P[b] = P0
+    o = {'gtol': 1e-8, 'ftol': 1e-10, 'maxiter': 60, 'maxfun': 100000}
+    for bnds in ([(-4.0, 4.0)] * (N * D) + [(7.0, 7.5)], [(-1.0, 6.0)] * (N * D) + [(None, 8.0)],
+                 [(-15, 15)] * (N * D) + [(6.5, 10.0)]):
+        lo = np.array([-np.inf if q[0] is None else q[0] for q in bnds]); hi = np.array([np.inf if q[1] is None else q[1] for q in bnds])
+        with _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", bounds=bnds) as pb:
+            r = pb.minimize_lbfgs(XP, 50.0, o)
+        assert np.all(r["x"] >= lo) and np.all(r["x"] <= hi)
+        for b in range(B):
+            opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[b], [0])
+            x, A, st, nit, nfev = opb.minimize_lbfgs(XP[b], 50.0, o, bounds=bnds)
+            assert (r["nit"][b], r["nfev"][b], r["status"][b]) == (nit, nfev, st), (b, r["nit"][b], nit, r["nfev"][b], nfev)
+            assert abs(r["A"][b] - A) <= 1e-6 * abs(A) and np.abs(r["x"][b] - x).max() <= 1e-6

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VARANNEAL_AMD_LIB", os.path.join(_HERE, "libvaranneal_amd.so"))   # (env: diagnostic builds)
 
 VA_OK = 0
-ABI_VERSION = 8          # VA_ABI_VERSION of include/varanneal_amd.h
+ABI_VERSION = 9          # VA_ABI_VERSION of include/varanneal_amd.h
 ERRNAMES = {-1: "VA_EINVAL", -2: "VA_ENOMEM", -3: "VA_EHIP", -4: "VA_EUNSUPPORTED", -5: "VA_ESTATE"}
 DISC = {"euler": 0, "trapezoid": 1, "SimpsonHermite": 2, "forwardmap": 3}
 RHS = {"lorenz96": 0}
@@ -46,7 +46,8 @@ class ProblemDesc(C.Structure):
                 ("disc", C.c_int32), ("rhs", C.c_int32), ("lbfgs_m", C.c_int32),
                 ("max_beta", C.c_int32), ("keep_paths", C.c_int32), ("tile_rows", C.c_int32),
                 ("eval_kernel", C.c_int32), ("t_model", c_dp), ("stim", c_dp), ("n_stim", C.c_int32),
-                ("p_time_dependent", C.c_int32), ("stream", C.c_void_p)]
+                ("p_time_dependent", C.c_int32), ("stream", C.c_void_p),
+                ("lower", c_dp), ("upper", c_dp)]
 
 
 class NnetDesc(C.Structure):
@@ -81,7 +82,7 @@ def _f64(a):
 
 def make_desc(batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, disc="trapezoid",
               rhs="lorenz96", merr_nskip=1, lbfgs_m=10, max_beta=1, keep_paths=0, tile_rows=0,
-              eval_kernel=0, device=0, stream=None, t_model=None, stim=None, p_time_dependent=False):
+              eval_kernel=0, device=0, stream=None, t_model=None, stim=None, p_time_dependent=False, bounds=None):
     """Build a ProblemDesc plus the list of arrays that must outlive it.  With
     p_time_dependent, P has shape (batch, N_model, NP) (or (N_model, NP), shared by the seeds)."""
     Y = _f64(Y)
@@ -144,6 +145,16 @@ def make_desc(batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, disc="trap
     else:
         d.stim, d.n_stim = None, 0
     d.stream = stream
+    d.lower = d.upper = None
+    if bounds is not None:
+        # one (lo, hi) per entry of the path vector [X | p_est] (va_ode.py:582-605); None = no bound
+        n_var = N_model * (D + len(Pidx)) if p_time_dependent else N_model * D + len(Pidx)
+        if len(bounds) != n_var:
+            raise ValueError("bounds must have one (lo, hi) pair per entry of the path vector (%d), got %d" % (n_var, len(bounds)))
+        lo = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=np.float64)
+        hi = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=np.float64)
+        keep += [lo, hi]
+        d.lower, d.upper = lo.ctypes.data_as(c_dp), hi.ctypes.data_as(c_dp)
     return d, keep
 
 

@@ -115,6 +115,7 @@ void run_eval(va_handle h, int epi)
 void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, bool user_rhs)
 {
     user_rhs = user_rhs || d->p_time_dependent || d->rm_kind == 2;   // per-row parameters / full RM: flat kernel only
+    user_rhs = user_rhs || (d->lower && d->upper);                   // box bounds: the flat kernel carries the clamp / projected gradient
     const int D = d->D, N = d->N_model;
     const bool sh = d->disc == VA_DISC_SIMPSON_HERMITE;
     const int HLR = sh ? 3 : 2;
@@ -341,6 +342,7 @@ int run_ladder(va_handle h, const double *rf_scale, int nbeta)
     HIPCHK(hipMemcpyAsync(dv.n_active, h->h_nactive, sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(dv.dpp, 0, sizeof(double) * dv.dm.B * dv.dm.nchunks * DP_N, h->stream));
     launch_init_states(dv, PH_START, -1.0, h->stream);
+    if (dv.dm.bounded) launch_clamp_x(dv, h->stream);
     // every cycle costs each live seed at least one evaluation
     const double per_step = (double)dv.o.maxfun + dv.o.maxls + 4.0;
     const double bound = per_step * nbeta;
@@ -482,6 +484,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     if (tdp && (int64_t)d->N_model * (d->D + d->NPest) > 2000000000LL) return fail(VA_EUNSUPPORTED, "n_var does not fit 32-bit indexing");
     if (!d->Y || (d->L > 0 && !d->Lidx) || !d->P || (d->NPest > 0 && !d->Pidx)) return fail(VA_EINVAL, "null array in desc");
     if ((d->rm_kind && !d->rm_array) || (d->rf_kind && !d->rf0_array)) return fail(VA_EINVAL, "rm/rf array kind without array");
+    if ((d->lower != nullptr) != (d->upper != nullptr)) return fail(VA_EINVAL, "lower and upper bounds come together");
     {
         std::vector<char> seen(d->D, 0);
         for (int l = 0; l < d->L; ++l) {
@@ -520,6 +523,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dm.nskip = d->merr_nskip; dm.NP = d->NP; dm.NPest = d->NPest; dm.B = d->batch; dm.m = m;
     dm.disc = d->disc;
     dm.tdp = tdp ? 1 : 0; dm.NPt = d->NP; dm.NPe = d->NPest;
+    dm.bounded = (d->lower && d->upper) ? 1 : 0;
     if (tdp) { dm.ND = dm.N * (dm.D + dm.NPe); dm.NP = 0; dm.NPest = 0; }   // one flat run for the L-BFGS kernels
     dm.ld = ((dm.ND + dm.NPest + 15) / 16) * 16;
     pick_eval_geometry(d, dm, dv.g4, user != nullptr);
@@ -578,6 +582,17 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     if (d->rm_kind) TRY(h->alloc(&rm_d, rm_elems));
     if (d->rm_kind == 2) TRY(h->alloc(&lidx_d, dm.L));
     if (d->rf_kind) TRY(h->alloc(&rf_d, (size_t)(dm.N - 1) * dm.D));
+    double *lo_d = nullptr, *hi_d = nullptr;
+    std::vector<double> lo_h, hi_h;
+    if (dm.bounded) {
+        const int nv = dm.ND + dm.NPest;
+        lo_h.assign(dm.ld, -HUGE_VAL); hi_h.assign(dm.ld, HUGE_VAL);
+        for (int i = 0; i < nv; ++i) {
+            if (!(d->lower[i] <= d->upper[i])) { va_problem_destroy(h); return fail(VA_EINVAL, "lower[%d] > upper[%d] (or NaN)", i, i); }
+            lo_h[i] = d->lower[i]; hi_h[i] = d->upper[i];
+        }
+        TRY(h->alloc(&lo_d, (size_t)dm.ld)); TRY(h->alloc(&hi_d, (size_t)dm.ld));
+    }
     if (d->t_model) TRY(h->alloc(&t_d, (size_t)dm.N));
     if (d->n_stim > 0) TRY(h->alloc(&st_d, (size_t)dm.N * d->n_stim));
     TRY(alloc_solver_state(h, max_beta, d->keep_paths));
@@ -612,6 +627,8 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     if (d->rm_kind) H2D(rm_d, d->rm_kind == 1 ? rms.data() : d->rm_array, rm_elems, double);
     if (d->rm_kind == 2) H2D(lidx_d, d->Lidx, dm.L, int);
     if (d->rf_kind) H2D(rf_d, d->rf0_array, (size_t)(dm.N - 1) * dm.D, double);
+    if (dm.bounded) { H2D(lo_d, lo_h.data(), (size_t)dm.ld, double); H2D(hi_d, hi_h.data(), (size_t)dm.ld, double); }
+    dv.pp.lo = lo_d; dv.pp.hi = hi_d;
     if (d->t_model) H2D(t_d, d->t_model, (size_t)dm.N, double);
     if (d->n_stim > 0) H2D(st_d, d->stim, (size_t)dm.N * d->n_stim, double);
     dv.pp.lmap = lmap_d; dv.pp.Y = Y_d; dv.pp.rf0_arr = rf_d;

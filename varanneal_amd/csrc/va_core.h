@@ -50,7 +50,7 @@ constexpr int EP_N = EP_GP + RHS_MAX_NP;
 // update partial columns: 5 fixed + 4 per old history slot
 enum { UP_YGT = 0, UP_SGT = 1, UP_YY = 2, UP_SY = 3, UP_GTGT = 4, UP_OLD = 5 };
 constexpr int UP_N = UP_OLD + 4 * MAX_M;
-enum { DP_GD = 0, DP_DD = 1, DP_N = 2 };
+enum { DP_GD = 0, DP_DD = 1, DP_STPMX = 2, DP_N = 3 };   // g.d, d.d, largest step inside the box (min)
 
 struct Dims {
     int D, N, ND, ld, L, N_data, nskip, NP, NPest, T, ntiles, B, m, disc, nchunks, chunk;
@@ -62,6 +62,7 @@ struct Dims {
     // L-BFGS kernels (one flat run), and the flat tile kernel uses NPt / NPe.  Static: tdp = 0,
     // NPt = NP, NPe = NPest.
     int tdp, NPt, NPe;
+    int bounded;               // box bounds on the path vector (ProblemPtrs::lo / hi)
     double dt, cme, cfe, rm, rf0;
 };
 
@@ -78,6 +79,7 @@ struct ProblemPtrs {
     int nstim;
     const int *Lidx;       // [L] observed state columns (full-RM problems only)
     const double *rm_full; // NULL or [N_data*L*L]: full measurement precision matrices (va_ode.py:149-152)
+    const double *lo, *hi; // NULL or [ld]: box bounds of the path vector (va_ode.py:582-605), +-HUGE_VAL = none
 };
 
 struct LsState {
@@ -103,6 +105,7 @@ struct SeedHot {
     LsState ls;
     double cg;
     double gd_dir;          // g.d of the direction in use (left by k_direction's last arriver)
+    double stpmx;           // bounded problems: the largest step along d that stays inside the box
 };
 static_assert(sizeof(SeedHot) <= 512 && sizeof(SeedHot) % 8 == 0, "SeedHot must fit one wave-wide 8-byte load");
 
@@ -165,6 +168,10 @@ struct ThreadAcc {
 // trial point; the SAME expression is used by the update kernel so that the
 // accepted iterate is bit-identical to the point that was evaluated.
 VA_HD double trial(double x, double stp, double d) { return fma(stp, d, x); }
+// ... and inside the box to the last bit when there is one (stp <= stpmx keeps it there up to rounding)
+VA_HD double clampb(double v, const ProblemPtrs &pp, long i) { return pp.lo ? fmin(fmax(v, pp.lo[i]), pp.hi[i]) : v; }
+// L-BFGS-B's projected gradient (projgr): what the convergence test looks at when there are bounds
+VA_HD double proj_grad(double x, double g, double l, double u) { return g < 0.0 ? fmax(x - u, g) : fmin(x - l, g); }
 
 template <class RHS>
 VA_HD void tile_params(const Dims &dm, const ProblemPtrs &pp, int b, TileCtx &c)
@@ -173,7 +180,7 @@ VA_HD void tile_params(const Dims &dm, const ProblemPtrs &pp, int b, TileCtx &c)
     for (int k = 0; k < RHS::NP; ++k) c.p[k] = pp.Pfull[(size_t)b * dm.NP + k];
     for (int k = 0; k < dm.NPest; ++k) {
         double v = c.xg[dm.ND + k];
-        if (c.use_d) v = trial(v, c.stp, c.dg[dm.ND + k]);
+        if (c.use_d) v = clampb(trial(v, c.stp, c.dg[dm.ND + k]), pp, dm.ND + k);
         const int dst = pp.Pidx[k];
         // select chain instead of c.p[dst]: a runtime-indexed array would live in scratch
 #pragma unroll
@@ -183,7 +190,7 @@ VA_HD void tile_params(const Dims &dm, const ProblemPtrs &pp, int b, TileCtx &c)
 
 // phase 1: stage rows [n0-HL, n0-HL+R) of x (or x + stp*d); rows outside [0,N) read as 0.
 template <int DISC>
-VA_HD void tile_load(const Dims &dm, TileCtx &c, int tid, int nt)
+VA_HD void tile_load(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, int tid, int nt)
 {
     const long base = (long)(c.n0 - Halo<DISC>::HL) * dm.D;
     const int tot = c.R * dm.D;
@@ -193,7 +200,7 @@ VA_HD void tile_load(const Dims &dm, TileCtx &c, int tid, int nt)
         double v = 0.0;
         if (gi >= 0 && gi < NDx) {
             v = c.xg[gi];
-            if (c.use_d) v = trial(v, c.stp, c.dg[gi]);
+            if (c.use_d) v = clampb(trial(v, c.stp, c.dg[gi]), pp, gi);
         }
         c.xs[e] = v;
     }
@@ -216,7 +223,7 @@ VA_HD void tile_load_p(const Dims &dm, const ProblemPtrs &pp, int b, TileCtx &c,
             if (est >= 0) {
                 const long gi = NDx + (long)row * dm.NPe + est;
                 v = c.xg[gi];
-                if (c.use_d) v = trial(v, c.stp, c.dg[gi]);
+                if (c.use_d) v = clampb(trial(v, c.stp, c.dg[gi]), pp, gi);
             } else v = pp.Pfull[((size_t)b * dm.N + row) * NPt + k];
         }
         c.ps[e] = v;
@@ -376,7 +383,7 @@ VA_HD void tile_g(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &
             c.gtg[gi] = g;
             if (c.use_d) acc.v[EP_GTD] += g * c.dg[gi];
             acc.v[EP_GN2] += g * g;
-            acc.v[EP_GMAX] = fmax(acc.v[EP_GMAX], fabs(g));
+            acc.v[EP_GMAX] = fmax(acc.v[EP_GMAX], fabs(pp.lo ? proj_grad(xr[j], g, pp.lo[gi], pp.hi[gi]) : g));
         }
         lt += dlr; j += dj;
         if (j >= D) { j -= D; ++lt; }
@@ -408,7 +415,9 @@ VA_HD void tile_gp(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc 
             c.gtg[gi] = g;
             if (c.use_d) acc.v[EP_GTD] += g * c.dg[gi];
             acc.v[EP_GN2] += g * g;
-            acc.v[EP_GMAX] = fmax(acc.v[EP_GMAX], fabs(g));
+            double pv = 0.0;
+            for (int k = 0; k < RHS_MAX_NP; ++k) pv = (k == dst) ? pr[k < dm.NPt ? k : 0] : pv;
+            acc.v[EP_GMAX] = fmax(acc.v[EP_GMAX], fabs(pp.lo ? proj_grad(pv, g, pp.lo[gi], pp.hi[gi]) : g));
         }
     }
 }
@@ -569,9 +578,10 @@ VA_HD_FLAT void reset_memory(SeedHot &s) { s.col = 0; s.head = 0; s.theta = 1.0;
 // contributions; dirp[] = (g.d, d.d) of the direction in use.
 VA_HD_FLAT void ls_step(SeedHot &s, const double *ev, const double *dirp, const Opts &o,
                    const double *rf_ladder, int nbeta, const SeedResults &r, int *n_active_dec,
-                   double cme, double cfe)
+                   double cme, double cfe, bool bounded = false)
 {
     const double epsmch = 2.220446049250313e-16, big = 1e10;
+    const double stpmax = bounded ? s.stpmx : big;       // bounded: the line search stops at the box
     s.upd = 0; s.dir = 0; s.nold = 0; s.store_idx = -1;
     const double me = ev[EP_ME] * cme, fe = ev[EP_FE] * cfe * s.rf_scale;
     const double ft = me + fe;
@@ -591,7 +601,7 @@ VA_HD_FLAT void ls_step(SeedHot &s, const double *ev, const double *dirp, const 
         s.gdold = dirp[DP_GD]; s.fold = s.f;
         if (s.gdold >= 0.0) fail = true;
         else {
-            s.ls_task = dcsrch(s.f, s.gdold, s.stp, 1e-3, 0.9, 0.1, 0.0, big, LS_START, s.ls);
+            s.ls_task = dcsrch(s.f, s.gdold, s.stp, 1e-3, 0.9, 0.1, 0.0, stpmax, LS_START, s.ls);
             if (s.ls_task == LS_ERROR) fail = true;
             else { s.ifun = 1; s.iback = 0; s.nfev += 1; }    // the evaluation we are consuming
         }
@@ -599,7 +609,7 @@ VA_HD_FLAT void ls_step(SeedHot &s, const double *ev, const double *dirp, const 
     double stp_eval = s.stp;
     if (!fail) {
         s.gd = ev[EP_GTD];
-        s.ls_task = dcsrch(ft, s.gd, s.stp, 1e-3, 0.9, 0.1, 0.0, big, LS_FG, s.ls);
+        s.ls_task = dcsrch(ft, s.gd, s.stp, 1e-3, 0.9, 0.1, 0.0, stpmax, LS_FG, s.ls);
         if (s.ls_task == LS_FG) {
             s.ifun += 1; s.iback = s.ifun - 1;
             if (s.iback >= o.maxls) fail = true;
@@ -621,7 +631,7 @@ VA_HD_FLAT void ls_step(SeedHot &s, const double *ev, const double *dirp, const 
     if (s.iter >= o.maxiter) { finish_step(s, 1, true, rf_ladder, nbeta, r, n_active_dec); return; }
     if (s.nfev > o.maxfun) { finish_step(s, 1, true, rf_ladder, nbeta, r, n_active_dec); return; }
     if (ev[EP_GMAX] <= o.gtol) { finish_step(s, 0, true, rf_ladder, nbeta, r, n_active_dec); return; }
-    {
+    if (!(bounded && stp_eval >= stpmax)) {      // (a step that ended on a bound was cut short: no verdict on progress)
         const double dd = fmax(fmax(fabs(fold), fabs(ft)), 1.0);
         if (fold - ft <= o.ftol * dd) { finish_step(s, 0, true, rf_ladder, nbeta, r, n_active_dec); return; }
     }

@@ -120,11 +120,11 @@ __device__ __forceinline__ void reduce_eval_block(const Dev &dv, int b, int lane
 
 // parameter tail of grad A (sum over tiles of the per-tile parameter partials) and its
 // share of the line-search sums.
-__device__ __forceinline__ void eval_tail(const Dev &dv, int b, int use_d, double *ev)
+__device__ __forceinline__ void eval_tail(const Dev &dv, int b, int use_d, double *ev, double stp = 0.0)
 {
     const Dims &dm = dv.dm;
     double *gt = dv.gt + (size_t)b * dm.ld;
-    const double *d = dv.d + (size_t)b * dm.ld;
+    const double *d = dv.d + (size_t)b * dm.ld, *x = dv.x + (size_t)b * dm.ld;
     for (int k = 0; k < dm.NPest; ++k) {
         // (select chain, not ev[EP_GP + idx]: a run-time index would put ev[] -- and with it every wave
         // of the evaluation kernel -- on scratch memory)
@@ -135,7 +135,13 @@ __device__ __forceinline__ void eval_tail(const Dev &dv, int b, int use_d, doubl
         gt[dm.ND + k] = g;
         if (use_d) ev[EP_GTD] += g * as_const(d)[dm.ND + k];
         ev[EP_GN2] += g * g;
-        ev[EP_GMAX] = fmax(ev[EP_GMAX], fabs(g));
+        double pg = g;
+        if (dv.pp.lo) {        // bounded: the convergence test looks at the projected gradient
+            double xv = as_const(x)[dm.ND + k];
+            if (use_d) xv = clampb(trial(xv, stp, as_const(d)[dm.ND + k]), dv.pp, dm.ND + k);
+            pg = proj_grad(xv, g, dv.pp.lo[dm.ND + k], dv.pp.hi[dm.ND + k]);
+        }
+        ev[EP_GMAX] = fmax(ev[EP_GMAX], fabs(pg));
     }
 }
 
@@ -173,7 +179,7 @@ __device__ __forceinline__ void eval_epilogue(const Dev &dv, int b, int lane, Se
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (lane == 0) {
         atomicAdd(dv.n_evals, 1ULL);
-        eval_tail(dv, b, sh->phase == PH_LS, ev);
+        eval_tail(dv, b, sh->phase == PH_LS, ev, sh->stp);
         SeedResults r;
         r.ame = dv.ame + (size_t)b * dv.max_beta * 3;
         r.pest = nullptr;
@@ -183,7 +189,7 @@ __device__ __forceinline__ void eval_epilogue(const Dev &dv, int b, int lane, Se
         int dec = 0;
         double dirp[DP_N];
         dirp[DP_GD] = sh->gd_dir; dirp[DP_DD] = 0.0;
-        ls_step(*sh, ev, dirp, dv.o, dv.rf_ladder, dv.nbeta, r, &dec, dm.cme, dm.cfe);
+        ls_step(*sh, ev, dirp, dv.o, dv.rf_ladder, dv.nbeta, r, &dec, dm.cme, dm.cfe, dm.bounded != 0);
         if (dec) atomicSub(dv.n_active, 1);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

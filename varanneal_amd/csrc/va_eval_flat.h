@@ -117,7 +117,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
     const int tid = threadIdx.x, nt = blockDim.x;
     ThreadAcc acc;
     acc.clear();
-    tile_load<DISC>(dm, c, tid, nt);
+    tile_load<DISC>(dm, dv.pp, c, tid, nt);
     if (dm.tdp) tile_load_p<DISC>(dm, dv.pp, b, c, tid, nt);
     __syncthreads();
     tile_f<RHS, DISC>(dm, c, tid, nt);

@@ -576,13 +576,26 @@ __global__ void k_init_states(const Dev dv, int phase, double rf)
     s.phase = phase; s.beta_idx = 0; s.iter = 0; s.col = 0; s.head = 0; s.ifun = 0; s.iback = 0;
     s.ls_task = LS_START; s.upd = 0; s.slot = 0; s.dir = 0; s.store_idx = -1; s.nold = 0;
     s.nfev = 0; s.f = 0.0; s.fold = 0.0; s.me = 0.0; s.fe = 0.0; s.theta = 1.0; s.stp = 0.0;
-    s.stp_upd = 0.0; s.gd = 0.0; s.gdold = 0.0; s.gn2 = 0.0; s.dr = 0.0; s.cg = -1.0; s.gd_dir = 0.0;
+    s.stp_upd = 0.0; s.gd = 0.0; s.gdold = 0.0; s.gn2 = 0.0; s.dr = 0.0; s.cg = -1.0; s.gd_dir = 0.0; s.stpmx = 1e10;
     s.rf_scale = rf < 0.0 ? dv.rf_ladder[0] : rf;
     dv.cnt_eval[(size_t)b * CNT_STRIDE] = 0u; dv.cnt_upd[(size_t)b * CNT_STRIDE] = 0u; dv.cnt_dir[(size_t)b * CNT_STRIDE] = 0u;
 }
 void launch_init_states(const Dev &dv, int phase, double rf, hipStream_t s)
 {
     hipLaunchKernelGGL(k_init_states, dim3((dv.dm.B + 63) / 64), dim3(64), 0, s, dv, phase, rf);
+}
+
+// bounded problems: the start point is projected onto the box (as L-BFGS-B does with x0)
+__global__ void k_clamp_x(const Dev dv)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dv.dm.ld) return;
+    double *x = dv.x + (size_t)blockIdx.y * dv.dm.ld;
+    x[i] = fmin(fmax(x[i], dv.pp.lo[i]), dv.pp.hi[i]);
+}
+void launch_clamp_x(const Dev &dv, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_clamp_x, dim3((dv.dm.ld + 255) / 256, dv.dm.B), dim3(256), 0, s, dv);
 }
 
 // measurement only (va_lbfgs_timed): every seed as if in the middle of a long minimisation -- history
@@ -746,7 +759,8 @@ __global__ __launch_bounds__(VEC_THREADS) void k_update(const Dev dv)
         double2 xv = *reinterpret_cast<const double2 *>(x + i);
         gtv[e] = tv;
         if (upd & UPD_X) {
-            xv.x = trial(xv.x, stp, dv2.x); xv.y = trial(xv.y, stp, dv2.y);
+            // (the same expression as the evaluated trial point, clamp into the box included)
+            xv.x = clampb(trial(xv.x, stp, dv2.x), dv.pp, i); xv.y = clampb(trial(xv.y, stp, dv2.y), dv.pp, i + 1);
             *reinterpret_cast<double2 *>(x + i) = xv;
         }
         if (upd & UPD_STORE) {
@@ -878,32 +892,69 @@ __global__ __launch_bounds__(VEC_THREADS) void k_direction(const Dev dv)
             acc[e].x += cs * sv.x; acc[e].y += cs * sv.y;
         }
     }
-    double gd = 0.0, dd = 0.0;
+    double gd = 0.0, dd = 0.0, smx = 1e10;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         if (idx[e] >= dm.ld) continue;
+        if (dm.bounded) {
+            // box bounds: a component that would leave the box from the bound it sits on is dropped;
+            // the others limit the step (va_core.h: ls_step stops the line search at stpmx)
+            const double2 xv = *reinterpret_cast<const double2 *>(dv.x + vo + idx[e]);
+            const double xs[2] = {xv.x, xv.y};
+            double ds[2] = {acc[e].x, acc[e].y};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const double l = dv.pp.lo[idx[e] + u], h = dv.pp.hi[idx[e] + u];
+                if ((xs[u] <= l && ds[u] < 0.0) || (xs[u] >= h && ds[u] > 0.0)) ds[u] = 0.0;
+                if (ds[u] > 0.0) smx = fmin(smx, (h - xs[u]) / ds[u]);
+                else if (ds[u] < 0.0) smx = fmin(smx, (l - xs[u]) / ds[u]);
+            }
+            acc[e] = make_double2(ds[0], ds[1]);
+        }
         *reinterpret_cast<double2 *>(d + idx[e]) = acc[e];
         gd += gv[e].x * acc[e].x + gv[e].y * acc[e].y;
         dd += acc[e].x * acc[e].x + acc[e].y * acc[e].y;
     }
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    gd = wave_sum(gd); dd = wave_sum(dd);
-    if (lane == 0) { red[wave * DP_N + DP_GD] = gd; red[wave * DP_N + DP_DD] = dd; }
+    gd = wave_sum(gd); dd = wave_sum(dd); smx = -wave_max(-smx);
+    if (lane == 0) { red[wave * DP_N + DP_GD] = gd; red[wave * DP_N + DP_DD] = dd; red[wave * DP_N + DP_STPMX] = smx; }
     __syncthreads();
     if (wave != 0) return;
     if (lane < DP_N) {
         double v = red[lane];
 #pragma unroll
-        for (int ww = 1; ww < VEC_THREADS / 64; ++ww) v += red[ww * DP_N + lane];
+        for (int ww = 1; ww < VEC_THREADS / 64; ++ww) v = (lane == DP_STPMX) ? fmin(v, red[ww * DP_N + lane]) : v + red[ww * DP_N + lane];
         st_sc1(dv.dpp + ((size_t)b * dm.nchunks + chunk) * DP_N + lane, v);
     }
-    // the seed's last workgroup leaves g.d for the line search and consumes the request
+    // the seed's last workgroup leaves g.d (and the step limits of a bounded problem) for the line
+    // search and consumes the request
     if (!arrive_last(dv.cnt_dir + (size_t)b * CNT_STRIDE, (unsigned)dm.nchunks, lane)) return;
-    const int k = lane & 1, r = lane >> 1;
-    double v = col_reduce<true>(dv.dpp + (size_t)b * dm.nchunks * DP_N + k, dm.nchunks, DP_N, r, 32, false);
+    double tot[DP_N];
 #pragma unroll
-    for (int o = 32; o >= 2; o >>= 1) v += __shfl_down(v, o, 64);         // lanes 0 and 1 hold the totals
-    if (lane == 0) { dv.st[b].gd_dir = v; if (!dv.sticky) dv.st[b].dir = 0; }
+    for (int c = 0; c < DP_N; ++c) {
+        // lane r takes rows r, r+64, ...; the 64 lane totals meet through shuffles in a fixed order
+        double v = c == DP_STPMX ? 1e10 : 0.0;
+        for (int t = lane; t < dm.nchunks; t += 64) {
+            const double q = ld_sc1(dv.dpp + ((size_t)b * dm.nchunks + t) * DP_N + c);
+            v = c == DP_STPMX ? fmin(v, q) : v + q;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double q = __shfl_down(v, o, 64);
+            v = c == DP_STPMX ? fmin(v, q) : v + q;
+        }
+        tot[c] = v;
+    }
+    if (lane == 0) {
+        SeedState &s = dv.st[b];
+        s.gd_dir = tot[DP_GD];
+        if (dm.bounded) {
+            // the first trial step of the line search must already respect the box
+            s.stpmx = tot[DP_STPMX];
+            s.stp = fmin(s.iter == 0 ? fmin(1.0 / sqrt(tot[DP_DD]), 1e10) : 1.0, s.stpmx);
+        }
+        if (!dv.sticky) s.dir = 0;
+    }
 }
 void launch_direction(const Dev &dv, hipStream_t s)
 {

@@ -92,7 +92,8 @@ class Annealer(HIPmin):
                init_to_data=True, action='A_gaussian', disc='trapezoid',
                method='L-BFGS-B', bounds=None, opt_args=None, adolcID=0,
                track_paths=None, track_params=None, track_action_errors=None,
-               *, device=None, verbose=True, fused=None, n_seeds=None, devices=None, gather=True):
+               *, device=None, verbose=True, fused=None, n_seeds=None, devices=None, gather=True,
+               bounded_minimiser=None):
         """Full ladder (va_ode.py:459-528).  With no per-step tracking and the device
         minimiser, the whole ladder runs in one C-ABI call (`fused`).
 
@@ -104,7 +105,12 @@ class Annealer(HIPmin):
                    ONE all-gather leaves the per-seed tables of all seeds in `self.gathered` on every
                    rank.  A seed's results do not depend on how many ranks share the work.
           devices  device ordinals to use (rank r takes devices[r % len]); default LOCAL_RANK
-          gather   False: skip the collective (`self.gathered` then holds this rank's seeds only)"""
+          gather   False: skip the collective (`self.gathered` then holds this rank's seeds only)
+          bounded_minimiser  with `bounds`: 'scipy' = SciPy's L-BFGS-B on the host around the device
+                   evaluator, exactly the reference's call (_autodiffmin.py:85-86; one seed; the default
+                   for a single seed); 'device' = the device-resident minimiser in its active-set form
+                   (every seed at once, nothing leaves HBM; not L-BFGS-B's generalised Cauchy point, so
+                   iterates differ from SciPy's; the default for batched seeds)"""
         if n_seeds is not None:
             from . import parallel
             X0 = np.asarray(X0); P0 = np.asarray(P0, dtype=np.float64)
@@ -121,7 +127,7 @@ class Annealer(HIPmin):
                 self.anneal(X0[lo:hi], P0[lo:hi], alpha, beta_array, RM, RF0, Lidx, Pidx, dt_model,
                             init_to_data, action, disc, method, bounds, opt_args, adolcID,
                             track_paths, track_params, track_action_errors,
-                            device=device, verbose=verbose, fused=fused)
+                            device=device, verbose=verbose, fused=fused, bounded_minimiser=bounded_minimiser)
                 ND = self.N_model * self.D
                 local = {"A": self._A, "me": self._me, "fe": self._fe, "params": self._mp[:, :, ND:],
                          "exitflags": self._flags, "nit": self._nit, "nfev": self._nfev}
@@ -140,7 +146,7 @@ class Annealer(HIPmin):
         if self.annealing_initialized is False:       # reference: flag is never set (va_ode.py:468,705)
             self.anneal_init(X0, P0, alpha, beta_array, RM, RF0, Lidx, Pidx, dt_model,
                              init_to_data, action, disc, method, bounds, opt_args, adolcID,
-                             device=device, verbose=verbose)
+                             device=device, verbose=verbose, bounded_minimiser=bounded_minimiser)
         tracking = any(t is not None for t in (track_paths, track_params, track_action_errors))
         if fused is None:
             fused = (not tracking) and self._device_minimiser
@@ -171,7 +177,7 @@ class Annealer(HIPmin):
     def anneal_init(self, X0, P0, alpha, beta_array, RM, RF0, Lidx, Pidx, dt_model=None,
                     init_to_data=True, action='A_gaussian', disc='trapezoid',
                     method='L-BFGS-B', bounds=None, opt_args=None, adolcID=0,
-                    *, device=0, verbose=True):
+                    *, device=0, verbose=True, bounded_minimiser=None):
         """va_ode.py:531-705."""
         if method not in ('L-BFGS-B', 'NCG', 'LM', 'TNC'):
             print("ERROR: Optimization routine not recognized. Annealing not initialized.")
@@ -301,9 +307,15 @@ class Annealer(HIPmin):
             self.bounds += [param_b[i] for _ in range(self.N_model if self._tdp else 1) for i in range(self.NPest)]
         else:
             self.bounds = None
-        self._device_minimiser = (method == 'L-BFGS-B' and bounds is None)
+        if bounded_minimiser is None:
+            bounded_minimiser = 'scipy' if self.B == 1 else 'device'
+        if bounded_minimiser not in ('scipy', 'device'):
+            raise ValueError("bounded_minimiser must be 'scipy' or 'device'")
+        self._device_bounds = bounds is not None and method == 'L-BFGS-B' and bounded_minimiser == 'device'
+        self._device_minimiser = (method == 'L-BFGS-B' and (bounds is None or self._device_bounds))
         if not self._device_minimiser and self.B != 1:
-            raise ValueError("bounds / NCG / TNC run SciPy on the host around the device evaluator: one seed only")
+            raise ValueError("NCG / TNC / bounded_minimiser='scipy' run SciPy on the host around the device "
+                             "evaluator: one seed only")
 
         # initial path (va_ode.py:666-693); init_to_data overwrites the caller's X0 in place, as upstream
         if init_to_data is True:
@@ -336,7 +348,8 @@ class Annealer(HIPmin):
                                  p_time_dependent=self._tdp,
                                  t_model=np.asarray(self.t_model, dtype=np.float64), stim=stim,
                                  lbfgs_m=int((opt_args or {}).get("maxcor", 10)),
-                                 max_beta=self.Nbeta, keep_paths=1, device=device)
+                                 max_beta=self.Nbeta, keep_paths=1, device=device,
+                                 bounds=self.bounds if self._device_bounds else None)
         self.initalized = True                        # sic (va_ode.py:705)
 
     # views with the reference's shapes
