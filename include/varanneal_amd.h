@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VA_ABI_VERSION 9
+#define VA_ABI_VERSION 10
 
 enum { VA_OK = 0, VA_EINVAL = -1, VA_ENOMEM = -2, VA_EHIP = -3, VA_EUNSUPPORTED = -4,
        VA_ESTATE = -5 };
@@ -117,12 +117,23 @@ int va_device_count(int32_t *count);
  * varanneal_amd/csrc/va_user_rhs.hip + a generated header); returns its rhs id. */
 int va_rhs_load_module(const char *path, int32_t *rhs_id);
 
+/* For the code generator: which instantiation of the wave-private column-run kernel (k_eval4) a problem
+ * of this shape would run for a model whose column form publishes `ne` products per element.  Reads only
+ * the sizes, kinds and flags of `desc` (pointers other than lower/upper are not followed; no GPU call).
+ * out[4] = (1 if that kernel applies else 0, disc, rows per run K, 1 if scalar weights else 0).  A
+ * module built for exactly that triple runs on k_eval4; any other problem runs its flat kernel. */
+int va_eval4_plan(const va_problem_desc *desc, int32_t ne, int32_t *out);
+
 int va_problem_create(const va_problem_desc *desc, va_handle *out);
 void va_problem_destroy(va_handle h);
 
 /* n_var = N_model*D + NPest; ld_internal = device stride the library uses. */
 int va_problem_info(va_handle h, int64_t *n_var, int64_t *ld_internal, int32_t *tile_rows,
                     int32_t *ntiles);
+
+/* Which evaluation kernel the handle runs (the values of va_problem_desc.eval_kernel: 1 flat,
+ * 3 workgroup column runs, 4 wave-private column runs) and the rows per lane run (0 for the flat kernel). */
+int va_problem_eval_kernel(va_handle h, int32_t *eval_kernel, int32_t *run_rows);
 
 /* S1 evaluator -- replaces ADmin.A_gradA_taped (_autodiffmin.py:57-58), batched:
  * (A, me, fe, grad A) for all B seeds at RF = RF0*rf_scale.  me/fe follow

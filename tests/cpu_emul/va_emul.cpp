@@ -4,6 +4,7 @@
 // kernels execute, run phase by phase with an emulated thread loop.  Lets the CPU
 // test-suite cover halo indexing, edge tiles and the per-seed state machine without
 // a GPU.  Never linked into libvaranneal_amd.so and never used as a fallback.
+#include <cstdio>
 #include <stdlib.h>
 #include <string.h>
 
@@ -52,7 +53,11 @@ int setup(const va_problem_desc *d, int T, Emul &E)
         if (m.disc == DISC_SH && (K & 1)) ++K;
         const char *se = getenv("VA_EMUL_SUB");            // sub-tiles per wave (the device picks 1..3, va_capi.hip)
         const int SUB = se ? atoi(se) : 1;
-        E.g4 = m.disc == DISC_SH ? tile4_geo<3>(m.D, K, RhsL96s::NE, SUB) : tile4_geo<2>(m.D, K, RhsL96s::NE, SUB);
+        int ne = RhsL96s::NE;
+#ifdef VA_USER_COL
+        if (d->rhs >= VA_RHS_USER_BASE) ne = RhsUserCol::NE;
+#endif
+        E.g4 = m.disc == DISC_SH ? tile4_geo<3>(m.D, K, ne, SUB) : tile4_geo<2>(m.D, K, ne, SUB);
         if ((E.g4.XP + 63) / 64 > T4_NI_MAX || !tile4_magic_ok(E.g4)) return VA_EUNSUPPORTED;
         m.RY = 4 * (64 / m.D); m.NT = 256; m.maxr = K; T = E.g4.T;
     }
@@ -86,7 +91,12 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     if (d->n_stim > 0) E.stim.assign(d->stim, d->stim + (size_t)m.N * d->n_stim);
     E.pp.tmodel = d->t_model ? E.tm.data() : nullptr;
     E.pp.stim = d->n_stim > 0 ? E.stim.data() : nullptr; E.pp.nstim = d->n_stim;
-    if (d->rhs >= VA_RHS_USER_BASE || m.tdp || d->rm_kind == 2) m.emode = 1;
+    bool user_flat = d->rhs >= VA_RHS_USER_BASE;
+#ifdef VA_USER_COL
+    // a generated model with a column form runs the wave-private kernel's phases when asked for by name
+    if (d->eval_kernel == 4 && m.emode == 4) user_flat = false;
+#endif
+    if (user_flat || m.tdp || d->rm_kind == 2) m.emode = 1;
     E.rhs = d->rhs;
     if (m.disc == DISC_SH && (m.N % 2) == 0) return VA_EINVAL;
     return VA_OK;
@@ -217,7 +227,7 @@ void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_
                 const int sp = tile4_src_piece(g, q);
                 if (sp < 0) continue;
                 const long si = src0 + 2L * sp;
-                if (si < 0 || si + 1 >= (long)xg.size() || 2 * q + 1 >= g.XW) abort();      // a fault on the device
+                if (si < 0 || si + 1 >= (long)xg.size() || 2 * q + 1 >= g.XW) { fprintf(stderr, "emul: image piece %d out of range\n", q); abort(); }      // a fault on the device
                 xs[2 * q] = xg[si]; xs[2 * q + 1] = xg[si + 1];
                 if (use_d) { xs[2 * q] = trial(xg[si], stp, dgv[si]); xs[2 * q + 1] = trial(xg[si + 1], stp, dgv[si + 1]); }
             }
@@ -233,7 +243,7 @@ void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_
                 c.wobs = c.l >= 0 ? dm.rm : 0.0;
                 c.xs = xs.data(); c.es = r2.data(); c.gtg = gt;
                 Tile2 tmp; tmp.xg = x; tmp.dg = d; tmp.use_d = use_d; tmp.stp = stp;
-                tile2_params<RhsL96c>(dm, E.pp, b, tmp);
+                tile2_params<RHS>(dm, E.pp, b, tmp);           // (only RHS::NP is used)
                 for (int k = 0; k < RHS_MAX_NP; ++k) c.p[k] = tmp.p[k];
                 acc[l].clear();
                 tile4_obs<K, NE>(dm, E.pp, c, rg[l]);
@@ -264,7 +274,7 @@ void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_
                 }
                 for (int k = 0; k < K; ++k) {
                     if (th[l].r0 + k < dm.N) gt[(long)(th[l].r0 + k) * D + th[l].tx] = gvv[k];
-                    else if (gvv[k] != 0.0) abort();          // rows that do not exist must come out as exact zeros
+                    else if (gvv[k] != 0.0) { fprintf(stderr, "emul: row %d col %d beyond N has gradient %g\n", th[l].r0 + k, th[l].tx, gvv[k]); abort(); }          // rows that do not exist must come out as exact zeros
                 }
             }
             for (int l = 0; l < NL; ++l)
@@ -280,6 +290,16 @@ void eval_seed_rhs(const Emul &E, int b, const double *x, const double *d, int u
                    double rf_scale, double *gt, double *ev)
 {
 #ifdef VA_USER_RHS_HEADER
+#ifdef VA_USER_COL
+    if (E.rhs >= VA_RHS_USER_BASE && E.dm.emode == 4) {
+        if (E.dm.maxr == 4) eval_seed4<RhsUserCol, DISC, 4>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 5) eval_seed4<RhsUserCol, DISC, 5>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 6) eval_seed4<RhsUserCol, DISC, 6>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 7) eval_seed4<RhsUserCol, DISC, 7>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else eval_seed4<RhsUserCol, DISC, 8>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        return;
+    }
+#endif
     if (E.rhs >= VA_RHS_USER_BASE) { eval_seed<RhsUser, DISC>(E, b, x, d, use_d, stp, rf_scale, gt, ev); return; }
 #endif
     if (E.dm.emode == 4) {

@@ -125,3 +125,113 @@ def test_generated_nakl_matches_reference_golden(nakl_module, name):
     assert abs(A[0] - c["A"]) <= 1e-12 * c["A"]
     assert abs(me[0] - c["me"]) <= 1e-12 * c["A"] and abs(fe[0] - c["fe"]) <= 1e-12 * c["A"]
     assert np.abs(g[0] - c["grad"]).max() <= 1e-10 * np.abs(c["grad"]).max()
+
+
+# ---- the column form (codegen.column_form): the same models on the wave-private column-run kernel -------------
+def _l96_plain(t, x, p):
+    """Lorenz-96 written by a user (NOT the registry's callable): must be recognised as a translation-invariant
+    stencil and come out with the built-in's structure (3 neighbour columns, 2 exchanged products)."""
+    return np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - x + p[0]
+
+
+def test_column_form_structure():
+    ex, sy = codegen.trace(_l96_plain, 20, 1)
+    c = codegen.column_form(ex, sy, 20, 1, 0)
+    assert c["uniform"] and c["offsets"] == [-2, -1, 1] and c["NE"] == 2       # as RhsL96s (csrc/va_tile4.h)
+    ex, sy = codegen.trace(nakl, 4, 18, 1, 1)
+    c = codegen.column_form(ex, sy, 4, 18, 1)
+    assert not c["uniform"] and c["offsets"] == [1, 2, 3] and c["NE"] == 3      # dense: every other column
+    ex, sy = codegen.trace(l96_damped, 12, 2)
+    assert "USES_T = true" in codegen.column_form(ex, sy, 12, 2, 0)["text"]
+
+    def coupled9(t, x, p):                       # neither translation-invariant nor small: flat kernel only
+        return np.cumsum(x, 1) * p[0]
+    ex, sy = codegen.trace(coupled9, 9, 1)
+    assert codegen.column_form(ex, sy, 9, 1, 0) is None
+
+
+@pytest.mark.parametrize("disc", ["trapezoid", "SimpsonHermite", "euler", "forwardmap"])
+def test_column_form_nakl_matches_flat_form_and_complex_step(disc):
+    """dense column form (switch on the column) + stimulus + per-component RF + 18 estimated parameters"""
+    D, NP, N, t, stim, Y, X, P, RF0 = _nakl_problem(N=61)
+    m = codegen.module_for(nakl, 4, 18, nstim=1, stim_ndim=1, col_variant=lambda ne: (_capi.DISC[disc], 4, 0),
+                           compile=False)
+    assert m["col"] is not None and "#define VA_USER_COL" in m["text"]
+    Pidx = list(range(18))
+    XP = np.append(X.ravel(), P)
+    rf = 1.5 ** 6
+    fun = lambda z: va_oracle.numpy_action_generic(nakl, z, D, N, Y, [0], 0.02, 1.0, RF0 * rf, NP, Pidx, P,
+                                                   disc, t_model=t, stim=stim)
+    g0 = va_oracle.complex_step_grad(fun, XP)
+    out = {}
+    for ek in (1, 4):
+        desc, keep = _capi.make_desc(1, D, N, Y, [0], 0.02, 1.0, RF0, P[None, :], Pidx, disc=disc, rhs=1000,
+                                     t_model=t, stim=stim, eval_kernel=ek)
+        out[ek] = emul.action_grad(desc, 64, XP[None, :], rf, user_header=m["header"])
+    A0 = fun(XP)[0]
+    for ek in (1, 4):
+        A, me, fe, g = out[ek]
+        assert abs(A[0] - A0) <= 1e-12 * abs(A0)
+        assert np.abs(g[0] - g0).max() <= 1e-10 * np.abs(g0).max()
+    assert np.abs(out[4][3] - out[1][3]).max() <= 1e-12 * np.abs(g0).max()
+
+
+@pytest.mark.parametrize("disc", ["trapezoid", "SimpsonHermite"])
+def test_column_form_traced_l96_equals_builtin(disc):
+    """the traced Lorenz-96 on the column-run phases against the built-in on the same phases"""
+    D, N = 20, 85
+    rng = np.random.RandomState(2)
+    Lidx = [0, 3, 6, 9, 12, 15, 18]
+    Y = rng.randn(N, len(Lidx)); P = np.array([8.17])
+    XP = np.append(3.0 * rng.randn(N * D), P)
+    m = codegen.module_for(_l96_plain, D, 1, col_variant=lambda ne: (_capi.DISC[disc], 6, 1), compile=False)
+    res = {}
+    for rhs in ("lorenz96", 1000):
+        desc, keep = _capi.make_desc(1, D, N, Y, Lidx, 0.025, 4.0, 0.3, P[None, :], [0], disc=disc, rhs=rhs,
+                                     eval_kernel=4)
+        res[rhs] = emul.action_grad(desc, 72, XP[None, :], 8.0, user_header=m["header"])
+    A, me, fe, g = res[1000]
+    Ab, meb, feb, gb = res["lorenz96"]
+    assert abs(A[0] - Ab[0]) <= 1e-13 * abs(Ab[0]) and abs(fe[0] - feb[0]) <= 1e-13 * abs(Ab[0])
+    assert np.abs(g - gb).max() <= 1e-13 * np.abs(gb).max()
+
+
+def test_column_form_time_dependent_stencil():
+    D, NP, N = 12, 2, 45
+    m = codegen.module_for(l96_damped, D, NP, col_variant=lambda ne: (1, 4, 1), compile=False)
+    assert m["col"]["uniform"]
+    rng = np.random.RandomState(4)
+    t = 0.025 * np.arange(N)
+    Y = rng.randn(N, 5); Lidx = [0, 2, 5, 7, 10]
+    P = np.array([8.0, 1.1])
+    XP = np.append(3.0 * rng.randn(N * D), P)
+    fun = lambda z: va_oracle.numpy_action_generic(l96_damped, z, D, N, Y, Lidx, 0.025, 4.0, 0.3, NP, [0, 1], P,
+                                                   "trapezoid", t_model=t)
+    g0 = va_oracle.complex_step_grad(fun, XP)
+    desc, keep = _capi.make_desc(1, D, N, Y, Lidx, 0.025, 4.0, 0.3, P[None, :], [0, 1], rhs=1000, t_model=t,
+                                 eval_kernel=4)
+    A, me, fe, g = emul.action_grad(desc, 80, XP[None, :], 1.0, user_header=m["header"])
+    assert abs(A[0] - fun(XP)[0]) <= 1e-12 * abs(A[0])
+    assert np.abs(g[0] - g0).max() <= 1e-10 * np.abs(g0).max()
+
+
+def test_column_module_exports_its_variant():
+    import ctypes as C
+    m = codegen.module_for(_l96_plain, 20, 1, col_variant=lambda ne: (1, 7, 1) if ne == 2 else None)
+    L = C.CDLL(m["so"])
+    v = (C.c_int * 5)()
+    L.va_user_col_info(v)
+    assert list(v) == [1, 1, 7, 1, 2] and hasattr(L, "va_user_launch_eval4") and hasattr(L, "va_user_prepare_eval4")
+    m0 = codegen.module_for(_l96_plain, 20, 1)                  # no variant asked for: flat kernel only
+    L0 = C.CDLL(m0["so"])
+    L0.va_user_col_info(v)
+    assert list(v)[0] == 0 and not hasattr(L0, "va_user_launch_eval4")
+
+
+def test_eval4_plan_matches_the_geometry_rules():
+    assert _capi.eval4_plan(64, 20, 1000, "trapezoid", 2) == (1, 7, 1)          # C3: 12 tiles x 64 = 3 per CU
+    assert _capi.eval4_plan(512, 20, 1000, "trapezoid", 2) == (1, 6, 1)
+    assert _capi.eval4_plan(1, 4, 2001, "SimpsonHermite", 3, rf_array=True) == (2, 4, 0)
+    assert _capi.eval4_plan(1, 4, 2001, "SimpsonHermite", 3, bounded=True) is None   # bounds: flat kernel
+    assert _capi.eval4_plan(1, 22, 200, "trapezoid", 2) is None                 # D = 22: two runs leave 20 lanes idle
+    assert _capi.eval4_plan(1, 20, 200, "trapezoid", 2, p_time_dependent=True) is None

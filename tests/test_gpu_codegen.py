@@ -168,3 +168,105 @@ def test_bounded_device_minimiser_follows_the_oracle_step_for_step():
             x, A, st, nit, nfev = opb.minimize_lbfgs(XP[b], 50.0, o, bounds=bnds)
             assert (r["nit"][b], r["nfev"][b], r["status"][b]) == (nit, nfev, st), (b, r["nit"][b], nit, r["nfev"][b], nfev)
             assert abs(r["A"][b] - A) <= 1e-6 * abs(A) and np.abs(r["x"][b] - x).max() <= 2e-2   # (flat directions: 60 iterations amplify last-bit differences)
+
+
+# ---- generated models on the wave-private column-run kernel (codegen.column_form, va_eval4_plan) ---------------
+def _l96_user(t, x, p):
+    """Lorenz-96 as a user would write it (not the registry's callable): traced, recognised as a stencil"""
+    return np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - x + p[0]
+
+
+@pytest.mark.parametrize("name", ["g5_nakl_SimpsonHermite_rf1e+00", "g5_nakl_SimpsonHermite_rf5e+01",
+                                  "g5_nakl_trapezoid_rf1e+00", "g5_nakl_trapezoid_rf2e+03"])
+def test_nakl_on_the_column_kernel_matches_reference(gold, name):
+    """the reference's own NaKL numbers again, now with the model's dense column form on k_eval4"""
+    c = gold[name]
+    D, N = int(c["D"]), int(c["N_model"])
+    RF0 = np.resize(c["RF0"], (N - 1, D))
+    XP = c["XP"]
+    P = XP[N * D:]
+    B = 3
+    m = codegen.module_for(nakl, 4, 18, nstim=1, stim_ndim=1,
+                           col_variant=lambda ne: _capi.eval4_plan(B, D, N, str(c["disc"]), ne, rf_array=True))
+    assert m["col_variant"] is not None
+    rng = np.random.RandomState(5)
+    XPb = np.stack([XP, XP + 0.01 * rng.randn(XP.size), XP])
+    pr = _capi.Problem(B, D, N, c["Y"], [0], float(c["dt_model"]), float(c["RM"]), RF0, np.tile(P, (B, 1)),
+                       list(range(18)), disc=str(c["disc"]), rhs=_capi.load_rhs_module(m["so"]), t_model=c["t"],
+                       stim=c["stim"])
+    assert pr.info()["eval_kernel"] == 4 and pr.info()["run_rows"] == m["col_variant"][1]
+    A, me, fe, g = pr.action_grad(XPb, float(c["rf_scale"]))
+    for b in (0, 2):
+        assert abs(A[b] - c["A"]) <= 1e-12 * c["A"]
+        assert abs(me[b] - c["me"]) <= 1e-12 * c["A"] and abs(fe[b] - c["fe"]) <= 1e-12 * c["A"]
+        assert np.abs(g[b] - c["grad"]).max() <= 1e-10 * np.abs(c["grad"]).max()
+    assert np.array_equal(g[0], g[2]) and A[1] != A[0]
+    pr.close()
+
+
+def test_column_module_on_another_geometry_runs_its_flat_kernel(gold):
+    """a module carries ONE instantiation of k_eval4; a problem that calls for another runs the flat kernel"""
+    c = gold["g5_nakl_trapezoid_rf1e+00"]
+    D, N = int(c["D"]), int(c["N_model"])
+    m = codegen.module_for(nakl, 4, 18, nstim=1, stim_ndim=1, col_variant=lambda ne: (2, 4, 0))   # Simpson-Hermite
+    XP = c["XP"]; P = XP[N * D:]
+    pr = _capi.Problem(1, D, N, c["Y"], [0], float(c["dt_model"]), float(c["RM"]), np.resize(c["RF0"], (N - 1, D)),
+                       P[None, :], list(range(18)), disc="trapezoid", rhs=_capi.load_rhs_module(m["so"]),
+                       t_model=c["t"], stim=c["stim"])
+    assert pr.info()["eval_kernel"] == 1
+    A, me, fe, g = pr.action_grad(XP[None, :], float(c["rf_scale"]))
+    assert abs(A[0] - c["A"]) <= 1e-12 * c["A"] and np.abs(g[0] - c["grad"]).max() <= 1e-10 * np.abs(c["grad"]).max()
+    pr.close()
+
+
+def test_traced_l96_runs_at_the_builtin_speed_and_agrees():
+    """a traced Lorenz-96 (not recognised by the registry) at BASELINE config 3's shape:
+    within 1e-13 of the built-in's values and within 10 % of its evaluation time (same kernel, generated RHS)."""
+    from varanneal_amd import twin
+    D, N, B = 20, 1000, 64
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    XP = np.empty((B, N * D + 1))
+    for s in range(B):
+        x, p = twin.initial_guess(N, D, s, Y, Lidx)
+        XP[s, :N * D] = x.ravel(); XP[s, N * D:] = p
+    P = XP[:, N * D:].copy()
+    m = codegen.module_for(_l96_user, D, 1, col_variant=lambda ne: _capi.eval4_plan(B, D, N, "trapezoid", ne))
+    assert m["col"]["uniform"] and m["col_variant"] == (1, 7, 1)
+    out, us = {}, {}
+    for rhs in ("lorenz96", _capi.load_rhs_module(m["so"])):
+        pr = _capi.Problem(B, D, N, Y, Lidx, 0.025, 4.0, 4e-6, P, [0], disc="trapezoid", rhs=rhs)
+        assert pr.info()["eval_kernel"] == 4 and pr.info()["run_rows"] == 7
+        out[rhs] = pr.action_grad(XP, 1.5 ** 20)
+        pr.eval_timed(1.5 ** 20, 200)                                   # warm-up
+        us[rhs] = min(pr.eval_timed(1.5 ** 20, 2000) for _ in range(5)) / 2000 * 1e3
+        pr.close()
+    (Ab, meb, feb, gb), (A, me, fe, g) = out["lorenz96"], out[[k for k in out if k != "lorenz96"][0]]
+    assert np.all(np.abs(A - Ab) <= 1e-13 * np.abs(Ab)) and np.all(np.abs(fe - feb) <= 1e-13 * np.abs(Ab))
+    assert np.array_equal(me, meb)
+    assert np.abs(g - gb).max() <= 1e-13 * np.abs(gb).max()
+    ub, uu = us["lorenz96"], [v for k, v in us.items() if k != "lorenz96"][0]
+    print("C3 evaluation: built-in %.2f us, traced + generated %.2f us" % (ub, uu))
+    assert uu <= 1.10 * ub
+
+
+def test_annealer_puts_a_traced_stencil_on_the_column_kernel():
+    """through the drop-in: set_model(callable) -> trace -> column form -> the module instantiation the
+    problem's geometry calls for; one rung against the built-in's"""
+    from varanneal_amd import twin
+    D, N, B = 20, 300, 8
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    X0 = np.empty((B, N, D)); P0 = np.empty((B, 1))
+    for s in range(B):
+        X0[s], P0[s] = twin.initial_guess(N, D, s, Y, Lidx)
+    res = {}
+    for f in (twin.l96, _l96_user):
+        a = va_ode.Annealer()
+        a.set_model(f, D)
+        a.set_data(Y, t=t)
+        a.anneal(X0.copy(), P0.copy(), 1.5, [0], 4.0, 4e-6, list(Lidx), [0], disc="trapezoid",
+                 opt_args={'gtol': 1e-8, 'ftol': 1e-8, 'maxiter': 25, 'maxfun': 1000}, verbose=False)
+        assert a._pb.info()["eval_kernel"] == 4
+        res[f] = (a.A_array.copy(), a.nit_array.copy())
+        a.close()
+    assert np.array_equal(res[twin.l96][1], res[_l96_user][1])
+    assert np.allclose(res[twin.l96][0], res[_l96_user][0], rtol=1e-9)

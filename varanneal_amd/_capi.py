@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VARANNEAL_AMD_LIB", os.path.join(_HERE, "libvaranneal_amd.so"))   # (env: diagnostic builds)
 
 VA_OK = 0
-ABI_VERSION = 9          # VA_ABI_VERSION of include/varanneal_amd.h
+ABI_VERSION = 10         # VA_ABI_VERSION of include/varanneal_amd.h
 ERRNAMES = {-1: "VA_EINVAL", -2: "VA_ENOMEM", -3: "VA_EHIP", -4: "VA_EUNSUPPORTED", -5: "VA_ESTATE"}
 DISC = {"euler": 0, "trapezoid": 1, "SimpsonHermite": 2, "forwardmap": 3}
 RHS = {"lorenz96": 0}
@@ -183,6 +183,7 @@ def lib():
     L.va_problem_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(h)]
     L.va_nnet_problem_create.argtypes = [C.POINTER(NnetDesc), C.POINTER(h)]
     L.va_rhs_load_module.argtypes = [C.c_char_p, c_ip]
+    L.va_eval4_plan.argtypes = [C.POINTER(ProblemDesc), C.c_int32, C.POINTER(C.c_int32)]
     L.va_problem_destroy.argtypes = [h]
     L.va_problem_destroy.restype = None
     L.va_problem_info.argtypes = [h, c_lp, c_lp, c_ip, c_ip]
@@ -203,7 +204,8 @@ def lib():
     L.va_lbfgs_timed.argtypes = [h, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.va_read_eval_outputs.argtypes = [h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.va_debug_read_partials.argtypes = [h, c_dp, C.c_int64]
-    for fn in ("va_device_count", "va_rhs_load_module", "va_problem_create", "va_nnet_problem_create",
+    L.va_problem_eval_kernel.argtypes = [h, c_ip, c_ip]
+    for fn in ("va_device_count", "va_rhs_load_module", "va_eval4_plan", "va_problem_eval_kernel", "va_problem_create", "va_nnet_problem_create",
                "va_problem_info", "va_action_grad",
                "va_minimize_lbfgs", "va_anneal", "va_get_minpath", "va_eval_timed",
                "va_get_counters", "va_debug_read_partials", "va_read_eval_outputs", "va_lbfgs_timed",
@@ -213,7 +215,7 @@ def lib():
     return L
 
 
-EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_problem_create",
+EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_eval4_plan", "va_problem_eval_kernel", "va_problem_create",
            "va_problem_destroy", "va_problem_info", "va_action_grad", "va_minimize_lbfgs",
            "va_anneal", "va_get_minpath", "va_eval_timed", "va_get_counters", "va_nnet_problem_create", "va_debug_read_partials",
            "va_read_eval_outputs", "va_lbfgs_timed", "va_comm_unique_id", "va_comm_create", "va_comm_destroy",
@@ -223,6 +225,27 @@ EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_mo
 def check(rc):
     if rc != VA_OK:
         raise VaError(rc, lib().va_last_error().decode("utf-8", "replace"))
+
+
+def eval4_plan(batch, D, N_model, disc, ne, rm_array=False, rm_full=False, rf_array=False, merr_nskip=1,
+               tile_rows=0, eval_kernel=0, bounded=False, p_time_dependent=False):
+    """(disc, K, w_scalar) of the column-run kernel instantiation a problem of this shape would run for a
+    model whose column form publishes `ne` products per element, or None (flat kernel).  No GPU call."""
+    d = ProblemDesc()
+    d.struct_size = C.sizeof(ProblemDesc)
+    d.batch, d.D, d.N_model, d.merr_nskip = batch, D, N_model, merr_nskip
+    d.N_data = (N_model - 1) // merr_nskip + 1
+    d.rm_kind = (2 if rm_full else 1) if rm_array else 0
+    d.rf_kind = 1 if rf_array else 0
+    d.disc = DISC[disc] if isinstance(disc, str) else int(disc)
+    d.tile_rows, d.eval_kernel = tile_rows, eval_kernel
+    d.p_time_dependent = 1 if p_time_dependent else 0
+    dummy = (C.c_double * 1)()
+    if bounded:
+        d.lower = C.cast(dummy, c_dp); d.upper = C.cast(dummy, c_dp)
+    out = (C.c_int32 * 4)()
+    check(lib().va_eval4_plan(C.byref(d), int(ne), out))
+    return (out[1], out[2], out[3]) if out[0] else None
 
 
 _modules = {}
@@ -297,7 +320,10 @@ class Problem(object):
         nv, ld = C.c_int64(), C.c_int64()
         T, nt = C.c_int32(), C.c_int32()
         check(self._L.va_problem_info(self._h, C.byref(nv), C.byref(ld), C.byref(T), C.byref(nt)))
-        return dict(n_var=nv.value, ld=ld.value, tile_rows=T.value, ntiles=nt.value)
+        ek, rr = C.c_int32(), C.c_int32()
+        check(self._L.va_problem_eval_kernel(self._h, C.byref(ek), C.byref(rr)))
+        return dict(n_var=nv.value, ld=ld.value, tile_rows=T.value, ntiles=nt.value, eval_kernel=ek.value,
+                    run_rows=rr.value)
 
     def _xp(self, XP):
         XP = _f64(XP)

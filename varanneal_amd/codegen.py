@@ -149,7 +149,7 @@ def _emit_case(pr, expr, ret):
     return " ".join(lines)
 
 
-def generate_header(exprs, syms, D, NP, nstim, name="user"):
+def generate_header(exprs, syms, D, NP, nstim, name="user", col=None):
     sp = _sympy()
     pr = _printer()
     sv = sp.symbols("sv0:%d" % D, real=True)
@@ -198,8 +198,150 @@ def generate_header(exprs, syms, D, NP, nstim, name="user"):
     out.append("        }")
     out.append("    }")
     out.append("};")
+    if col is not None:
+        out.append("// the same model in column form (codegen.column_form): %s"
+                   % ("translation-invariant stencil, offsets %s" % col["offsets"] if col["uniform"] else "dense, switch on the column"))
+        out.append("#define VA_USER_COL 1")
+        out.append(col["text"])
     out.append("}  // namespace va")
     return "\n".join(out) + "\n"
+
+
+def _local_printer(xmap):
+    """C printer that writes state symbols as the column kernel sees them: the lane's own value `x0`
+    and the neighbour values `xn[k]` (xmap: symbol -> C text)."""
+    base = _printer().__class__
+
+    class P(base):
+        def _print_Symbol(self, s):
+            if s in xmap:
+                return xmap[s]
+            return base._print_Symbol(self, s)
+    return P()
+
+
+def column_form(exprs, syms, D, NP, nstim, max_dense=8):
+    """The model in the form the wave-private column-run kernel wants (csrc/va_tile4.h), or None.
+
+    A lane owns ONE state column i of a run of time rows; it reads its own value and NB neighbour
+    columns, evaluates f_i, and -- for the adjoint -- publishes the products s_i * df_i/dx_j of its own
+    element, which the lanes of the columns j gather (J^T s without a second look at x).  Two kinds of
+    model fit: (a) translation-invariant stencils (every f_i is f_0 shifted cyclically, e.g. Lorenz-96),
+    where the neighbours are fixed column offsets and the code has one path; (b) small systems (D <= 8,
+    e.g. the tutorial's NaKL neuron) with any coupling, where every other column is a neighbour and the
+    code switches on the column.  Products that are constant multiples of one another are exchanged once."""
+    sp = _sympy()
+    xs, ps = list(syms["x"]), list(syms["p"])
+    uses_t = any(e.has(syms["t"]) for e in exprs)
+
+    def shifted(e, i):
+        return e.xreplace({xs[j]: xs[(j + i) % D] for j in range(D)})
+    uniform = D >= 3 and all(sp.simplify(shifted(exprs[0], i) - exprs[i]) == 0 for i in range(1, D))
+    if uniform:
+        cols = [j for j in range(1, D) if sp.diff(exprs[0], xs[j]) != 0]
+        offs = sorted(((j + D // 2) % D) - D // 2 for j in cols)          # signed cyclic offsets
+        if len(set(o % D for o in offs)) != len(offs) or len(offs) > 8 or len(offs) == 0:
+            uniform = False
+    if not uniform:
+        if D > max_dense or D < 2:
+            return None
+        offs = list(range(1, D))
+    NB = len(offs)
+    out = []
+    s_sym = sp.Symbol("s", real=True)
+
+    def local_printer(i):
+        xmap = {xs[i]: "x0"}
+        for k, o in enumerate(offs):
+            xmap[xs[(i + o) % D]] = "xn[%d]" % k
+        return _local_printer(xmap)
+
+    rows = [0] if uniform else list(range(D))
+    # products: per neighbour k the derivative df_i/dx_{i+off_k}; in the uniform case proportional ones share a slot
+    derivs = {i: [sp.diff(exprs[i], xs[(i + o) % D]) for o in offs] for i in rows}
+    slot_of, coef_of = list(range(NB)), [sp.Integer(1)] * NB
+    if uniform:
+        reps = []
+        for k in range(NB):
+            dk = derivs[0][k]
+            hit = None
+            for r in reps:
+                if dk == 0 or derivs[0][r] == 0:
+                    continue
+                ratio = sp.simplify(dk / derivs[0][r])
+                if ratio.is_number:
+                    hit = (r, ratio)
+                    break
+            if hit is None:
+                reps.append(k)
+                slot_of[k], coef_of[k] = len(reps) - 1, sp.Integer(1)
+            else:
+                slot_of[k], coef_of[k] = reps.index(hit[0]), hit[1]
+        NE = len(reps)
+        e_src = reps
+    else:
+        NE, e_src = NB, list(range(NB))
+    out.append("struct RhsUserCol {")
+    out.append("    static constexpr int NP = %d, D = %d, NSTIM = %d, NB = %d, NE = %d, NG = %d;" % (NP, D, nstim, NB, NE, NB))
+    out.append("    static constexpr bool USES_T = %s, UNIFORM = %s;" % ("true" if uses_t else "false", "true" if uniform else "false"))
+    chain = lambda vals: " : ".join(["k == %d ? %s" % (k, v) for k, v in enumerate(vals[:-1])] + [str(vals[-1])]) if len(vals) > 1 else str(vals[0])
+    out.append("    static VA_HD constexpr int nb_off(int k) { return %s; }" % chain(offs))
+    out.append("    static VA_HD constexpr int g_e(int k) { return %s; }" % chain(slot_of))
+    out.append("    static VA_HD constexpr int g_off(int k) { return %s; }" % chain([-o for o in offs]))
+    sig = "int col, double x0, const double *xn, const double *p, double t, const double *st"
+    unused = "(void)col; (void)x0; (void)xn; (void)p; (void)t; (void)st;"
+
+    def emit_switch(body_for_row, default):
+        if uniform:
+            return ["        " + body_for_row(0)]
+        lines = ["        switch (col) {"]
+        for i in rows:
+            lines.append("        case %d: { %s break; }" % (i, body_for_row(i)))
+        lines.append("        default: { %s break; }" % default)
+        lines.append("        }")
+        return lines
+    # f
+    out.append("    static VA_HD double f(%s)" % sig)
+    out.append("    {")
+    out.append("        %s double r = 0.0;" % unused)
+    out += emit_switch(lambda i: _emit_case(local_printer(i), exprs[i], "r = %s;"), "r = 0.0;")
+    out.append("        return r;")
+    out.append("    }")
+    # scatter
+    out.append("    static VA_HD void scatter(int col, double s, double x0, const double *xn, const double *p, double t, const double *st, double *e, double &diag)")
+    out.append("    {")
+    out.append("        %s (void)s;" % unused)
+
+    def scat(i):
+        pr = local_printer(i)
+        parts = []
+        for slot, k in enumerate(e_src):
+            parts.append("{ %s }" % _emit_case(pr, s_sym * derivs[i][k], "e[%d] = %%s;" % slot))
+        parts.append("{ %s }" % _emit_case(pr, s_sym * sp.diff(exprs[i], xs[i]), "diag = %s;"))
+        return " ".join(parts)
+    out += emit_switch(scat, " ".join("e[%d] = 0.0;" % k for k in range(NE)) + " diag = 0.0;")
+    out.append("    }")
+    # gather
+    terms = " + ".join("%s * r[%d]" % (_printer().doprint(sp.Float(coef_of[k]) if coef_of[k].is_Float else coef_of[k]), k) for k in range(NB))
+    terms = terms.replace("1 * ", "").replace("-1 * ", "-")
+    out.append("    static VA_HD double gather(const double *r) { return %s; }" % terms)
+    # pgrad
+    out.append("    static VA_HD void pgrad(int col, double s, double x0, const double *xn, const double *p, double t, const double *st, double *acc)")
+    out.append("    {")
+    out.append("        %s (void)s; (void)acc;" % unused)
+
+    def pg(i):
+        pr = local_printer(i)
+        parts = []
+        for k in range(NP):
+            dk = sp.diff(exprs[i], ps[k])
+            if dk != 0:
+                parts.append("{ %s }" % _emit_case(pr, s_sym * dk, "acc[%d] += %%s;" % k))
+        return " ".join(parts)
+    out += emit_switch(pg, "")
+    out.append("    }")
+    out.append("};")
+    return dict(text="\n".join(out), uniform=uniform, offsets=offs, NE=NE, NB=NB)
 
 
 def check_against(f, exprs, syms, D, NP, nstim, stim_ndim=1, trials=3, rtol=1e-10, p_rows=False):
@@ -228,17 +370,22 @@ def check_against(f, exprs, syms, D, NP, nstim, stim_ndim=1, trials=3, rtol=1e-1
 
 def _core_fingerprint():
     h = hashlib.sha1()
-    for fn in ("va_core.h", "va_device.h", "va_eval_flat.h", "va_epilogue.h", "va_tile2.h", "va_tile3.h", "va_tile4.h",
-               "va_user_rhs.hip"):
+    for fn in ("va_core.h", "va_device.h", "va_eval_flat.h", "va_eval4.h", "va_epilogue.h", "va_tile2.h", "va_tile3.h",
+               "va_tile4.h", "va_user_rhs.hip"):
         with open(os.path.join(CSRC, fn), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
 
 
-def build_module(header_text, verbose=False):
-    """Write the header, compile the module for gfx950 (cached by content).  Returns (so, header)."""
+def build_module(header_text, verbose=False, col_variant=None, compile=True):
+    """Write the header, compile the module for gfx950 (cached by content).  Returns (so, header).
+    col_variant = (disc, K, w_scalar): the ONE instantiation of the column-run kernel to compile in
+    (models with a column form; csrc/va_user_rhs.hip)."""
     os.makedirs(CACHE, exist_ok=True)
-    key = hashlib.sha1((header_text + _core_fingerprint()).encode()).hexdigest()[:16]
+    defs = []
+    if col_variant is not None:
+        defs = ["-DVA_USER_DISC=%d" % col_variant[0], "-DVA_USER_K=%d" % col_variant[1], "-DVA_USER_WS=%d" % col_variant[2]]
+    key = hashlib.sha1((header_text + _core_fingerprint() + " ".join(defs)).encode()).hexdigest()[:16]
     hdr = os.path.join(CACHE, "rhs_%s.h" % key)
     so = os.path.join(CACHE, "libva_rhs_%s.so" % key)
     # Several ranks may build the same module at once (one process per GPU, each calling
@@ -249,9 +396,11 @@ def build_module(header_text, verbose=False):
         with open(hdr + tag, "w") as fh:
             fh.write(header_text)
         os.replace(hdr + tag, hdr)
+    if not compile:
+        return None, hdr                                   # (header only: the CPU emulator of the tests compiles it itself)
     if not os.path.exists(so):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-Wno-unused-function", "-I", CSRC, '-DVA_USER_RHS_HEADER="%s"' % hdr,
+               "-Wno-unused-function", "-I", CSRC, '-DVA_USER_RHS_HEADER="%s"' % hdr] + defs + [
                "-o", so + tag, os.path.join(CSRC, "va_user_rhs.hip")]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -264,12 +413,21 @@ def build_module(header_text, verbose=False):
     return so, hdr
 
 
-def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False, p_rows=False):
-    """trace + check + generate + build.  Returns dict(so=, header=, exprs=)."""
+def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False, p_rows=False, col_variant=None, compile=True):
+    """trace + check + generate + build.  Returns dict(so=, header=, exprs=, col=).
+    col_variant: None, or a callable NE -> (disc, K, w_scalar) or None naming the instantiation of the
+    column-run kernel to compile for a model that has a column form."""
     if NP > MAX_NP:
         raise NotImplementedError("right-hand sides with more than %d parameters" % MAX_NP)
     exprs, syms = trace(f, D, NP, nstim, stim_ndim, p_rows)
     check_against(f, exprs, syms, D, NP, nstim, stim_ndim, p_rows=p_rows)
-    text = generate_header(exprs, syms, D, NP, nstim, getattr(f, "__name__", "f"))
-    so, hdr = build_module(text, verbose)
-    return dict(so=so, header=hdr, exprs=exprs, text=text)
+    col = None
+    variant = None
+    if col_variant is not None and not p_rows:
+        col = column_form(exprs, syms, D, NP, nstim)
+        variant = col_variant(col["NE"]) if col is not None else None
+        if variant is None:
+            col = None
+    text = generate_header(exprs, syms, D, NP, nstim, getattr(f, "__name__", "f"), col=col)
+    so, hdr = build_module(text, verbose, variant, compile)
+    return dict(so=so, header=hdr, exprs=exprs, text=text, col=col, col_variant=variant)

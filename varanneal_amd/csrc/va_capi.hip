@@ -48,6 +48,10 @@ int fail(int code, const char *fmt, ...)
 
 // generated right-hand-side modules (va_rhs_load_module); ids are VA_RHS_USER_BASE + index
 struct UserRhs {
+    // the model's column form on k_eval4, when the module carries one: (has, DISC, K, W_SCALAR, NE)
+    int col[5] = {0, 0, 0, 0, 0};
+    void (*launch4)(const Dev *, void *) = nullptr;
+    int (*prepare4)(const Dev *) = nullptr;
     std::string path;
     void *dl = nullptr;
     void (*launch)(const Dev *, void *) = nullptr;
@@ -112,8 +116,11 @@ void run_eval(va_handle h, int epi)
 }
 
 // Tile geometry of the eval kernel: which mapping, rows per workgroup, threads.
-void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, bool user_rhs)
+// ne: products per element of the model's column form (RhsL96s::NE for the built-in; a generated
+// module's RhsUserCol::NE), or 0 when the model only exists in the flat kernel's form.
+void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne)
 {
+    bool user_rhs = ne <= 0;
     user_rhs = user_rhs || d->p_time_dependent || d->rm_kind == 2;   // per-row parameters / full RM: flat kernel only
     user_rhs = user_rhs || (d->lower && d->upper);                   // box bounds: the flat kernel carries the clamp / projected gradient
     const int D = d->D, N = d->N_model;
@@ -124,7 +131,7 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, bool user_
     // to 1024 columns, flat mapping beyond
     if (dm.emode == 2) dm.emode = 3;                      // (the row-strided kernel of round 1 is gone)
     if (dm.emode < 1 || dm.emode > 4) dm.emode = tile4_ok(D) ? 4 : ((D <= 1024) ? 3 : 1);
-    if (user_rhs) dm.emode = 1;                           // generated modules instantiate the flat kernel
+    if (user_rhs) dm.emode = 1;                           // no column form (or a case only the flat kernel carries)
     if (dm.emode == 4 && !tile4_ok(D)) dm.emode = 3;
     if (dm.emode == 3 && D > 1024) dm.emode = 1;          // column runs: a lane per column
     int tmin, tmax;
@@ -157,7 +164,7 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, bool user_
             const long wtiles = (long)d->batch * ((N + RW * K - 1) / (RW * K));
             if (wtiles > 1024 && wtiles <= 3 * 1024) SUB = (int)((wtiles + 1023) / 1024);
         }
-        g4 = sh ? tile4_geo<3>(D, K, RhsL96s::NE, SUB) : tile4_geo<2>(D, K, RhsL96s::NE, SUB);
+        g4 = sh ? tile4_geo<3>(D, K, ne, SUB) : tile4_geo<2>(D, K, ne, SUB);
         if ((g4.XP + 63) / 64 <= T4_NI_MAX && tile4_magic_ok(g4)) {
             dm.RY = 4 * RW; dm.NT = 256; dm.maxr = K; dm.T = g4.T;
             dm.ntiles = (N + dm.T - 1) / dm.T;
@@ -421,6 +428,21 @@ int va_device_count(int32_t *count)
     return VA_OK;
 }
 
+int va_eval4_plan(const va_problem_desc *d, int32_t ne, int32_t *out)
+{
+    if (!d || !out) return fail(VA_EINVAL, "null argument");
+    if (d->struct_size != (int32_t)sizeof(va_problem_desc)) return fail(VA_EINVAL, "struct_size %d != %zu", d->struct_size, sizeof(va_problem_desc));
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (ne <= 0 || d->D < 1 || d->N_model < 2 || d->batch < 1) return VA_OK;
+    Dims dm{};
+    Geo4 g4{};
+    pick_eval_geometry(d, dm, g4, ne);
+    if (dm.emode != 4) return VA_OK;
+    out[0] = 1; out[1] = d->disc; out[2] = dm.maxr;
+    out[3] = (d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1) ? 1 : 0;
+    return VA_OK;
+}
+
 int va_rhs_load_module(const char *path, int32_t *rhs_id)
 {
     if (!path || !rhs_id) return fail(VA_EINVAL, "null argument");
@@ -444,6 +466,12 @@ int va_rhs_load_module(const char *path, int32_t *rhs_id)
     }
     if (v[0] < 0 || v[0] > RHS_MAX_NP) { dlclose(u.dl); return fail(VA_EUNSUPPORTED, "%s: NP=%d > %d", path, v[0], RHS_MAX_NP); }
     u.NP = v[0]; u.D = v[1]; u.NSTIM = v[2];
+    if (info_fn cinfo = (info_fn)dlsym(u.dl, "va_user_col_info")) {
+        cinfo(u.col);
+        u.launch4 = (void (*)(const Dev *, void *))dlsym(u.dl, "va_user_launch_eval4");
+        u.prepare4 = (int (*)(const Dev *))dlsym(u.dl, "va_user_prepare_eval4");
+        if (!u.launch4 || !u.prepare4) u.col[0] = 0;
+    }
     g_user_rhs.push_back(u);
     *rhs_id = VA_RHS_USER_BASE + (int32_t)g_user_rhs.size() - 1;
     return VA_OK;
@@ -526,7 +554,17 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dm.bounded = (d->lower && d->upper) ? 1 : 0;
     if (tdp) { dm.ND = dm.N * (dm.D + dm.NPe); dm.NP = 0; dm.NPest = 0; }   // one flat run for the L-BFGS kernels
     dm.ld = ((dm.ND + dm.NPest + 15) / 16) * 16;
-    pick_eval_geometry(d, dm, dv.g4, user != nullptr);
+    pick_eval_geometry(d, dm, dv.g4, user ? (user->col[0] ? user->col[4] : 0) : RhsL96s::NE);
+    if (user && dm.emode == 4) {
+        // the module holds ONE instantiation of the column-run kernel (va_eval4_plan named it when the
+        // module was generated); any other geometry runs the module's flat kernel
+        const bool ws = d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1;
+        if (user->col[1] == d->disc && user->col[2] == dm.maxr && (user->col[3] != 0) == ws) {
+            h->user_launch = user->launch4; h->user_prepare = user->prepare4;
+        } else {
+            pick_eval_geometry(d, dm, dv.g4, 0);
+        }
+    }
     if (dm.emode == 4 && (unsigned long long)dm.B * dm.ntiles * dm.ntiles >= (1ull << 32)) {
         va_problem_destroy(h);        // (umulhi by ntiles_magic would no longer be an exact division)
         return fail(VA_EUNSUPPORTED, "batch x tiles too large for the wave-private kernel: pass eval_kernel=3");
@@ -810,6 +848,14 @@ int va_problem_info(va_handle h, int64_t *n_var, int64_t *ld_internal, int32_t *
     if (ld_internal) *ld_internal = h->dv.dm.ld;
     if (tile_rows) *tile_rows = h->dv.dm.T;
     if (ntiles) *ntiles = h->dv.dm.ntiles;
+    return VA_OK;
+}
+
+int va_problem_eval_kernel(va_handle h, int32_t *eval_kernel, int32_t *run_rows)
+{
+    if (!h) return fail(VA_EINVAL, "null handle");
+    if (eval_kernel) *eval_kernel = h->is_nnet ? 0 : h->dv.dm.emode;
+    if (run_rows) *run_rows = h->is_nnet ? 0 : h->dv.dm.maxr;
     return VA_OK;
 }
 

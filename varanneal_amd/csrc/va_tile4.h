@@ -35,12 +35,15 @@ struct RhsL96s {
     static constexpr int NG = 3;                       // products gathered per element
     static VA_HD constexpr int g_e(int t) { return t == 0 ? 0 : 1; }                   // which product
     static VA_HD constexpr int g_off(int t) { return t == 0 ? 1 : (t == 1 ? -1 : 2); } // sender column - own column
-    static VA_HD double f(double x0, const double *xn, const double *p, double, const double *)
+    static constexpr bool USES_T = false;              // autonomous: no model time, no stimulus
+    static constexpr int NSTIM = 0;
+    // (int col: the lane's state column -- unused by a translation-invariant right-hand side)
+    static VA_HD double f(int, double x0, const double *xn, const double *p, double, const double *)
     {
         return xn[1] * (xn[2] - xn[0]) - x0 + p[0];
     }
     // e[0] = s df_i/dx_{i-1},  e[1] = s df_i/dx_{i+1} = -s df_i/dx_{i-2};  diag = s df_i/dx_i
-    static VA_HD void scatter(double s, double, const double *xn, const double *, double, const double *, double *e, double &diag)
+    static VA_HD void scatter(int, double s, double, const double *xn, const double *, double, const double *, double *e, double &diag)
     {
         e[0] = s * (xn[2] - xn[0]);
         e[1] = s * xn[1];
@@ -48,7 +51,7 @@ struct RhsL96s {
     }
     // sum_{i != j} s_i df_i/dx_j for the own column j from the received products r[0..NG)
     static VA_HD double gather(const double *r) { return r[0] + (r[1] - r[2]); }
-    static VA_HD void pgrad(double s, double, const double *, const double *, double, const double *, double *acc) { acc[0] += s; }
+    static VA_HD void pgrad(int, double s, double, const double *, const double *, double, const double *, double *acc) { acc[0] += s; }
 };
 
 // ------------------------------------------------------------------ geometry
@@ -186,6 +189,7 @@ VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, cons
     for (int k = 0; k < NB; ++k) xnp[k] = VA_LDS_CVP(t.xs + t.a * PITCH + wrap_col(t.tx + RHS::nb_off(k), D));
     double xo[NR], fo[NR], q[NQ];
     double xnb[K][NB];                                   // neighbour values of the own rows (for the products)
+    double tm[NR];                                       // model time of the rows (non-autonomous right-hand sides only)
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int off = j < K ? j * D : PITCH + (j - K) * D;
@@ -193,17 +197,20 @@ VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, cons
         xo[j] = x0p[off];
 #pragma unroll
         for (int k = 0; k < NB; ++k) xn[k] = xnp[k][off];
+        const int row = t.r0 - HL + j;
+        const int rowc = row < 0 ? 0 : (row > N - 1 ? N - 1 : row);       // (clamped: only ever dereferenced, never used, outside [0, N))
+        tm[j] = (RHS::USES_T && pp.tmodel) ? pp.tmodel[rowc] : 0.0;
+        const double *st = RHS::NSTIM > 0 ? pp.stim + (size_t)rowc * pp.nstim : nullptr;
         if (EDGE) {
             // staged rows that do not exist hold whatever lies next to the path in memory: zero them
             // (selects), so that everything computed from them below is an exact zero
-            const int row = t.r0 - HL + j;
             const bool ok = row >= 0 && row < N;
             xo[j] = ok ? xo[j] : 0.0;
 #pragma unroll
             for (int k = 0; k < NB; ++k) xn[k] = ok ? xn[k] : 0.0;
-            fo[j] = RHS::f(xo[j], xn, t.p, 0.0, nullptr);
+            fo[j] = RHS::f(t.tx, xo[j], xn, t.p, tm[j], st);
             fo[j] = ok ? fo[j] : 0.0;
-        } else fo[j] = RHS::f(xo[j], xn, t.p, 0.0, nullptr);
+        } else fo[j] = RHS::f(t.tx, xo[j], xn, t.p, tm[j], st);
         if (j >= HL && j < HL + K) {
 #pragma unroll
             for (int k = 0; k < NB; ++k) xnb[j - HL][k] = xn[k];
@@ -275,8 +282,23 @@ VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, cons
         }
         // (rows >= N: every q that enters is an exact zero already, see above)
         double e[NE], diag;
-        RHS::scatter(s, xo[j], xnb[k], t.p, 0.0, nullptr, e, diag);
-        RHS::pgrad(s, xo[j], xnb[k], t.p, 0.0, nullptr, acc.v + EP_GP);
+        const int rowk = t.r0 + k < N ? t.r0 + k : N - 1;
+        const double *stk = RHS::NSTIM > 0 ? pp.stim + (size_t)rowk * pp.nstim : nullptr;
+        RHS::scatter(t.tx, s, xo[j], xnb[k], t.p, tm[j], stk, e, diag);
+        if (EDGE) {
+            // a row that does not exist was evaluated at x = 0, where a right-hand side may be singular
+            // (1/x, log x): its s = 0 does not make 0 * inf an exact zero, selects do
+            const bool okk = t.r0 + k < N;
+            double pa[RHS::NP > 0 ? RHS::NP : 1];
+#pragma unroll
+            for (int u = 0; u < RHS::NP; ++u) pa[u] = 0.0;
+            RHS::pgrad(t.tx, s, xo[j], xnb[k], t.p, tm[j], stk, pa);
+#pragma unroll
+            for (int u = 0; u < RHS::NP; ++u) acc.v[EP_GP + u] += okk ? pa[u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < NE; ++u) e[u] = okk ? e[u] : 0.0;
+            diag = okk ? diag : 0.0;
+        } else RHS::pgrad(t.tx, s, xo[j], xnb[k], t.p, tm[j], stk, acc.v + EP_GP);
         rg.direct[k] = direct + diag; rg.xown[k] = xo[j];
 #pragma unroll
         for (int u = 0; u < NE; ++u) ep[u * g.EW1 + k * D] = e[u];

@@ -251,13 +251,8 @@ class Annealer(HIPmin):
                 raise ValueError("RHS %r takes %d parameter(s), P0 has %d" % (self._rhs_name, NPr, self.NP))
             rhs_id = self._rhs_name
         else:
-            # any other callable: trace it, differentiate it, emit HIP, compile a module
-            from . import codegen
-            nstim = 0 if stim is None else (1 if stim.ndim == 1 else stim.shape[1])
-            mod = codegen.module_for(self.f, self.D, self.NP, nstim, 1 if stim is None else stim.ndim,
-                                     p_rows=self._tdp)
-            rhs_id = _capi.load_rhs_module(mod["so"])
-            self._rhs_module = mod
+            rhs_id = None                             # any other callable: a generated module, built below
+                                                      # once the weights and bounds (its kernel variant) are known
 
         # RM / RF0 broadcasting (va_ode.py:612-640)
         if isinstance(RM, list):
@@ -337,6 +332,23 @@ class Annealer(HIPmin):
         self._nfev = np.zeros((self.B, self.Nbeta), dtype=np.int64)
         self._Pfull = np.array(Pf, dtype=np.float64)
         self.adolcID = adolcID                        # accepted, unused: there is no tape
+
+        if rhs_id is None:
+            # trace the callable, differentiate it, emit HIP, compile a module.  A model with a column form
+            # (codegen.column_form) also gets the ONE instantiation of the wave-private column-run kernel
+            # this problem's geometry calls for (va_eval4_plan), the same kernel the built-in Lorenz-96 runs on
+            from . import codegen
+            nstim = 0 if stim is None else (1 if stim.ndim == 1 else stim.shape[1])
+
+            def variant(ne):
+                return _capi.eval4_plan(self.B, self.D, self.N_model, disc, ne,
+                                        rm_array=isinstance(self.RM, np.ndarray), rm_full=np.ndim(self.RM) == 3,
+                                        rf_array=isinstance(self.RF0, np.ndarray), merr_nskip=self.merr_nskip,
+                                        bounded=self._device_bounds, p_time_dependent=self._tdp)
+            mod = codegen.module_for(self.f, self.D, self.NP, nstim, 1 if stim is None else stim.ndim,
+                                     p_rows=self._tdp, col_variant=variant)
+            rhs_id = _capi.load_rhs_module(mod["so"])
+            self._rhs_module = mod
 
         # device image
         if self._pb is not None:
