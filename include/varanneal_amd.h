@@ -68,7 +68,8 @@ typedef struct va_problem_desc {
                                * 2: rm_array [N_data*L*L], full precision matrices (va_ode.py:149-152) */
     double rm;
     const double *rm_array;
-    int32_t rf_kind;          /* 0: scalar rf0; 1: rf0_array [(N_model-1)*D] (va_ode.py:203-209) */
+    int32_t rf_kind;          /* 0: scalar rf0; 1: rf0_array [(N_model-1)*D] (va_ode.py:203-209);
+                               * 2: rf0_array [(N_model-1)*D*D] full matrices, diff_n.(RF_n.diff_n) (va_ode.py:211-217) */
     double rf0;
     const double *rf0_array;
     int32_t NP;               /* parameters of the RHS                               */

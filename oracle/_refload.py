@@ -14,7 +14,7 @@ type-polymorphic, so we
 
   1. register an inert module named ``adolc`` (only the names the reference
      touches at import time / in isinstance checks, ``va_ode.py:752,763``);
-  2. read the two source files as text, apply three mechanical py2->py3
+  2. read the two source files as text, apply four mechanical py2->py3
      substitutions, and ``exec`` them into fresh module objects.
 
 The reference's ``A``/``me_gaussian``/``fe_gaussian``/``disc_*``/
@@ -34,6 +34,8 @@ def _py3(src):
     src = re.sub(r"exec ('self\.[A-Za-z]+ = self\.[a-z_%]+'%\([a-z,]+\))", r"exec(\1)", src)
     src = src.replace("xrange", "range")
     src = src.replace(".im_func.", ".__func__.")
+    # py2 integer division in the one loop bound that relies on it (va_ode.py:215, full RF matrices)
+    src = src.replace("range((self.N_model - 1) / 2)", "range((self.N_model - 1) // 2)")
     return src
 
 

@@ -312,9 +312,50 @@ def rmfull_cases(va):
     return out
 
 
+def rffull_cases(va):
+    """g10_*: full model-error precision matrices, RF0 of shape (D, D) (resized over time,
+    va_ode.py:631-632) and (N_model-1, D, D), contracted as diff . (RF . diff) per time step
+    (va_ode.py:211-217).  Only the Simpson-Hermite branch of the reference can run: the other
+    discretisations' branch (va_ode.py:218-222) contracts RF[i] with the WHOLE diff array and
+    raises / returns an array.  Not symmetric on purpose."""
+    out = {}
+    D, Lidx = 10, [0, 3, 5, 8]
+
+    def l96(t, x, k):
+        return np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - x + k
+    for N, timedep, beta in ((31, False, 0), (45, True, 7)):
+        t, Y, _, _ = twin.make_twin(D, N, Lidx=Lidx)
+        rng = np.random.RandomState(9000 + N)
+        base = 0.4 * np.eye(D) + 0.05 * rng.randn(D, D)
+        RF0 = np.array([base + 0.03 * rng.randn(D, D) for _ in range(N - 1)]) if timedep else base
+        X0 = 20.0 * rng.rand(N, D) - 10.0
+        P0 = np.array([6.0 + 4.0 * rng.rand()])
+        a = va.Annealer()
+        a.set_model(l96, D)
+        a.set_data(Y, t=t)
+        with quiet():
+            a.anneal_init(X0, P0, 1.5, np.array([beta]), 2.5, RF0, Lidx, [0], dt_model=None, init_to_data=False,
+                          disc="SimpsonHermite", method='L-BFGS-B', opt_args=None, adolcID=0)
+        XP = np.array(a.minpaths[0])
+        A = float(a.A(XP)); me = float(a.me_gaussian(XP[:N * D])); fe = float(a.fe_gaussian(XP))
+        grad = _refload.complex_step_grad(a.A, XP)
+        name = "g10_rffull_SimpsonHermite_%s" % ("time" if timedep else "const")
+        out[name] = dict(XP=XP, Y=Y, t=t, D=D, N_model=N, Lidx=np.array(Lidx), dt_model=twin.DT, disc="SimpsonHermite",
+                         RM=2.5, RF0=RF0, alpha=1.5, beta=beta, A=A, me=me, fe=fe, grad=grad)
+        print("%-34s A=%.16e me=%.3e fe=%.3e |g|max=%.3e" % (name, A, me, fe, np.abs(grad).max()))
+    return out
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     va = _refload.load_reference("va_ode")
+    if "--only-rffull" in sys.argv:
+        flat = {}
+        for cname, rec in rffull_cases(va).items():
+            for k, v in rec.items():
+                flat["%s/%s" % (cname, k)] = v
+        np.savez_compressed(os.path.join(GOLD, "rffull.npz"), **flat)
+        return
     shutil.copyfile(SHIPPED, os.path.join(GOLD, os.path.basename(SHIPPED)))   # data file (MIT)
     cases = single_eval_cases(va)
     flat = {}
@@ -353,6 +394,12 @@ def main():
         for k, v in rec.items():
             flat["%s/%s" % (cname, k)] = v
     np.savez_compressed(os.path.join(GOLD, "rmfull.npz"), **flat)
+
+    flat = {}
+    for cname, rec in rffull_cases(va).items():
+        for k, v in rec.items():
+            flat["%s/%s" % (cname, k)] = v
+    np.savez_compressed(os.path.join(GOLD, "rffull.npz"), **flat)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 

@@ -267,7 +267,7 @@ def numpy_action_generic(f, XP, D, N, Y, Lidx, dt, RM, RF, NP, Pidx, P, disc, t_
                          nskip=1):
     """The reference's action (va_ode.py:130-234, 341-454) for an arbitrary user `f`, array op
     for array op, including the stimulus tuple convention (:345-375).  Type-polymorphic, so a
-    complex XP gives complex-step derivatives.  RM: scalar or (N_data,L); RF: scalar or (N-1,D).
+    complex XP gives complex-step derivatives.  RM: scalar, (N_data,L) or (N_data,L,L); RF: scalar, (N-1,D) or (N-1,D,D).
     P of shape (N, NP) = time-dependent parameters (trapezoid / SimpsonHermite as upstream)."""
     x = np.reshape(XP[:N * D], (N, D))
     p = np.array(P, dtype=XP.dtype)
@@ -285,6 +285,8 @@ def numpy_action_generic(f, XP, D, N, Y, Lidx, dt, RM, RF, NP, Pidx, P, disc, t_
     pp = (lambda sl: p[sl]) if tdp else (lambda sl: p)            # f sees the rows' own parameters
     arg = pp if stim is None else (lambda sl: (pp(sl), stim[sl]))
     arr = isinstance(RF, np.ndarray)
+    full = arr and RF.ndim == 3              # (N-1, D, D) matrices: diff_n . (RF_n . diff_n), va_ode.py:211-217
+    quad = lambda R, d: sum(np.dot(d[i], np.dot(R[i], d[i])) for i in range(d.shape[0]))
     if disc == "SimpsonHermite":
         a, m_, b = slice(None, -2, 2), slice(1, -1, 2), slice(2, None, 2)
         fn, fmid, fnp1 = f(t[a], x[a], arg(a)), f(t[m_], x[m_], arg(m_)), f(t[b], x[b], arg(b))
@@ -292,7 +294,10 @@ def numpy_action_generic(f, XP, D, N, Y, Lidx, dt, RM, RF, NP, Pidx, P, disc, t_
         v2 = (x[a] + x[b]) / 2.0 + (fn - fnp1) * (2.0 * dt) / 8.0
         d1 = x[2::2] - x[:-2:2] - v1
         d2 = x[1::2] - v2
-        fe = (np.sum(RF[::2] * d1 * d1) + np.sum(RF[1::2] * d2 * d2)) if arr else RF * np.sum(d1 * d1 + d2 * d2)
+        if full:
+            fe = quad(RF[::2], d1) + quad(RF[1::2], d2)
+        else:
+            fe = (np.sum(RF[::2] * d1 * d1) + np.sum(RF[1::2] * d2 * d2)) if arr else RF * np.sum(d1 * d1 + d2 * d2)
     else:
         a, b = slice(None, -1), slice(1, None)
         if disc == "trapezoid":
@@ -301,7 +306,9 @@ def numpy_action_generic(f, XP, D, N, Y, Lidx, dt, RM, RF, NP, Pidx, P, disc, t_
             d = x[1:] - x[:-1] - dt * f(t[a], x[a], arg(a))
         else:
             d = x[1:] - f(t[a], x[a], arg(a))
-        fe = np.sum(RF * d * d) if arr else RF * np.sum(d * d)
+        # (full matrices: upstream's branch for these discretisations, va_ode.py:218-222, contracts RF[i] with
+        # the whole diff array -- a slip; the contraction meant, and the one Simpson-Hermite uses, is per row)
+        fe = quad(RF, d) if full else (np.sum(RF * d * d) if arr else RF * np.sum(d * d))
     fe = fe / (D * (N - 1))
     return me + fe, me, fe
 

@@ -78,13 +78,14 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     E.Y.assign(d->Y, d->Y + (size_t)m.N_data * m.L);
     if (d->rm_kind) E.rm.assign(d->rm_array, d->rm_array + (size_t)m.N_data * m.L * (d->rm_kind == 2 ? m.L : 1));
     E.lidx.assign(d->Lidx, d->Lidx + m.L);
-    if (d->rf_kind) E.rf0.assign(d->rf0_array, d->rf0_array + (size_t)(m.N - 1) * m.D);
+    if (d->rf_kind) E.rf0.assign(d->rf0_array, d->rf0_array + (size_t)(m.N - 1) * m.D * (d->rf_kind == 2 ? m.D : 1));
     E.pidx.assign(d->Pidx, d->Pidx + m.NPe);
     E.P.assign(d->P, d->P + (size_t)m.B * (m.tdp ? (size_t)m.N * m.NPt : (size_t)m.NPt));
     E.pp.lmap = E.lmap.data(); E.pp.Y = E.Y.data();
     E.pp.rm_arr = d->rm_kind == 1 ? E.rm.data() : nullptr;
     E.pp.rm_full = d->rm_kind == 2 ? E.rm.data() : nullptr; E.pp.Lidx = E.lidx.data();
-    E.pp.rf0_arr = d->rf_kind ? E.rf0.data() : nullptr;
+    E.pp.rf0_arr = d->rf_kind == 1 ? E.rf0.data() : nullptr;
+    E.pp.rf0_full = d->rf_kind == 2 ? E.rf0.data() : nullptr;
     E.pp.Pidx = E.pidx.data(); E.pp.Pfull = E.P.data();
     E.pp.lo = E.pp.hi = nullptr; m.bounded = 0;
     if (d->t_model) E.tm.assign(d->t_model, d->t_model + m.N);
@@ -96,7 +97,7 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     // a generated model with a column form runs the wave-private kernel's phases when asked for by name
     if (d->eval_kernel == 4 && m.emode == 4) user_flat = false;
 #endif
-    if (user_flat || m.tdp || d->rm_kind == 2) m.emode = 1;
+    if (user_flat || m.tdp || d->rm_kind == 2 || d->rf_kind == 2) m.emode = 1;
     E.rhs = d->rhs;
     if (m.disc == DISC_SH && (m.N % 2) == 0) return VA_EINVAL;
     return VA_OK;
@@ -127,6 +128,10 @@ void eval_seed(const Emul &E, int b, const double *x, const double *d, int use_d
         if (dm.tdp) for (int t = 0; t < NT; ++t) tile_load_p<DISC>(dm, E.pp, b, c, t, NT);
         for (int t = 0; t < NT; ++t) tile_f<RHS, DISC>(dm, c, t, NT);
         for (int t = 0; t < NT; ++t) tile_q<DISC>(dm, E.pp, c, acc[t], t, NT);
+        if (E.pp.rf0_full) {
+            for (int t = 0; t < NT; ++t) tile_qfull<DISC>(dm, E.pp, c, acc[t], t, NT);
+            std::swap(c.qs, c.fs);
+        }
         for (int t = 0; t < NT; ++t) tile_s<DISC>(dm, c, t, NT);
         for (int t = 0; t < NT; ++t) tile_g<RHS, DISC>(dm, E.pp, c, acc[t], t, NT);
         if (dm.tdp) for (int t = 0; t < NT; ++t) tile_gp<RHS, DISC>(dm, E.pp, c, acc[t], t, NT);

@@ -115,10 +115,10 @@ def make_desc(batch, D, N_model, Y, Lidx, dt_model, RM, RF0, P, Pidx, disc="trap
         d.rm_kind, d.rm, d.rm_array = 0, float(RM), None
     if isinstance(RF0, np.ndarray):
         rf = _f64(RF0)
-        if rf.shape != (N_model - 1, D):
-            raise ValueError("RF0 array must have shape (N_model-1, D)")
+        if rf.shape not in [(N_model - 1, D), (N_model - 1, D, D)]:
+            raise ValueError("RF0 array must have shape (N_model-1, D) or (N_model-1, D, D)")
         keep.append(rf)
-        d.rf_kind, d.rf0, d.rf0_array = 1, 0.0, rf.ctypes.data_as(c_dp)
+        d.rf_kind, d.rf0, d.rf0_array = rf.ndim - 1, 0.0, rf.ctypes.data_as(c_dp)
     else:
         d.rf_kind, d.rf0, d.rf0_array = 0, float(RF0), None
     d.NP, d.NPest = P.shape[-1], len(Pidx)
@@ -227,7 +227,7 @@ def check(rc):
         raise VaError(rc, lib().va_last_error().decode("utf-8", "replace"))
 
 
-def eval4_plan(batch, D, N_model, disc, ne, rm_array=False, rm_full=False, rf_array=False, merr_nskip=1,
+def eval4_plan(batch, D, N_model, disc, ne, rm_array=False, rm_full=False, rf_array=False, rf_full=False, merr_nskip=1,
                tile_rows=0, eval_kernel=0, bounded=False, p_time_dependent=False):
     """(disc, K, w_scalar) of the column-run kernel instantiation a problem of this shape would run for a
     model whose column form publishes `ne` products per element, or None (flat kernel).  No GPU call."""
@@ -236,7 +236,7 @@ def eval4_plan(batch, D, N_model, disc, ne, rm_array=False, rm_full=False, rf_ar
     d.batch, d.D, d.N_model, d.merr_nskip = batch, D, N_model, merr_nskip
     d.N_data = (N_model - 1) // merr_nskip + 1
     d.rm_kind = (2 if rm_full else 1) if rm_array else 0
-    d.rf_kind = 1 if rf_array else 0
+    d.rf_kind = (2 if rf_full else 1) if rf_array else 0
     d.disc = DISC[disc] if isinstance(disc, str) else int(disc)
     d.tile_rows, d.eval_kernel = tile_rows, eval_kernel
     d.p_time_dependent = 1 if p_time_dependent else 0

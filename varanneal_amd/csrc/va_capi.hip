@@ -121,7 +121,7 @@ void run_eval(va_handle h, int epi)
 void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne)
 {
     bool user_rhs = ne <= 0;
-    user_rhs = user_rhs || d->p_time_dependent || d->rm_kind == 2;   // per-row parameters / full RM: flat kernel only
+    user_rhs = user_rhs || d->p_time_dependent || d->rm_kind == 2 || d->rf_kind == 2;   // per-row parameters / full RM or RF matrices: flat kernel only
     user_rhs = user_rhs || (d->lower && d->upper);                   // box bounds: the flat kernel carries the clamp / projected gradient
     const int D = d->D, N = d->N_model;
     const bool sh = d->disc == VA_DISC_SIMPSON_HERMITE;
@@ -619,7 +619,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     int *lidx_d = nullptr;
     if (d->rm_kind) TRY(h->alloc(&rm_d, rm_elems));
     if (d->rm_kind == 2) TRY(h->alloc(&lidx_d, dm.L));
-    if (d->rf_kind) TRY(h->alloc(&rf_d, (size_t)(dm.N - 1) * dm.D));
+    if (d->rf_kind) TRY(h->alloc(&rf_d, (size_t)(dm.N - 1) * dm.D * (d->rf_kind == 2 ? dm.D : 1)));
     double *lo_d = nullptr, *hi_d = nullptr;
     std::vector<double> lo_h, hi_h;
     if (dm.bounded) {
@@ -664,12 +664,13 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     H2D(P_d, d->P, B * np_seed, double);
     if (d->rm_kind) H2D(rm_d, d->rm_kind == 1 ? rms.data() : d->rm_array, rm_elems, double);
     if (d->rm_kind == 2) H2D(lidx_d, d->Lidx, dm.L, int);
-    if (d->rf_kind) H2D(rf_d, d->rf0_array, (size_t)(dm.N - 1) * dm.D, double);
+    if (d->rf_kind) H2D(rf_d, d->rf0_array, (size_t)(dm.N - 1) * dm.D * (d->rf_kind == 2 ? dm.D : 1), double);
     if (dm.bounded) { H2D(lo_d, lo_h.data(), (size_t)dm.ld, double); H2D(hi_d, hi_h.data(), (size_t)dm.ld, double); }
     dv.pp.lo = lo_d; dv.pp.hi = hi_d;
     if (d->t_model) H2D(t_d, d->t_model, (size_t)dm.N, double);
     if (d->n_stim > 0) H2D(st_d, d->stim, (size_t)dm.N * d->n_stim, double);
-    dv.pp.lmap = lmap_d; dv.pp.Y = Y_d; dv.pp.rf0_arr = rf_d;
+    dv.pp.lmap = lmap_d; dv.pp.Y = Y_d; dv.pp.rf0_arr = d->rf_kind == 1 ? rf_d : nullptr;
+    dv.pp.rf0_full = d->rf_kind == 2 ? rf_d : nullptr;
     dv.pp.rm_arr = d->rm_kind == 1 ? rm_d : nullptr;
     dv.pp.rm_full = d->rm_kind == 2 ? rm_d : nullptr; dv.pp.Lidx = lidx_d;
     dv.pp.Pidx = pidx_d; dv.pp.Pfull = P_d;

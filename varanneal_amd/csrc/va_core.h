@@ -72,6 +72,7 @@ struct ProblemPtrs {
     const double *Y;       // [N_data*L]
     const double *rm_arr;  // NULL or [N_data*L]
     const double *rf0_arr; // NULL or [(N-1)*D]
+    const double *rf0_full; // NULL or [(N-1)*D*D]: full model-error precision matrices (va_ode.py:211-217), flat kernel only
     const int *Pidx;       // [NPest]
     const double *Pfull;   // [B*NP]
     const double *tmodel;  // NULL or [N]: model times, for non-autonomous right-hand sides
@@ -282,12 +283,46 @@ VA_HD void tile_q(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &
                 have = true;
             }
             if (have) {
-                double w = pp.rf0_arr ? pp.rf0_arr[(size_t)row * D + i] : dm.rf0;
-                q = c.c * w * r;
-                if (lr >= HL && row < N) acc.v[EP_FE] += w * r * r;
+                if (pp.rf0_full) q = r;       // the bare residual: tile_qfull contracts the row with its matrix
+                else {
+                    double w = pp.rf0_arr ? pp.rf0_arr[(size_t)row * D + i] : dm.rf0;
+                    q = c.c * w * r;
+                    if (lr >= HL && row < N) acc.v[EP_FE] += w * r * r;
+                }
             }
         }
         c.qs[e] = q;
+        lr += dlr; i += di;
+        if (i >= D) { i -= D; ++lr; }
+    }
+}
+
+// phase 3b (full RF matrices, va_ode.py:211-217): fe = sum_n r_n . (R_n r_n) with R_n = RF0[n] (row n's
+// residual; Simpson-Hermite: d1 of the interval at even n, d2 at odd n -- RF[2i], RF[2i+1] upstream).  Reads the
+// residuals tile_q left in c.qs and writes the adjoints q_n = (c/2) (R_n + R_n^T) r_n over c.fs (f is no
+// longer needed); the caller then swaps the two arrays.  R is not assumed symmetric.
+template <int DISC>
+VA_HD void tile_qfull(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &acc, int tid, int nt)
+{
+    constexpr int HL = Halo<DISC>::HL;
+    const int D = dm.D, N = dm.N, tot = (dm.T + HL) * D;
+    int lr = tid / D, i = tid - lr * D;
+    const int dlr = nt / D, di = nt - dlr * D;
+    for (int e = tid; e < tot; e += nt) {
+        const int row = c.n0 - HL + lr;
+        double q = 0.0;
+        if (row >= 0 && row <= N - 2) {      // (rows without a residual hold zeros in c.qs)
+            const double *R = pp.rf0_full + (size_t)row * D * D;
+            const double *r = c.qs + lr * D;
+            double rowsum = 0.0, sym = 0.0;
+            for (int k = 0; k < D; ++k) {
+                rowsum += R[i * D + k] * r[k];
+                sym += (R[i * D + k] + R[k * D + i]) * r[k];
+            }
+            q = 0.5 * c.c * sym;
+            if (lr >= HL) acc.v[EP_FE] += r[i] * rowsum;
+        }
+        c.fs[e] = q;
         lr += dlr; i += di;
         if (i >= D) { i -= D; ++lr; }
     }

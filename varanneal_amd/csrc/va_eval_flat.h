@@ -124,6 +124,11 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
     __syncthreads();
     tile_q<DISC>(dm, dv.pp, c, acc, tid, nt);
     __syncthreads();
+    if (dv.pp.rf0_full) {
+        tile_qfull<DISC>(dm, dv.pp, c, acc, tid, nt);
+        double *t = c.qs; c.qs = c.fs; c.fs = t;
+        __syncthreads();
+    }
     tile_s<DISC>(dm, c, tid, nt);
     __syncthreads();
     tile_g<RHS, DISC>(dm, dv.pp, c, acc, tid, nt);

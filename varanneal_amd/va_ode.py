@@ -277,8 +277,13 @@ class Annealer(HIPmin):
                 self.RF0 = np.resize(RF0, (self.N_model - 1, self.D))
             elif RF0.shape == (self.N_model - 1, self.D):
                 self.RF0 = RF0
-            elif RF0.shape in [(self.D, self.D), (self.N_model - 1, self.D, self.D)]:
-                raise NotImplementedError("full RF matrices (va_ode.py:211-222)")
+            elif RF0.shape == (self.D, self.D):
+                # full matrices (va_ode.py:631-632): diff_n . (RF_n . diff_n) per time step, as upstream's
+                # Simpson-Hermite branch contracts them (:211-217; the other branch, :218-222, slips to the
+                # whole diff array -- the per-row contraction is what is computed for every discretisation)
+                self.RF0 = np.resize(RF0, (self.N_model - 1, self.D, self.D))
+            elif RF0.shape == (self.N_model - 1, self.D, self.D):
+                self.RF0 = RF0
             else:
                 raise ValueError("ERROR: RF0 has an invalid shape.")
         else:
@@ -343,7 +348,8 @@ class Annealer(HIPmin):
             def variant(ne):
                 return _capi.eval4_plan(self.B, self.D, self.N_model, disc, ne,
                                         rm_array=isinstance(self.RM, np.ndarray), rm_full=np.ndim(self.RM) == 3,
-                                        rf_array=isinstance(self.RF0, np.ndarray), merr_nskip=self.merr_nskip,
+                                        rf_array=isinstance(self.RF0, np.ndarray), rf_full=np.ndim(self.RF0) == 3,
+                                        merr_nskip=self.merr_nskip,
                                         bounded=self._device_bounds, p_time_dependent=self._tdp)
             mod = codegen.module_for(self.f, self.D, self.NP, nstim, 1 if stim is None else stim.ndim,
                                      p_rows=self._tdp, col_variant=variant)
