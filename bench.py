@@ -60,16 +60,14 @@ def bytes_alg(B, N, D, NPest, N_data, L):
     return 8 * (B * (2 * N * D + 2 * NPest + 3) + N_data * L)
 
 
-def kernel_name(D, tile_rows, eval_kernel):
-    """the evaluation kernel va_problem_create picks (csrc/va_capi.hip: pick_eval_geometry)"""
-    t4 = 4 <= D <= 64 and D % 2 == 0 and (64 // D) * D >= 48
-    ek = eval_kernel or (4 if t4 else (3 if D <= 1024 else 1))
-    if ek == 4 and t4:
-        return "k_eval4<RhsL96s,trapezoid,K=%d,D=%d>" % (tile_rows // (4 * (64 // D)), D)
-    if ek in (2, 3, 4):
-        nt = 256 if D <= 64 else 512 if D <= 128 else 256 if D <= 256 else 512 if D <= 512 else 1024
-        return "k_eval3<RhsL96g,trapezoid,K=%d,D=%d>" % (tile_rows // max(1, nt // D), D)
-    return "k_eval<RhsL96,trapezoid>"
+def kernel_name(D, info, generated=False):
+    """the evaluation kernel the handle runs (va_problem_eval_kernel; csrc/va_capi.hip: pick_eval_geometry)"""
+    ek, K = info["eval_kernel"], info["run_rows"]
+    if ek == 4:
+        return "k_eval4<%s,trapezoid,K=%d,D=%d>" % ("RhsUserCol" if generated else "RhsL96s", K, D)
+    if ek == 3:
+        return "k_eval3<%s,trapezoid,K=%d,D=%d>" % ("RhsUserG" if generated else "RhsL96g", K, D)
+    return "k_eval<%s,trapezoid>" % ("RhsUser" if generated else "RhsL96")
 
 
 def kernel_source_hash():
@@ -130,13 +128,34 @@ def cpu_baseline(D, N, Y, Lidx, XP, P, budget_s=10.0):
                       % (n, D, N, dt, os.cpu_count() or 0)}
 
 
+def usable_cpus():
+    """host CPUs this process may actually use: its affinity mask, capped by the container's CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline_all(D, N, Y, Lidx, XP, P, budget_s=8.0):
-    """the same C restatement, OpenMP over the seeds, every host core."""
+    """the same C restatement, OpenMP over the seeds, on every host core this process may
+    use (the GPU box gives one GPU's share of the host, not all of its cores)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import va_oracle
     from varanneal_amd import twin
-    nt = va_oracle.num_threads()
-    nb = min(len(P), max(nt, 8) * 2)
+    nt = min(usable_cpus(), len(P))
+    va_oracle.set_num_threads(nt)
+    nb = len(P) - len(P) % nt if len(P) >= nt else len(P)
     pbs = [va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[b], [0], disc="trapezoid") for b in range(nb)]
     va_oracle.action_grad_batch(pbs, XP[:nb], RF_SCALE)
     n, t0 = 0, time.perf_counter()
@@ -146,7 +165,7 @@ def cpu_baseline_all(D, N, Y, Lidx, XP, P, budget_s=8.0):
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "evals/s", "cores": nt, "kind": "port",
             "sample": "%d (A,gradA) evaluations of the same D=%d N=%d paths in %.1f s, OpenMP over seeds on %d "
-                      "threads (%d host cores)" % (n, D, N, dt, nt, os.cpu_count() or 0)}
+                      "threads (%d usable of %d host cores)" % (n, D, N, dt, nt, usable_cpus(), os.cpu_count() or 0)}
 
 
 def extra_c4(device, steps=60):
@@ -161,7 +180,7 @@ def extra_c4(device, steps=60):
         pb.eval_timed(RF_SCALE, 10)
         ks = pb.eval_timed(RF_SCALE, steps) * 1e-3 / steps
     balg = bytes_alg(B, N, D, 1, N, len(Lidx))
-    return {"workload": w["name"], "kernel": kernel_name(D, info["tile_rows"], 0) + " + k_finalize_eval",
+    return {"workload": w["name"], "kernel": kernel_name(D, info) + " + k_finalize_eval",
             "us_per_eval_launch": ks * 1e6, "evals_per_s": B / ks, "bytes_alg_per_launch": balg,
             "achieved_GBs": balg / ks / 1e9, "frac": balg / ks / 1e9 / HBM_PEAK_GBS}
 
@@ -346,6 +365,9 @@ def main():
                     help="eval: the contract line (batched A/gradA launches); ladder: a whole "
                          "RF ladder through va_anneal, extra information (stderr-style JSON)")
     ap.add_argument("--nbeta", type=int, default=30)
+    ap.add_argument("--generated", action="store_true",
+                    help="run the workload's Lorenz-96 as a user would supply it: a Python callable traced and "
+                         "compiled by varanneal_amd.codegen (not the built-in right-hand side)")
     ap.add_argument("--eval-kernel", type=int, default=0, help="0 auto, 1 flat-mapped, 3 workgroup column runs, 4 wave-private column runs")
     args = ap.parse_args()
 
@@ -370,7 +392,16 @@ def main():
     w = WORKLOADS[args.workload]
     D, N, B = w["D"], w["N"], w["B"]
     Y, Lidx, XP, P = make_inputs(D, N, B, rank)
-    pb = _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid",
+    rhs = "lorenz96"
+    if args.generated:
+        from varanneal_amd import codegen
+
+        def l96_user(t, x, p):
+            return np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - x + p[0]
+        mod = codegen.module_for(l96_user, D, 1, col_variant=lambda ne, gh: _capi.eval_plan(
+            B, D, N, "trapezoid", ne, gh, tile_rows=args.tile_rows, eval_kernel=args.eval_kernel))
+        rhs = _capi.load_rhs_module(mod["so"])
+    pb = _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", rhs=rhs,
                        device=local_rank, tile_rows=args.tile_rows, eval_kernel=args.eval_kernel)
     info = pb.info()
     if args.mode == "ladder":
@@ -402,7 +433,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "step": "complete S1 evaluation: A, me, fe formed in the same launch (va_epilogue.h)",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(w["name"]),
-                         "kernel": kernel_name(D, info["tile_rows"], args.eval_kernel),
+                         "kernel": kernel_name(D, info, args.generated),
                          "kernel_us": kern_s * 1e6, "bytes_alg_per_launch": balg},
             "cpu_baseline": None,
         }

@@ -118,12 +118,15 @@ int va_device_count(int32_t *count);
  * varanneal_amd/csrc/va_user_rhs.hip + a generated header); returns its rhs id. */
 int va_rhs_load_module(const char *path, int32_t *rhs_id);
 
-/* For the code generator: which instantiation of the wave-private column-run kernel (k_eval4) a problem
- * of this shape would run for a model whose column form publishes `ne` products per element.  Reads only
- * the sizes, kinds and flags of `desc` (pointers other than lower/upper are not followed; no GPU call).
- * out[4] = (1 if that kernel applies else 0, disc, rows per run K, 1 if scalar weights else 0).  A
- * module built for exactly that triple runs on k_eval4; any other problem runs its flat kernel. */
-int va_eval4_plan(const va_problem_desc *desc, int32_t ne, int32_t *out);
+/* For the code generator: which instantiation of a column-run evaluation kernel a problem of this shape
+ * would run for a model that has a column form publishing `ne` products per element (wave-private kernel
+ * k_eval4, narrow states; 0 = no such form) and / or a ghosted form with `ghost` ghost columns per side
+ * (workgroup kernel k_eval3, wide states; 0 = none).  Reads only the sizes, kinds and flags of `desc`
+ * (pointers other than lower/upper are not followed; no GPU call).
+ * out[4] = (eval kernel: 0 flat / 3 / 4, disc, rows per lane run K,
+ *           kernel 4: 1 if scalar weights else 0; kernel 3: threads per workgroup).
+ * A module built for exactly that instantiation runs it; any other problem runs the module's flat kernel. */
+int va_eval_plan(const va_problem_desc *desc, int32_t ne, int32_t ghost, int32_t *out);
 
 int va_problem_create(const va_problem_desc *desc, va_handle *out);
 void va_problem_destroy(va_handle h);

@@ -83,13 +83,28 @@ int vao_action_grad(const vao_problem *pb, const double *XP, double rf_scale,
 
     /* parameter vector: copy of P with the estimated entries taken from XP
      * (va_ode.py:165-181). */
-    double *p = (double *)malloc(sizeof(double) * (pb->NP > 0 ? pb->NP : 1));
+    /* scratch: one block per thread, kept between calls (buffers of this size would otherwise be
+     * mmap'ed and unmapped on every call, which serialises the threads of vao_action_grad_batch
+     * in the kernel) */
+    static _Thread_local double *scratch = NULL;
+    static _Thread_local size_t scratch_cap = 0;
+    const size_t npp = (size_t)(pb->NP > 0 ? pb->NP : 1);
+    const size_t need = 2 * (size_t)ND + 2 * npp;
+    if (need > scratch_cap) {
+        free(scratch);
+        scratch = (double *)malloc(sizeof(double) * need);
+        scratch_cap = scratch ? need : 0;
+        if (!scratch) return -4;
+    }
+    double *f = scratch;                                    /* f at every row   */
+    double *sadj = f + ND;                                  /* adjoint of f rows */
+    double *p = sadj + ND;
+    double *gpfull = p + npp;
+    memset(sadj, 0, sizeof(double) * ND);
+    memset(gpfull, 0, sizeof(double) * npp);
     for (int k = 0; k < pb->NP; ++k) p[k] = pb->P[k];
     for (int k = 0; k < pb->NPest; ++k) p[pb->Pidx[k]] = XP[ND + k];
 
-    double *f = (double *)malloc(sizeof(double) * ND);      /* f at every row   */
-    double *sadj = (double *)calloc(ND, sizeof(double));    /* adjoint of f rows */
-    double *gpfull = (double *)calloc(pb->NP > 0 ? pb->NP : 1, sizeof(double));
     for (int n = 0; n < N; ++n) rf(D, XP + n * D, p, f + n * D);
     if (grad) memset(grad, 0, sizeof(double) * (ND + pb->NPest));
 
@@ -175,7 +190,6 @@ int vao_action_grad(const vao_problem *pb, const double *XP, double rf_scale,
         for (int k = 0; k < pb->NPest; ++k) grad[ND + k] = gpfull[pb->Pidx[k]];
     }
     *A_out = me + fe; *me_out = me; *fe_out = fe;
-    free(p); free(f); free(sadj); free(gpfull);
     return 0;
 }
 
@@ -498,6 +512,16 @@ int vao_num_threads(void)
     return omp_get_max_threads();
 #else
     return 1;
+#endif
+}
+
+/* threads the next batch calls use (a container's CPU quota can be far below the cores it can see) */
+void vao_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
 #endif
 }
 

@@ -62,6 +62,7 @@ int vao_action_grad_batch(const vao_problem *const *pb, int nseeds, const double
                           double *A, double *me, double *fe, double *grad);
 /* threads an OpenMP region of this library runs on */
 int vao_num_threads(void);
+void vao_set_num_threads(int n);
 
 /* objective callback of vao_lbfgs_generic: value and gradient at x; non-zero return = failure */
 typedef int (*vao_fg_t)(void *ctx, const double *x, double *f, double *g);

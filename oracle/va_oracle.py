@@ -108,6 +108,10 @@ def lbfgs_generic(fg, x0, opt_args=None, bounds=None):
     return x, A.value, st.value, nit.value, nfev.value
 
 
+def set_num_threads(n):
+    lib().vao_set_num_threads(int(n))
+
+
 def num_threads():
     """threads the batch evaluation runs on (OpenMP; OMP_NUM_THREADS or every host core)"""
     return lib().vao_num_threads()

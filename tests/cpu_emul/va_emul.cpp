@@ -42,6 +42,10 @@ int setup(const va_problem_desc *d, int T, Emul &E)
     if (m.tdp) { m.ND = m.N * (m.D + m.NPe); m.NP = 0; m.NPest = 0; }
     m.ld = ((m.ND + m.NPest + 15) / 16) * 16;
     if (m.disc == DISC_SH && (T & 1)) ++T;
+    m.ghost = 2;
+#ifdef VA_USER_GHOST
+    if (d->rhs >= VA_RHS_USER_BASE) m.ghost = RhsUserG::GHOST;
+#endif
     m.emode = (d->eval_kernel >= 1 && d->eval_kernel <= 4) ? d->eval_kernel : (tile4_ok(m.D) ? 4 : 3);
     if (m.emode == 2) m.emode = 3;           // (the row-strided kernel of round 1 is gone)
     if (m.emode == 4 && !tile4_ok(m.D)) m.emode = 3;
@@ -96,6 +100,9 @@ int setup(const va_problem_desc *d, int T, Emul &E)
 #ifdef VA_USER_COL
     // a generated model with a column form runs the wave-private kernel's phases when asked for by name
     if (d->eval_kernel == 4 && m.emode == 4) user_flat = false;
+#endif
+#ifdef VA_USER_GHOST
+    if (d->eval_kernel == 3 && m.emode == 3) user_flat = false;      // likewise the ghosted form / workgroup kernel
 #endif
     if (user_flat || m.tdp || d->rm_kind == 2 || d->rf_kind == 2) m.emode = 1;
     E.rhs = d->rhs;
@@ -165,7 +172,7 @@ void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_
             c.xs = xs.data(); c.ss = ss.data();
             c.xg = x; c.dg = d; c.gtg = gt;
             Tile2 tmp; tmp.xg = x; tmp.dg = d; tmp.use_d = use_d; tmp.stp = stp;
-            tile2_params<RhsL96c>(dm, E.pp, b, tmp);
+            tile2_params<RHS>(dm, E.pp, b, tmp);          // (only RHS::NP is used)
             for (int k = 0; k < RHS_MAX_NP; ++k) c.p[k] = tmp.p[k];
             acc[t].clear();
         }
@@ -302,6 +309,16 @@ void eval_seed_rhs(const Emul &E, int b, const double *x, const double *d, int u
         else if (E.dm.maxr == 6) eval_seed4<RhsUserCol, DISC, 6>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
         else if (E.dm.maxr == 7) eval_seed4<RhsUserCol, DISC, 7>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
         else eval_seed4<RhsUserCol, DISC, 8>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        return;
+    }
+#endif
+#ifdef VA_USER_GHOST
+    if (E.rhs >= VA_RHS_USER_BASE && E.dm.emode == 3) {
+        if (E.dm.maxr == 4) eval_seed3<RhsUserG, DISC, 4>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 5) eval_seed3<RhsUserG, DISC, 5>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 6) eval_seed3<RhsUserG, DISC, 6>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 7) eval_seed3<RhsUserG, DISC, 7>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else eval_seed3<RhsUserG, DISC, 8>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
         return;
     }
 #endif

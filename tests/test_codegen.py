@@ -72,7 +72,7 @@ def test_generated_nakl_matches_complex_step(nakl_module, disc):
 
 def test_generated_time_dependent_rhs():
     D, NP, N = 12, 2, 31
-    m = codegen.module_for(l96_damped, D, NP)
+    m = codegen.module_for(l96_damped, D, NP, compile=False)          # (the emulator compiles the header itself)
     rng = np.random.RandomState(4)
     t = 0.025 * np.arange(N)
     Y = rng.randn(N, 5); Lidx = [0, 2, 5, 7, 10]
@@ -154,7 +154,7 @@ def test_column_form_structure():
 def test_column_form_nakl_matches_flat_form_and_complex_step(disc):
     """dense column form (switch on the column) + stimulus + per-component RF + 18 estimated parameters"""
     D, NP, N, t, stim, Y, X, P, RF0 = _nakl_problem(N=61)
-    m = codegen.module_for(nakl, 4, 18, nstim=1, stim_ndim=1, col_variant=lambda ne: (_capi.DISC[disc], 4, 0),
+    m = codegen.module_for(nakl, 4, 18, nstim=1, stim_ndim=1, col_variant=lambda ne, gh: (4, _capi.DISC[disc], 4, 0),
                            compile=False)
     assert m["col"] is not None and "#define VA_USER_COL" in m["text"]
     Pidx = list(range(18))
@@ -184,7 +184,7 @@ def test_column_form_traced_l96_equals_builtin(disc):
     Lidx = [0, 3, 6, 9, 12, 15, 18]
     Y = rng.randn(N, len(Lidx)); P = np.array([8.17])
     XP = np.append(3.0 * rng.randn(N * D), P)
-    m = codegen.module_for(_l96_plain, D, 1, col_variant=lambda ne: (_capi.DISC[disc], 6, 1), compile=False)
+    m = codegen.module_for(_l96_plain, D, 1, col_variant=lambda ne, gh: (4, _capi.DISC[disc], 6, 1), compile=False)
     res = {}
     for rhs in ("lorenz96", 1000):
         desc, keep = _capi.make_desc(1, D, N, Y, Lidx, 0.025, 4.0, 0.3, P[None, :], [0], disc=disc, rhs=rhs,
@@ -198,7 +198,7 @@ def test_column_form_traced_l96_equals_builtin(disc):
 
 def test_column_form_time_dependent_stencil():
     D, NP, N = 12, 2, 45
-    m = codegen.module_for(l96_damped, D, NP, col_variant=lambda ne: (1, 4, 1), compile=False)
+    m = codegen.module_for(l96_damped, D, NP, col_variant=lambda ne, gh: (4, 1, 4, 1), compile=False)
     assert m["col"]["uniform"]
     rng = np.random.RandomState(4)
     t = 0.025 * np.arange(N)
@@ -217,21 +217,86 @@ def test_column_form_time_dependent_stencil():
 
 def test_column_module_exports_its_variant():
     import ctypes as C
-    m = codegen.module_for(_l96_plain, 20, 1, col_variant=lambda ne: (1, 7, 1) if ne == 2 else None)
+    m = codegen.module_for(_l96_plain, 20, 1, col_variant=lambda ne, gh: (4, 1, 7, 1) if ne == 2 else None)
     L = C.CDLL(m["so"])
-    v = (C.c_int * 5)()
-    L.va_user_col_info(v)
-    assert list(v) == [1, 1, 7, 1, 2] and hasattr(L, "va_user_launch_eval4") and hasattr(L, "va_user_prepare_eval4")
-    m0 = codegen.module_for(_l96_plain, 20, 1)                  # no variant asked for: flat kernel only
-    L0 = C.CDLL(m0["so"])
-    L0.va_user_col_info(v)
-    assert list(v)[0] == 0 and not hasattr(L0, "va_user_launch_eval4")
+    v = (C.c_int * 6)()
+    L.va_user_variant_info(v)
+    assert list(v) == [4, 1, 7, 1, 2, 0] and hasattr(L, "va_user_launch_variant") and hasattr(L, "va_user_prepare_variant")
 
 
-def test_eval4_plan_matches_the_geometry_rules():
-    assert _capi.eval4_plan(64, 20, 1000, "trapezoid", 2) == (1, 7, 1)          # C3: 12 tiles x 64 = 3 per CU
-    assert _capi.eval4_plan(512, 20, 1000, "trapezoid", 2) == (1, 6, 1)
-    assert _capi.eval4_plan(1, 4, 2001, "SimpsonHermite", 3, rf_array=True) == (2, 4, 0)
-    assert _capi.eval4_plan(1, 4, 2001, "SimpsonHermite", 3, bounded=True) is None   # bounds: flat kernel
-    assert _capi.eval4_plan(1, 22, 200, "trapezoid", 2) is None                 # D = 22: two runs leave 20 lanes idle
-    assert _capi.eval4_plan(1, 20, 200, "trapezoid", 2, p_time_dependent=True) is None
+def test_module_without_variant_reports_none(nakl_module):
+    import ctypes as C
+    L0 = C.CDLL(nakl_module["so"])                              # no variant asked for: flat kernel only
+    v = (C.c_int * 6)()
+    L0.va_user_variant_info(v)
+    assert list(v)[0] == 0 and not hasattr(L0, "va_user_launch_variant")
+
+
+def test_eval_plan_matches_the_geometry_rules():
+    assert _capi.eval_plan(64, 20, 1000, "trapezoid", 2, 2) == (4, 1, 7, 1)          # C3: 12 tiles x 64 = 3 per CU
+    assert _capi.eval_plan(512, 20, 1000, "trapezoid", 2, 2) == (4, 1, 6, 1)
+    assert _capi.eval_plan(1, 4, 2001, "SimpsonHermite", 3, rf_array=True) == (4, 2, 4, 0)
+    assert _capi.eval_plan(1, 4, 2001, "SimpsonHermite", 3, bounded=True) is None   # bounds: flat kernel
+    assert _capi.eval_plan(1, 22, 200, "trapezoid", 2) is None                 # D = 22: two runs leave 20 lanes idle...
+    assert _capi.eval_plan(1, 22, 200, "trapezoid", 2, 2)[0] == 3              # ...the workgroup kernel takes it
+    assert _capi.eval_plan(1, 20, 200, "trapezoid", 2, 2, p_time_dependent=True) is None
+    assert _capi.eval_plan(64, 200, 5000, "trapezoid", 0, 2) == (3, 1, 8, 256)  # C4's shape: one lane per column
+    assert _capi.eval_plan(64, 200, 5000, "trapezoid", 2, 0) is None
+    assert _capi.eval_plan(64, 2000, 500, "trapezoid", 0, 2) is None            # beyond 1024 columns: flat
+
+
+# ---- the ghosted form (codegen.ghost_form): wide stencils on the workgroup column-run kernel ------------------
+def _wide_stencil(t, x, p):
+    """not Lorenz-96: a five-point stencil with a cubic term and two parameters"""
+    return (np.roll(x, 1, 1) * (np.roll(x, -2, 1) - np.roll(x, 2, 1)) - p[1] * x ** 3
+            + p[0] * np.roll(x, -1, 1))
+
+
+def test_ghost_form_structure():
+    ex, sy = codegen.trace(_l96_plain, 100, 1)
+    g = codegen.ghost_form(ex, sy, 100, 1, 0)
+    assert g["GHOST"] == 2 and g["offsets"] == [-2, -1, 0, 1]                  # as RhsL96g (csrc/va_tile3.h)
+    ex, sy = codegen.trace(_wide_stencil, 70, 2)
+    g = codegen.ghost_form(ex, sy, 70, 2, 0)
+    assert g["GHOST"] == 4                       # the adjoint of x_{j-1} x_{j+2} reads three columns away
+    ex, sy = codegen.trace(l96_damped, 12, 2)
+    assert codegen.ghost_form(ex, sy, 12, 2, 0) is None                        # explicit time: column form only
+    ex, sy = codegen.trace(nakl, 4, 18, 1, 1)
+    assert codegen.ghost_form(ex, sy, 4, 18, 1) is None
+
+
+@pytest.mark.parametrize("f,D,NP", [(_l96_plain, 72, 1), (_wide_stencil, 70, 2)])
+@pytest.mark.parametrize("disc", ["trapezoid", "SimpsonHermite", "euler", "forwardmap"])
+def test_ghost_form_matches_flat_form_and_complex_step(f, D, NP, disc):
+    N = 41
+    rng = np.random.RandomState(D)
+    Lidx = list(range(0, D, 5))
+    Y = rng.randn(N, len(Lidx)); P = np.array([8.0, 0.05][:NP])
+    XP = np.append(2.0 * rng.randn(N * D), P)
+    m = codegen.module_for(f, D, NP, col_variant=lambda ne, gh: (3, _capi.DISC[disc], 4, 128) if gh else None,
+                           compile=False)
+    assert m["ghost"] is not None and "#define VA_USER_GHOST" in m["text"]
+    Pidx = list(range(NP))
+    fun = lambda z: va_oracle.numpy_action_generic(f, z, D, N, Y, Lidx, 0.025, 4.0, 0.3, NP, Pidx, P, disc)
+    g0 = va_oracle.complex_step_grad(fun, XP)
+    out = {}
+    for ek in (1, 3):
+        desc, keep = _capi.make_desc(1, D, N, Y, Lidx, 0.025, 4.0, 0.3, P[None, :], Pidx, disc=disc, rhs=1000,
+                                     eval_kernel=ek)
+        out[ek] = emul.action_grad(desc, 8, XP[None, :], 1.0, user_header=m["header"])
+    A0 = fun(XP)[0]
+    for ek in (1, 3):
+        A, me, fe, g = out[ek]
+        assert abs(A[0] - A0) <= 1e-12 * abs(A0)
+        assert np.abs(g[0] - g0).max() <= 1e-10 * np.abs(g0).max()
+    assert np.abs(out[3][3] - out[1][3]).max() <= 1e-12 * np.abs(g0).max()
+
+
+def test_ghost_module_exports_its_variant():
+    import ctypes as C
+    m = codegen.module_for(_l96_plain, 200, 1, col_variant=lambda ne, gh: _capi.eval_plan(64, 200, 5000, "trapezoid", ne, gh))
+    assert m["col_variant"] == (3, 1, 8, 256) and m["col"] is None
+    L = C.CDLL(m["so"])
+    v = (C.c_int * 6)()
+    L.va_user_variant_info(v)
+    assert list(v) == [3, 1, 8, 256, 0, 2]

@@ -170,7 +170,7 @@ def test_bounded_device_minimiser_follows_the_oracle_step_for_step():
             assert abs(r["A"][b] - A) <= 1e-6 * abs(A) and np.abs(r["x"][b] - x).max() <= 2e-2   # (flat directions: 60 iterations amplify last-bit differences)
 
 
-# ---- generated models on the wave-private column-run kernel (codegen.column_form, va_eval4_plan) ---------------
+# ---- generated models on the wave-private column-run kernel (codegen.column_form, va_eval_plan) ---------------
 def _l96_user(t, x, p):
     """Lorenz-96 as a user would write it (not the registry's callable): traced, recognised as a stencil"""
     return np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - x + p[0]
@@ -187,14 +187,14 @@ def test_nakl_on_the_column_kernel_matches_reference(gold, name):
     P = XP[N * D:]
     B = 3
     m = codegen.module_for(nakl, 4, 18, nstim=1, stim_ndim=1,
-                           col_variant=lambda ne: _capi.eval4_plan(B, D, N, str(c["disc"]), ne, rf_array=True))
+                           col_variant=lambda ne, gh: _capi.eval_plan(B, D, N, str(c["disc"]), ne, gh, rf_array=True))
     assert m["col_variant"] is not None
     rng = np.random.RandomState(5)
     XPb = np.stack([XP, XP + 0.01 * rng.randn(XP.size), XP])
     pr = _capi.Problem(B, D, N, c["Y"], [0], float(c["dt_model"]), float(c["RM"]), RF0, np.tile(P, (B, 1)),
                        list(range(18)), disc=str(c["disc"]), rhs=_capi.load_rhs_module(m["so"]), t_model=c["t"],
                        stim=c["stim"])
-    assert pr.info()["eval_kernel"] == 4 and pr.info()["run_rows"] == m["col_variant"][1]
+    assert pr.info()["eval_kernel"] == 4 and pr.info()["run_rows"] == m["col_variant"][2]
     A, me, fe, g = pr.action_grad(XPb, float(c["rf_scale"]))
     for b in (0, 2):
         assert abs(A[b] - c["A"]) <= 1e-12 * c["A"]
@@ -208,7 +208,7 @@ def test_column_module_on_another_geometry_runs_its_flat_kernel(gold):
     """a module carries ONE instantiation of k_eval4; a problem that calls for another runs the flat kernel"""
     c = gold["g5_nakl_trapezoid_rf1e+00"]
     D, N = int(c["D"]), int(c["N_model"])
-    m = codegen.module_for(nakl, 4, 18, nstim=1, stim_ndim=1, col_variant=lambda ne: (2, 4, 0))   # Simpson-Hermite
+    m = codegen.module_for(nakl, 4, 18, nstim=1, stim_ndim=1, col_variant=lambda ne, gh: (4, 2, 4, 0))   # Simpson-Hermite
     XP = c["XP"]; P = XP[N * D:]
     pr = _capi.Problem(1, D, N, c["Y"], [0], float(c["dt_model"]), float(c["RM"]), np.resize(c["RF0"], (N - 1, D)),
                        P[None, :], list(range(18)), disc="trapezoid", rhs=_capi.load_rhs_module(m["so"]),
@@ -230,8 +230,8 @@ def test_traced_l96_runs_at_the_builtin_speed_and_agrees():
         x, p = twin.initial_guess(N, D, s, Y, Lidx)
         XP[s, :N * D] = x.ravel(); XP[s, N * D:] = p
     P = XP[:, N * D:].copy()
-    m = codegen.module_for(_l96_user, D, 1, col_variant=lambda ne: _capi.eval4_plan(B, D, N, "trapezoid", ne))
-    assert m["col"]["uniform"] and m["col_variant"] == (1, 7, 1)
+    m = codegen.module_for(_l96_user, D, 1, col_variant=lambda ne, gh: _capi.eval_plan(B, D, N, "trapezoid", ne, gh))
+    assert m["col"]["uniform"] and m["col_variant"] == (4, 1, 7, 1)
     out, us = {}, {}
     for rhs in ("lorenz96", _capi.load_rhs_module(m["so"])):
         pr = _capi.Problem(B, D, N, Y, Lidx, 0.025, 4.0, 4e-6, P, [0], disc="trapezoid", rhs=rhs)
@@ -270,3 +270,71 @@ def test_annealer_puts_a_traced_stencil_on_the_column_kernel():
         a.close()
     assert np.array_equal(res[twin.l96][1], res[_l96_user][1])
     assert np.allclose(res[twin.l96][0], res[_l96_user][0], rtol=1e-9)
+
+
+# ---- wide generated stencils on the workgroup column-run kernel (codegen.ghost_form) ------------------------------
+def _wide_stencil(t, x, p):
+    """not Lorenz-96: five-point stencil, cubic damping, two parameters; its adjoint needs 4 ghost columns"""
+    return (np.roll(x, 1, 1) * (np.roll(x, -2, 1) - np.roll(x, 2, 1)) - p[1] * x ** 3
+            + p[0] * np.roll(x, -1, 1))
+
+
+def test_traced_l96_at_c4_width_runs_the_builtin_kernel():
+    """D = 200 (BASELINE config 4's width): the traced Lorenz-96 gets k_eval3 through its ghosted form --
+    values within 1e-13 of the built-in's, evaluation time within 10 % (the flat kernel takes 2.6x as long)"""
+    from varanneal_amd import twin
+    D, N, B = 200, 2000, 64
+    Lidx = list(range(0, D, 5))
+    t, Y, _, _ = twin.make_twin(D, N, Lidx=Lidx)
+    rng = np.random.RandomState(0)
+    XP = np.concatenate([8.0 * rng.rand(B, N * D) - 4.0, 8.17 + 0.1 * rng.randn(B, 1)], axis=1)
+    P = XP[:, N * D:].copy()
+    m = codegen.module_for(_l96_user, D, 1, col_variant=lambda ne, gh: _capi.eval_plan(B, D, N, "trapezoid", ne, gh))
+    assert m["ghost"]["GHOST"] == 2 and m["col_variant"][0] == 3
+    out, us = {}, {}
+    for key, rhs in (("builtin", "lorenz96"), ("traced", _capi.load_rhs_module(m["so"]))):
+        pr = _capi.Problem(B, D, N, Y, Lidx, 0.025, 4.0, 4e-6, P, [0], disc="trapezoid", rhs=rhs)
+        assert pr.info()["eval_kernel"] == 3 and pr.info()["run_rows"] == m["col_variant"][2]
+        out[key] = pr.action_grad(XP, 1.5 ** 20)
+        pr.eval_timed(1.5 ** 20, 20)
+        us[key] = min(pr.eval_timed(1.5 ** 20, 100) for _ in range(3)) / 100 * 1e3
+        pr.close()
+    (Ab, meb, feb, gb), (A, me, fe, g) = out["builtin"], out["traced"]
+    assert np.all(np.abs(A - Ab) <= 1e-13 * np.abs(Ab)) and np.array_equal(me, meb)
+    assert np.abs(g - gb).max() <= 1e-13 * np.abs(gb).max()
+    print("D=200 N=2000 B=64 evaluation: built-in %.1f us, traced + generated %.1f us" % (us["builtin"], us["traced"]))
+    assert us["traced"] <= 1.10 * us["builtin"]
+
+
+@pytest.mark.parametrize("disc", ["trapezoid", "SimpsonHermite"])
+def test_wide_stencil_with_four_ghost_columns_on_device(disc):
+    D, NP, N, B = 70, 2, 201, 3
+    rng = np.random.RandomState(70)
+    Lidx = list(range(0, D, 7))
+    Y = rng.randn(N, len(Lidx)); P = np.array([8.0, 0.05])
+    XP = np.append(2.0 * rng.randn(N * D), P)
+    m = codegen.module_for(_wide_stencil, D, NP, col_variant=lambda ne, gh: _capi.eval_plan(B, D, N, disc, ne, gh))
+    assert m["ghost"]["GHOST"] == 4 and m["col_variant"][0] == 3
+    fun = lambda z: va_oracle.numpy_action_generic(_wide_stencil, z, D, N, Y, Lidx, 0.025, 4.0, 0.3, NP, [0, 1], P, disc)
+    pr = _capi.Problem(B, D, N, Y, Lidx, 0.025, 4.0, 0.3, np.tile(P, (B, 1)), [0, 1], disc=disc,
+                       rhs=_capi.load_rhs_module(m["so"]))
+    assert pr.info()["eval_kernel"] == 3
+    XPb = np.stack([XP, XP * 1.01, XP])
+    A, me, fe, g = pr.action_grad(XPb, 1.0)
+    # the flat kernel of the same module on the same point (independent mapping, same generated derivatives)
+    pf = _capi.Problem(B, D, N, Y, Lidx, 0.025, 4.0, 0.3, np.tile(P, (B, 1)), [0, 1], disc=disc,
+                       rhs=_capi.load_rhs_module(m["so"]), eval_kernel=1)
+    assert pf.info()["eval_kernel"] == 1
+    Af, mef, fef, gf = pf.action_grad(XPb, 1.0)
+    A0 = fun(XP)[0]
+    assert abs(A[0] - A0) <= 1e-12 * A0 and abs(A[2] - A0) <= 1e-12 * A0
+    assert np.abs(g - gf).max() <= 1e-12 * np.abs(gf).max()
+    # a handful of gradient entries against complex-step derivatives of the NumPy restatement
+    idx = np.r_[rng.choice(N * D, 12, replace=False), N * D, N * D + 1]
+    z = XP.astype(complex)
+    for i in idx:
+        z[i] += 1e-30j
+        gi = fun(z)[0].imag / 1e-30
+        z[i] = XP[i]
+        assert abs(g[0, i] - gi) <= 1e-10 * np.abs(g[0]).max()
+    pr.close(); pf.close()

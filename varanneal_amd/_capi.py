@@ -183,7 +183,7 @@ def lib():
     L.va_problem_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(h)]
     L.va_nnet_problem_create.argtypes = [C.POINTER(NnetDesc), C.POINTER(h)]
     L.va_rhs_load_module.argtypes = [C.c_char_p, c_ip]
-    L.va_eval4_plan.argtypes = [C.POINTER(ProblemDesc), C.c_int32, C.POINTER(C.c_int32)]
+    L.va_eval_plan.argtypes = [C.POINTER(ProblemDesc), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     L.va_problem_destroy.argtypes = [h]
     L.va_problem_destroy.restype = None
     L.va_problem_info.argtypes = [h, c_lp, c_lp, c_ip, c_ip]
@@ -205,7 +205,7 @@ def lib():
     L.va_read_eval_outputs.argtypes = [h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.va_debug_read_partials.argtypes = [h, c_dp, C.c_int64]
     L.va_problem_eval_kernel.argtypes = [h, c_ip, c_ip]
-    for fn in ("va_device_count", "va_rhs_load_module", "va_eval4_plan", "va_problem_eval_kernel", "va_problem_create", "va_nnet_problem_create",
+    for fn in ("va_device_count", "va_rhs_load_module", "va_eval_plan", "va_problem_eval_kernel", "va_problem_create", "va_nnet_problem_create",
                "va_problem_info", "va_action_grad",
                "va_minimize_lbfgs", "va_anneal", "va_get_minpath", "va_eval_timed",
                "va_get_counters", "va_debug_read_partials", "va_read_eval_outputs", "va_lbfgs_timed",
@@ -215,7 +215,7 @@ def lib():
     return L
 
 
-EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_eval4_plan", "va_problem_eval_kernel", "va_problem_create",
+EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_eval_plan", "va_problem_eval_kernel", "va_problem_create",
            "va_problem_destroy", "va_problem_info", "va_action_grad", "va_minimize_lbfgs",
            "va_anneal", "va_get_minpath", "va_eval_timed", "va_get_counters", "va_nnet_problem_create", "va_debug_read_partials",
            "va_read_eval_outputs", "va_lbfgs_timed", "va_comm_unique_id", "va_comm_create", "va_comm_destroy",
@@ -227,10 +227,12 @@ def check(rc):
         raise VaError(rc, lib().va_last_error().decode("utf-8", "replace"))
 
 
-def eval4_plan(batch, D, N_model, disc, ne, rm_array=False, rm_full=False, rf_array=False, rf_full=False, merr_nskip=1,
-               tile_rows=0, eval_kernel=0, bounded=False, p_time_dependent=False):
-    """(disc, K, w_scalar) of the column-run kernel instantiation a problem of this shape would run for a
-    model whose column form publishes `ne` products per element, or None (flat kernel).  No GPU call."""
+def eval_plan(batch, D, N_model, disc, ne, ghost=0, rm_array=False, rm_full=False, rf_array=False, rf_full=False,
+              merr_nskip=1, tile_rows=0, eval_kernel=0, bounded=False, p_time_dependent=False):
+    """(eval kernel 3 | 4, disc, K, w) of the column-run kernel instantiation a problem of this shape would run
+    for a model with a column form of `ne` products per element and / or a ghosted form of `ghost` ghost
+    columns (0 = the model has no such form), or None (flat kernel).  w: kernel 4 -- 1 for scalar weights;
+    kernel 3 -- threads per workgroup.  No GPU call (va_eval_plan)."""
     d = ProblemDesc()
     d.struct_size = C.sizeof(ProblemDesc)
     d.batch, d.D, d.N_model, d.merr_nskip = batch, D, N_model, merr_nskip
@@ -244,8 +246,8 @@ def eval4_plan(batch, D, N_model, disc, ne, rm_array=False, rm_full=False, rf_ar
     if bounded:
         d.lower = C.cast(dummy, c_dp); d.upper = C.cast(dummy, c_dp)
     out = (C.c_int32 * 4)()
-    check(lib().va_eval4_plan(C.byref(d), int(ne), out))
-    return (out[1], out[2], out[3]) if out[0] else None
+    check(lib().va_eval_plan(C.byref(d), int(ne), int(ghost), out))
+    return (out[0], out[1], out[2], out[3]) if out[0] else None
 
 
 _modules = {}

@@ -149,7 +149,7 @@ def _emit_case(pr, expr, ret):
     return " ".join(lines)
 
 
-def generate_header(exprs, syms, D, NP, nstim, name="user", col=None):
+def generate_header(exprs, syms, D, NP, nstim, name="user", col=None, ghost=None):
     sp = _sympy()
     pr = _printer()
     sv = sp.symbols("sv0:%d" % D, real=True)
@@ -203,6 +203,11 @@ def generate_header(exprs, syms, D, NP, nstim, name="user", col=None):
                    % ("translation-invariant stencil, offsets %s" % col["offsets"] if col["uniform"] else "dense, switch on the column"))
         out.append("#define VA_USER_COL 1")
         out.append(col["text"])
+    if ghost is not None:
+        out.append("// the same stencil in ghosted column form (codegen.ghost_form): offsets %s, %d ghost columns"
+                   % (ghost["offsets"], ghost["GHOST"]))
+        out.append("#define VA_USER_GHOST 1")
+        out.append(ghost["text"])
     out.append("}  // namespace va")
     return "\n".join(out) + "\n"
 
@@ -283,7 +288,11 @@ def column_form(exprs, syms, D, NP, nstim, max_dense=8):
         NE, e_src = NB, list(range(NB))
     out.append("struct RhsUserCol {")
     out.append("    static constexpr int NP = %d, D = %d, NSTIM = %d, NB = %d, NE = %d, NG = %d;" % (NP, D, nstim, NB, NE, NB))
-    out.append("    static constexpr bool USES_T = %s, UNIFORM = %s;" % ("true" if uses_t else "false", "true" if uniform else "false"))
+    # rows of an edge tile that do not exist are evaluated at x = 0 with a zero adjoint: their products are exact
+    # zeros on their own when every expression is polynomial in x; otherwise (1/x, log x ...) the kernel selects
+    poly = all(e.is_polynomial(*xs) for e in exprs)
+    out.append("    static constexpr bool USES_T = %s, UNIFORM = %s, GUARD_EDGE = %s;"
+               % ("true" if uses_t else "false", "true" if uniform else "false", "false" if poly else "true"))
     chain = lambda vals: " : ".join(["k == %d ? %s" % (k, v) for k, v in enumerate(vals[:-1])] + [str(vals[-1])]) if len(vals) > 1 else str(vals[0])
     out.append("    static VA_HD constexpr int nb_off(int k) { return %s; }" % chain(offs))
     out.append("    static VA_HD constexpr int g_e(int k) { return %s; }" % chain(slot_of))
@@ -344,6 +353,76 @@ def column_form(exprs, syms, D, NP, nstim, max_dense=8):
     return dict(text="\n".join(out), uniform=uniform, offsets=offs, NE=NE, NB=NB)
 
 
+def ghost_form(exprs, syms, D, NP, nstim):
+    """A translation-invariant, autonomous stencil in the ghosted column form of the workgroup column-run
+    kernel (csrc/va_tile3.h, k_eval3: wide states), or None.  A lane owns one column of rows staged with
+    GHOST cyclic ghost columns on each side: f reads xc[off], and the adjoint is the GATHER
+    (J^T s)_j = sum_off s_{j-off} (df_0/dx_off shifted to row j-off), which reads s and x up to
+    max |k - off| columns away -- that, rounded up to even, is GHOST (at most 4)."""
+    sp = _sympy()
+    xs, ps = list(syms["x"]), list(syms["p"])
+    if nstim > 0 or any(e.has(syms["t"]) for e in exprs) or D < 8:
+        return None
+
+    def shifted(e, i):
+        return e.xreplace({xs[j]: xs[(j + i) % D] for j in range(D)})
+    if not all(sp.simplify(shifted(exprs[0], i) - exprs[i]) == 0 for i in range(1, D)):
+        return None
+    rel = lambda j: ((j + D // 2) % D) - D // 2
+    f0 = exprs[0]
+    used = sorted(rel(j) for j in range(D) if f0.has(xs[j]))
+    need = max([abs(o) for o in used] + [0])
+    terms = []                                  # (off, derivative as an expression in x_k, k relative to column 0)
+    for o in used:
+        dk = sp.diff(f0, xs[o % D])
+        if dk == 0:
+            continue
+        ks = [rel(j) for j in range(D) if dk.has(xs[j])]
+        need = max([need, abs(o)] + [abs(k - o) for k in ks])
+        terms.append((o, dk))
+    G = need + (need & 1)
+    if G < 2:
+        G = 2
+    if G > 4 or 2 * G >= D:
+        return None
+    base = _printer().__class__
+
+    def printer(shift, own="xi"):
+        class P(base):
+            def _print_Symbol(self, sym):
+                if sym in xs:
+                    k = rel(xs.index(sym)) - shift
+                    return own if (k == 0 and shift == 0) else "xc[%d]" % k
+                return base._print_Symbol(self, sym)
+        return P()
+    out = ["struct RhsUserG {",
+           "    static constexpr int NP = %d, D = %d, GHOST = %d;" % (NP, D, G),
+           "    static VA_HD double f(const double *xc, double xi, const double *p)",
+           "    {",
+           "        (void)xc; (void)xi; (void)p; double r;",
+           "        " + _emit_case(printer(0), f0, "r = %s;"),
+           "        return r;",
+           "    }",
+           "    static VA_HD double vjp(const double *xc, const double *sc, double s_own, const double *p)",
+           "    {",
+           "        (void)xc; (void)sc; (void)s_own; (void)p; double r = 0.0;"]
+    for o, dk in terms:
+        sname = "s_own" if o == 0 else "sc[%d]" % (-o)
+        # row i = j - off: its x_k sits at column k + i = j + (k - off)
+        pr = printer(o, "xc[0]")
+        out.append("        { %s }" % _emit_case(pr, sp.Symbol("SADJ") * dk, "r += %s;").replace("SADJ", sname))
+    out += ["        return r;", "    }",
+            "    static VA_HD void pgrad(const double *xc, double xi, double s_own, const double *p, double *acc)",
+            "    {",
+            "        (void)xc; (void)xi; (void)s_own; (void)p; (void)acc;"]
+    for k in range(NP):
+        dk = sp.diff(f0, ps[k])
+        if dk != 0:
+            out.append("        { %s }" % _emit_case(printer(0), sp.Symbol("SADJ") * dk, "acc[%d] += %%s;" % k).replace("SADJ", "s_own"))
+    out += ["    }", "};"]
+    return dict(text="\n".join(out), GHOST=G, offsets=used)
+
+
 def check_against(f, exprs, syms, D, NP, nstim, stim_ndim=1, trials=3, rtol=1e-10, p_rows=False):
     """The traced expressions must reproduce `f` on random numeric slices."""
     sp = _sympy()
@@ -370,7 +449,7 @@ def check_against(f, exprs, syms, D, NP, nstim, stim_ndim=1, trials=3, rtol=1e-1
 
 def _core_fingerprint():
     h = hashlib.sha1()
-    for fn in ("va_core.h", "va_device.h", "va_eval_flat.h", "va_eval4.h", "va_epilogue.h", "va_tile2.h", "va_tile3.h",
+    for fn in ("va_core.h", "va_device.h", "va_eval_flat.h", "va_eval3.h", "va_eval4.h", "va_epilogue.h", "va_tile2.h", "va_tile3.h",
                "va_tile4.h", "va_user_rhs.hip"):
         with open(os.path.join(CSRC, fn), "rb") as fh:
             h.update(fh.read())
@@ -379,12 +458,13 @@ def _core_fingerprint():
 
 def build_module(header_text, verbose=False, col_variant=None, compile=True):
     """Write the header, compile the module for gfx950 (cached by content).  Returns (so, header).
-    col_variant = (disc, K, w_scalar): the ONE instantiation of the column-run kernel to compile in
-    (models with a column form; csrc/va_user_rhs.hip)."""
+    col_variant = (eval kernel 3 | 4, disc, K, w): the ONE instantiation of a column-run kernel to compile in
+    (models with a column / ghosted form; csrc/va_user_rhs.hip)."""
     os.makedirs(CACHE, exist_ok=True)
     defs = []
     if col_variant is not None:
-        defs = ["-DVA_USER_DISC=%d" % col_variant[0], "-DVA_USER_K=%d" % col_variant[1], "-DVA_USER_WS=%d" % col_variant[2]]
+        defs = ["-DVA_USER_EK=%d" % col_variant[0], "-DVA_USER_DISC=%d" % col_variant[1], "-DVA_USER_K=%d" % col_variant[2],
+                "-DVA_USER_W=%d" % col_variant[3]]
     key = hashlib.sha1((header_text + _core_fingerprint() + " ".join(defs)).encode()).hexdigest()[:16]
     hdr = os.path.join(CACHE, "rhs_%s.h" % key)
     so = os.path.join(CACHE, "libva_rhs_%s.so" % key)
@@ -415,19 +495,23 @@ def build_module(header_text, verbose=False, col_variant=None, compile=True):
 
 def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False, p_rows=False, col_variant=None, compile=True):
     """trace + check + generate + build.  Returns dict(so=, header=, exprs=, col=).
-    col_variant: None, or a callable NE -> (disc, K, w_scalar) or None naming the instantiation of the
-    column-run kernel to compile for a model that has a column form."""
+    col_variant: None, or a callable (NE, GHOST) -> (eval kernel 3 | 4, disc, K, w) or None (as
+    _capi.eval_plan returns it) naming the instantiation of a column-run kernel to compile for a model that has
+    a column form (NE products per element; 0 = none) and / or a ghosted form (GHOST columns; 0 = none)."""
     if NP > MAX_NP:
         raise NotImplementedError("right-hand sides with more than %d parameters" % MAX_NP)
     exprs, syms = trace(f, D, NP, nstim, stim_ndim, p_rows)
     check_against(f, exprs, syms, D, NP, nstim, stim_ndim, p_rows=p_rows)
-    col = None
+    col = ghost = None
     variant = None
     if col_variant is not None and not p_rows:
         col = column_form(exprs, syms, D, NP, nstim)
-        variant = col_variant(col["NE"]) if col is not None else None
-        if variant is None:
+        ghost = ghost_form(exprs, syms, D, NP, nstim)
+        variant = col_variant(col["NE"] if col else 0, ghost["GHOST"] if ghost else 0) if (col or ghost) else None
+        if variant is None or variant[0] != 4:
             col = None
-    text = generate_header(exprs, syms, D, NP, nstim, getattr(f, "__name__", "f"), col=col)
+        if variant is None or variant[0] != 3:
+            ghost = None
+    text = generate_header(exprs, syms, D, NP, nstim, getattr(f, "__name__", "f"), col=col, ghost=ghost)
     so, hdr = build_module(text, verbose, variant, compile)
-    return dict(so=so, header=hdr, exprs=exprs, text=text, col=col, col_variant=variant)
+    return dict(so=so, header=hdr, exprs=exprs, text=text, col=col, ghost=ghost, col_variant=variant)

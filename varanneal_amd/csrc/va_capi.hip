@@ -48,10 +48,11 @@ int fail(int code, const char *fmt, ...)
 
 // generated right-hand-side modules (va_rhs_load_module); ids are VA_RHS_USER_BASE + index
 struct UserRhs {
-    // the model's column form on k_eval4, when the module carries one: (has, DISC, K, W_SCALAR, NE)
-    int col[5] = {0, 0, 0, 0, 0};
-    void (*launch4)(const Dev *, void *) = nullptr;
-    int (*prepare4)(const Dev *) = nullptr;
+    // the ONE column-run instantiation the module carries besides its flat kernel, if any (va_user_rhs.hip):
+    // (eval kernel 0 / 3 / 4, DISC, K, W_SCALAR [4] or threads [3], NE [4], GHOST [3])
+    int var[6] = {0, 0, 0, 0, 0, 0};
+    void (*launch_var)(const Dev *, void *) = nullptr;
+    int (*prepare_var)(const Dev *) = nullptr;
     std::string path;
     void *dl = nullptr;
     void (*launch)(const Dev *, void *) = nullptr;
@@ -117,10 +118,13 @@ void run_eval(va_handle h, int epi)
 
 // Tile geometry of the eval kernel: which mapping, rows per workgroup, threads.
 // ne: products per element of the model's column form (RhsL96s::NE for the built-in; a generated
-// module's RhsUserCol::NE), or 0 when the model only exists in the flat kernel's form.
-void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne)
+// module's RhsUserCol::NE), or 0 when the model has none; ghost: ghost columns per side of its ghosted
+// form for the workgroup column-run kernel (RhsL96g::GHOST; a module's RhsUserG::GHOST), or 0.  A model
+// with neither runs the flat kernel.
+void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, int ghost)
 {
-    bool user_rhs = ne <= 0;
+    bool user_rhs = ne <= 0 && ghost <= 0;
+    dm.ghost = ghost > 0 ? ghost : 2;
     user_rhs = user_rhs || d->p_time_dependent || d->rm_kind == 2 || d->rf_kind == 2;   // per-row parameters / full RM or RF matrices: flat kernel only
     user_rhs = user_rhs || (d->lower && d->upper);                   // box bounds: the flat kernel carries the clamp / projected gradient
     const int D = d->D, N = d->N_model;
@@ -130,9 +134,10 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne)
     // auto: wave-private column runs for narrow states that fill a wave, workgroup column runs up
     // to 1024 columns, flat mapping beyond
     if (dm.emode == 2) dm.emode = 3;                      // (the row-strided kernel of round 1 is gone)
-    if (dm.emode < 1 || dm.emode > 4) dm.emode = tile4_ok(D) ? 4 : ((D <= 1024) ? 3 : 1);
+    if (dm.emode < 1 || dm.emode > 4) dm.emode = (tile4_ok(D) && ne > 0) ? 4 : ((D <= 1024 && ghost > 0) ? 3 : 1);
     if (user_rhs) dm.emode = 1;                           // no column form (or a case only the flat kernel carries)
-    if (dm.emode == 4 && !tile4_ok(D)) dm.emode = 3;
+    if (dm.emode == 4 && (!tile4_ok(D) || ne <= 0)) dm.emode = 3;
+    if (dm.emode == 3 && ghost <= 0) dm.emode = 1;
     if (dm.emode == 3 && D > 1024) dm.emode = 1;          // column runs: a lane per column
     int tmin, tmax;
     if (dm.emode == 4) {
@@ -170,7 +175,7 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne)
             dm.ntiles = (N + dm.T - 1) / dm.T;
             return;
         }
-        dm.emode = 3;
+        dm.emode = ghost > 0 ? 3 : 1;
     }
     if (dm.emode == 3) {
         // column-run kernel: T = RY*K exactly, K rows per lane in {4, 6, 8}
@@ -200,7 +205,7 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne)
         if (D > 64 && d->tile_rows <= 0 && (long)d->batch * ((N + dm.RY * 8 - 1) / (dm.RY * 8)) >= 256)
             K = 8;                                         // few lanes per column: long runs keep the halo share down
         for (;;) {                                        // shrink until the staging arrays fit in LDS
-            const size_t elems = (size_t)tile3_stage_elems(K, D, 2, dm.RY, HLR) + tile3_s_elems(K, D, 2, dm.RY);
+            const size_t elems = (size_t)tile3_stage_elems(K, D, dm.ghost, dm.RY, HLR) + tile3_s_elems(K, D, dm.ghost, dm.RY);
             if (sizeof(double) * elems <= (D <= 64 ? 60 : (D <= 512 ? 78 : 150)) * 1024 || K <= 4) break;   // two groups per CU (one beyond D = 512)
             K -= (sh || K == 5) ? (K == 5 ? 1 : 2) : 1;  // Simpson-Hermite keeps K even; never below 4
         }
@@ -428,18 +433,18 @@ int va_device_count(int32_t *count)
     return VA_OK;
 }
 
-int va_eval4_plan(const va_problem_desc *d, int32_t ne, int32_t *out)
+int va_eval_plan(const va_problem_desc *d, int32_t ne, int32_t ghost, int32_t *out)
 {
     if (!d || !out) return fail(VA_EINVAL, "null argument");
     if (d->struct_size != (int32_t)sizeof(va_problem_desc)) return fail(VA_EINVAL, "struct_size %d != %zu", d->struct_size, sizeof(va_problem_desc));
     out[0] = out[1] = out[2] = out[3] = 0;
-    if (ne <= 0 || d->D < 1 || d->N_model < 2 || d->batch < 1) return VA_OK;
+    if ((ne <= 0 && ghost <= 0) || d->D < 1 || d->N_model < 2 || d->batch < 1) return VA_OK;
     Dims dm{};
     Geo4 g4{};
-    pick_eval_geometry(d, dm, g4, ne);
-    if (dm.emode != 4) return VA_OK;
-    out[0] = 1; out[1] = d->disc; out[2] = dm.maxr;
-    out[3] = (d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1) ? 1 : 0;
+    pick_eval_geometry(d, dm, g4, ne, ghost);
+    if (dm.emode != 3 && dm.emode != 4) return VA_OK;
+    out[0] = dm.emode; out[1] = d->disc; out[2] = dm.maxr;
+    out[3] = dm.emode == 4 ? ((d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1) ? 1 : 0) : dm.NT;
     return VA_OK;
 }
 
@@ -466,11 +471,11 @@ int va_rhs_load_module(const char *path, int32_t *rhs_id)
     }
     if (v[0] < 0 || v[0] > RHS_MAX_NP) { dlclose(u.dl); return fail(VA_EUNSUPPORTED, "%s: NP=%d > %d", path, v[0], RHS_MAX_NP); }
     u.NP = v[0]; u.D = v[1]; u.NSTIM = v[2];
-    if (info_fn cinfo = (info_fn)dlsym(u.dl, "va_user_col_info")) {
-        cinfo(u.col);
-        u.launch4 = (void (*)(const Dev *, void *))dlsym(u.dl, "va_user_launch_eval4");
-        u.prepare4 = (int (*)(const Dev *))dlsym(u.dl, "va_user_prepare_eval4");
-        if (!u.launch4 || !u.prepare4) u.col[0] = 0;
+    if (info_fn vinfo = (info_fn)dlsym(u.dl, "va_user_variant_info")) {
+        vinfo(u.var);
+        u.launch_var = (void (*)(const Dev *, void *))dlsym(u.dl, "va_user_launch_variant");
+        u.prepare_var = (int (*)(const Dev *))dlsym(u.dl, "va_user_prepare_variant");
+        if (!u.launch_var || !u.prepare_var) u.var[0] = 0;
     }
     g_user_rhs.push_back(u);
     *rhs_id = VA_RHS_USER_BASE + (int32_t)g_user_rhs.size() - 1;
@@ -554,16 +559,17 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dm.bounded = (d->lower && d->upper) ? 1 : 0;
     if (tdp) { dm.ND = dm.N * (dm.D + dm.NPe); dm.NP = 0; dm.NPest = 0; }   // one flat run for the L-BFGS kernels
     dm.ld = ((dm.ND + dm.NPest + 15) / 16) * 16;
-    pick_eval_geometry(d, dm, dv.g4, user ? (user->col[0] ? user->col[4] : 0) : RhsL96s::NE);
-    if (user && dm.emode == 4) {
-        // the module holds ONE instantiation of the column-run kernel (va_eval4_plan named it when the
-        // module was generated); any other geometry runs the module's flat kernel
+    if (!user) pick_eval_geometry(d, dm, dv.g4, RhsL96s::NE, RhsL96g::GHOST);
+    else {
+        // the module holds ONE instantiation of a column-run kernel (va_eval_plan named it when the module
+        // was generated); a problem that calls for any other geometry runs the module's flat kernel
+        const int *v = user->var;
+        pick_eval_geometry(d, dm, dv.g4, v[0] == 4 ? v[4] : 0, v[0] == 3 ? v[5] : 0);
         const bool ws = d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1;
-        if (user->col[1] == d->disc && user->col[2] == dm.maxr && (user->col[3] != 0) == ws) {
-            h->user_launch = user->launch4; h->user_prepare = user->prepare4;
-        } else {
-            pick_eval_geometry(d, dm, dv.g4, 0);
-        }
+        const bool fits = dm.emode == v[0] && v[1] == d->disc && v[2] == dm.maxr &&
+                          (dm.emode == 4 ? (v[3] != 0) == ws : v[3] == dm.NT);
+        if (dm.emode != 1 && fits) { h->user_launch = user->launch_var; h->user_prepare = user->prepare_var; }
+        else if (dm.emode != 1) pick_eval_geometry(d, dm, dv.g4, 0, 0);
     }
     if (dm.emode == 4 && (unsigned long long)dm.B * dm.ntiles * dm.ntiles >= (1ull << 32)) {
         va_problem_destroy(h);        // (umulhi by ntiles_magic would no longer be an exact division)

@@ -54,6 +54,7 @@ enum { DP_GD = 0, DP_DD = 1, DP_STPMX = 2, DP_N = 3 };   // g.d, d.d, largest st
 
 struct Dims {
     int D, N, ND, ld, L, N_data, nskip, NP, NPest, T, ntiles, B, m, disc, nchunks, chunk;
+    int ghost;                 // column-run kernel (emode 3): ghost columns per side = RHS::GHOST (2 for Lorenz-96)
     int emode, RY, NT, maxr;   // eval kernel: 1 = flat-mapped, 3 = column-run (va_tile3.h), 4 = wave-private column runs (va_tile4.h)
     unsigned long long obsmask; // bit i set <=> state column i is observed (D <= 64; Lidx ascending on the device)
     int nprow;                 // eval partial rows per seed (ntiles, or ntiles*4 when every wave writes its own)

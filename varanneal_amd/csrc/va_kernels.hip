@@ -21,124 +21,10 @@
 // here is GEMM-shaped, so no MFMA (the network action in va_nnet.hip is, and uses it).
 #include "va_device.h"
 #include "va_eval_flat.h"
+#include "va_eval3.h"
 #include "va_eval4.h"
 
 namespace va {
-
-// ------------------------------------------------------------------ K1 (wide states): column-run
-template <class RHS, int DISC, int K, int DC, int NTMAX>
-__global__ __launch_bounds__(NTMAX) void k_eval3(const Dev dv)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const Dims &dm = dv.dm;
-    const int nwork = dm.B * dm.ntiles;
-    const int w = xcd_swizzle(blockIdx.x, nwork);
-    if (w >= nwork) return;
-    const int b = w / dm.ntiles, tile = w - b * dm.ntiles;
-
-    constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, G = RHS::GHOST;
-    constexpr int KP = EP_GP + RHS::NP;
-    // staged double2 per lane = ceil(R / RP), RP = 2*NT/D rows per pass
-    constexpr int DCs = DC > 0 ? DC : 2;
-    constexpr int RPc = 2 * tile3_threads(DCs) / DCs;
-    constexpr int NS = DC > 0 ? (tile3_RY(DCs) * K + HL + HR + RPc - 1) / RPc : tile3_ns_runtime(K);
-    // with D fixed at compile time the whole tile geometry (and every LDS offset) is constant
-    const int D = DC > 0 ? DC : dm.D;
-    const int RY = DC > 0 ? tile3_RY(DC > 0 ? DC : 1) : dm.RY;
-    const int T = RY * K;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int n0 = tile * T;
-    const bool edge = (n0 - HL < 0) || (n0 + T + HR > dm.N);          // workgroup-uniform
-    const bool evenD = (D & 1) == 0;
-    const double *xg = dv.x + (size_t)b * dm.ld;
-
-    // phase A step 1: x loads in flight before anything else is waited for
-    double xr[NS][2];
-    if (evenD) {
-        if (edge) tile3_stage_load<DISC, K, DC, true, NS>(dm, n0, xg, tid, nt, xr);
-        else tile3_stage_load<DISC, K, DC, false, NS>(dm, n0, xg, tid, nt, xr);
-    }
-
-    const SeedState &st = dv.st[b];
-    const int phase = st.phase;
-    if (phase != PH_START && phase != PH_LS) return;
-
-    const int ty = tid / D, tx = tid - ty * D;
-    const bool active = ty < RY;
-    const int SE = tile3_stage_elems(K, D, G, RY, HL + HR);
-    Tile3 t;
-    t.n0 = n0; t.ty = ty; t.tx = tx; t.r0 = n0 + ty * K; t.use_d = (phase == PH_LS);
-    t.l = active ? dv.pp.lmap[tx] : -1;      // the position in Lidx (which may come in any order), not a rank
-    t.stp = st.stp; t.c = 2.0 * st.rf_scale * dm.cfe;
-    t.xs = smem; t.ss = smem + SE;
-    t.xg = xg; t.dg = dv.d + (size_t)b * dm.ld;
-    t.gtg = dv.gt + (size_t)b * dm.ld;
-    {   // parameters (same select-chain as tile2_params)
-#pragma unroll
-        for (int k = 0; k < RHS::NP; ++k) t.p[k] = dv.pp.Pfull[(size_t)b * dm.NP + k];
-        for (int k = 0; k < dm.NPest; ++k) {
-            double v = t.xg[dm.ND + k];
-            if (t.use_d) v = trial(v, t.stp, t.dg[dm.ND + k]);
-            const int dst = dv.pp.Pidx[k];
-#pragma unroll
-            for (int j = 0; j < RHS::NP; ++j) t.p[j] = (dst == j) ? v : t.p[j];
-        }
-    }
-    T3Regs<K> rg;
-    ThreadAcc acc;
-    acc.clear();
-    // observations / own d entries: early (under the staging latency) when registers allow it;
-    // the 512/1024-thread variants need their groups at <= 128 VGPRs and would spill them across phase B
-    constexpr bool EARLY_OBS = NTMAX <= 256;
-    if (EARLY_OBS && active) tile3_obs<K>(dm, dv.pp, t, rg);
-    // phase A step 2: (+ d for a line-search point) -> LDS incl. ghost columns
-    if (evenD) {
-        if (edge) {
-            if (t.use_d) tile3_stage_store<RHS, DISC, K, DC, true, true, NS>(dm, t, tid, nt, xr);
-            else tile3_stage_store<RHS, DISC, K, DC, true, false, NS>(dm, t, tid, nt, xr);
-        } else {
-            if (t.use_d) tile3_stage_store<RHS, DISC, K, DC, false, true, NS>(dm, t, tid, nt, xr);
-            else tile3_stage_store<RHS, DISC, K, DC, false, false, NS>(dm, t, tid, nt, xr);
-        }
-    } else {
-        if (t.use_d) tile3_stage_odd<RHS, DISC, K, DC, true, true>(dm, t, tid, nt);
-        else tile3_stage_odd<RHS, DISC, K, DC, true, false>(dm, t, tid, nt);
-    }
-    __syncthreads();
-    if (active) {
-        if (edge) tile3_rows<RHS, DISC, K, true, DC>(dm, dv.pp, t, rg, acc);
-        else tile3_rows<RHS, DISC, K, false, DC>(dm, dv.pp, t, rg, acc);
-    }
-    __syncthreads();
-    if (!EARLY_OBS && active) tile3_obs<K>(dm, dv.pp, t, rg);
-    if (active) {
-        if (edge) tile3_grad<RHS, DISC, K, true, DC>(dm, t, rg, acc);
-        else tile3_grad<RHS, DISC, K, false, DC>(dm, t, rg, acc);
-    }
-
-    // every wave writes its own partial row (no workgroup barrier: a __syncthreads here would
-    // also wait for the gradient stores to land).  Rows of 16 lanes reduce through DPP moves (no
-    // LDS latency); the four row totals of each value meet in a wave-private LDS strip, and
-    // lane k finishes value k.
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *prow = dv.evp + (((size_t)b * dm.ntiles + tile) * (nt >> 6) + wave) * EP_N;
-    double *strip = smem + SE + tile3_s_elems(K, D, G, RY) + wave * 64;      // [4 rows][8 values]; 512 B per wave
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-        const double r = (k == EP_GMAX) ? row16_reduce<true>(acc.v[k]) : row16_reduce<false>(acc.v[k]);
-        if ((lane & 15) == 0) strip[(lane >> 4) * 8 + k] = r;
-    }
-    wave_sync_lds();
-    if (lane < KP) {
-        const double r0 = strip[lane], r1 = strip[8 + lane], r2 = strip[16 + lane], r3 = strip[24 + lane];
-        st_sc1(prow + lane, (lane == EP_GMAX) ? fmax(fmax(r0, r1), fmax(r2, r3)) : ((r0 + r1) + r2) + r3);
-    }
-    if (dv.epi == EPI_NONE) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wave == 0 && arrive_last(dv.cnt_eval + (size_t)b * CNT_STRIDE, (unsigned)dm.ntiles, lane))
-        eval_epilogue<true>(dv, b, lane, reinterpret_cast<SeedHot *>(strip), dv.epi);
-}
 
 size_t eval_lds_bytes(const Dev &dv)
 {
@@ -146,7 +32,7 @@ size_t eval_lds_bytes(const Dev &dv)
     if (dm.emode == 4) return sizeof(double) * (size_t)dv.g4.NW * dv.g4.WAVE;
     if (dm.emode == 1) return eval_flat_lds_bytes(dm);
     const int HL = dm.disc == DISC_SH ? 2 : 1;
-    const size_t elems = (size_t)tile3_stage_elems(dm.maxr, dm.D, 2, dm.RY, HL + 1) + tile3_s_elems(dm.maxr, dm.D, 2, dm.RY);
+    const size_t elems = (size_t)tile3_stage_elems(dm.maxr, dm.D, dm.ghost, dm.RY, HL + 1) + tile3_s_elems(dm.maxr, dm.D, dm.ghost, dm.RY);
     return sizeof(double) * (elems + (size_t)(dm.NT / 64) * 64);
 }
 

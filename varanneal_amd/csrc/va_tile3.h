@@ -44,7 +44,7 @@ struct RhsL96g {
     {
         return sc[1] * (xc[2] - xc[-1]) + sc[-1] * xc[-2] - sc[2] * xc[1] - s_own;
     }
-    static VA_HD void pgrad(double s_own, double *acc) { acc[0] += s_own; }
+    static VA_HD void pgrad(const double *, double, double s_own, const double *, double *acc) { acc[0] += s_own; }
 };
 
 template <int K> struct T3Regs {
@@ -376,7 +376,7 @@ VA_HD void tile3_grad(const Dims &dm, const Tile3 &t, const T3Regs<K> &rg, Threa
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         double g = rg.direct[k] + RHS::vjp(xrun + k * DP, srun + k * DP, rg.sown[k], t.p);
-        RHS::pgrad(rg.sown[k], acc.v + EP_GP);
+        if (!EDGE || t.r0 + k < dm.N) RHS::pgrad(xrun + k * DP, rg.xown[k], rg.sown[k], t.p, acc.v + EP_GP);   // (a row that does not exist sits at x = 0)
         // measurement term: wv = 0 on unobserved entries, so no branch
         const double diff = rg.xown[k] - rg.yv[k];
         const double wd = rg.wv[k] * diff;

@@ -36,6 +36,7 @@ struct RhsL96s {
     static VA_HD constexpr int g_e(int t) { return t == 0 ? 0 : 1; }                   // which product
     static VA_HD constexpr int g_off(int t) { return t == 0 ? 1 : (t == 1 ? -1 : 2); } // sender column - own column
     static constexpr bool USES_T = false;              // autonomous: no model time, no stimulus
+    static constexpr bool GUARD_EDGE = false;          // polynomial in x: finite at the x = 0 of rows that do not exist
     static constexpr int NSTIM = 0;
     // (int col: the lane's state column -- unused by a translation-invariant right-hand side)
     static VA_HD double f(int, double x0, const double *xn, const double *p, double, const double *)
@@ -285,7 +286,7 @@ VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, cons
         const int rowk = t.r0 + k < N ? t.r0 + k : N - 1;
         const double *stk = RHS::NSTIM > 0 ? pp.stim + (size_t)rowk * pp.nstim : nullptr;
         RHS::scatter(t.tx, s, xo[j], xnb[k], t.p, tm[j], stk, e, diag);
-        if (EDGE) {
+        if (EDGE && RHS::GUARD_EDGE) {
             // a row that does not exist was evaluated at x = 0, where a right-hand side may be singular
             // (1/x, log x): its s = 0 does not make 0 * inf an exact zero, selects do
             const bool okk = t.r0 + k < N;

@@ -8,6 +8,7 @@
 // and registered through va_rhs_load_module().  The reference replays an ADOL-C tape of f
 // instead (_autodiffmin.py:32-58).
 #include "va_eval_flat.h"
+#include "va_eval3.h"
 #include "va_eval4.h"
 
 #ifndef VA_USER_RHS_HEADER
@@ -35,29 +36,46 @@ int va_user_prepare_eval(const va::Dev *dv)
     return (int)va::prepare_eval_rhs<va::RhsUser>(*dv);
 }
 
-// The model's column form (struct RhsUserCol: translation-invariant stencil, or a small dense system),
-// when the generator found one, on the wave-private column-run kernel -- ONE instantiation, for the
-// discretisation / run length / weight kind the module was built for (-DVA_USER_DISC/K/WS):
-// (has column form, DISC, K, W_SCALAR, products per element)
-#if defined(VA_USER_COL) && defined(VA_USER_K)
-#define VA_USER_COL_BUILT 1
+// Besides the flat kernel a module may carry ONE instantiation of a column-run kernel, named when the module
+// was generated (va_eval_plan; -DVA_USER_EK=3|4 -DVA_USER_DISC -DVA_USER_K -DVA_USER_W):
+//   EK = 4: the model's column form (struct RhsUserCol: a translation-invariant stencil, or a small dense
+//           system) on the wave-private kernel k_eval4; W = 1 for scalar weights
+//   EK = 3: a stencil's ghosted form (struct RhsUserG) on the workgroup kernel k_eval3; W = threads per workgroup
+// (eval kernel or 0, DISC, K, W, products per element [4], ghost columns [3])
+#if defined(VA_USER_EK) && VA_USER_EK == 4 && defined(VA_USER_COL)
+#define VA_USER_VARIANT 4
+#elif defined(VA_USER_EK) && VA_USER_EK == 3 && defined(VA_USER_GHOST)
+#define VA_USER_VARIANT 3
 #endif
-void va_user_col_info(int *out)
+void va_user_variant_info(int *out)
 {
-#ifdef VA_USER_COL_BUILT
-    out[0] = 1; out[1] = VA_USER_DISC; out[2] = VA_USER_K; out[3] = VA_USER_WS; out[4] = va::RhsUserCol::NE;
+    out[0] = out[1] = out[2] = out[3] = out[4] = out[5] = 0;
+#ifdef VA_USER_VARIANT
+    out[0] = VA_USER_VARIANT; out[1] = VA_USER_DISC; out[2] = VA_USER_K; out[3] = VA_USER_W;
+#if VA_USER_VARIANT == 4
+    out[4] = va::RhsUserCol::NE;
 #else
-    out[0] = 0; out[1] = out[2] = out[3] = out[4] = 0;
+    out[5] = va::RhsUserG::GHOST;
+#endif
 #endif
 }
-#ifdef VA_USER_COL_BUILT
-void va_user_launch_eval4(const va::Dev *dv, void *stream)
+#if defined(VA_USER_VARIANT) && VA_USER_VARIANT == 4
+void va_user_launch_variant(const va::Dev *dv, void *stream)
 {
-    va::launch_eval4_one<va::RhsUserCol, VA_USER_DISC, VA_USER_K, va::RhsUserCol::D, VA_USER_WS != 0>(*dv, (hipStream_t)stream);
+    va::launch_eval4_one<va::RhsUserCol, VA_USER_DISC, VA_USER_K, va::RhsUserCol::D, VA_USER_W != 0>(*dv, (hipStream_t)stream);
 }
-int va_user_prepare_eval4(const va::Dev *dv)
+int va_user_prepare_variant(const va::Dev *dv)
 {
-    return (int)va::prepare_eval4_one<va::RhsUserCol, VA_USER_DISC, VA_USER_K, va::RhsUserCol::D, VA_USER_WS != 0>(*dv);
+    return (int)va::prepare_eval4_one<va::RhsUserCol, VA_USER_DISC, VA_USER_K, va::RhsUserCol::D, VA_USER_W != 0>(*dv);
+}
+#elif defined(VA_USER_VARIANT)
+void va_user_launch_variant(const va::Dev *dv, void *stream)
+{
+    va::launch_eval3_one<va::RhsUserG, VA_USER_DISC, VA_USER_K, 0, VA_USER_W>(*dv, (hipStream_t)stream);
+}
+int va_user_prepare_variant(const va::Dev *dv)
+{
+    return (int)va::prepare_eval3_one<va::RhsUserG, VA_USER_DISC, VA_USER_K, 0, VA_USER_W>(*dv);
 }
 #endif
 

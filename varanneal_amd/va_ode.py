@@ -340,13 +340,14 @@ class Annealer(HIPmin):
 
         if rhs_id is None:
             # trace the callable, differentiate it, emit HIP, compile a module.  A model with a column form
-            # (codegen.column_form) also gets the ONE instantiation of the wave-private column-run kernel
-            # this problem's geometry calls for (va_eval4_plan), the same kernel the built-in Lorenz-96 runs on
+            # (codegen.column_form: stencils, small dense systems) or a ghosted form (codegen.ghost_form: wide
+            # stencils) also gets the ONE instantiation of the column-run kernel this problem's geometry calls
+            # for (va_eval_plan) -- the kernels the built-in Lorenz-96 runs on
             from . import codegen
             nstim = 0 if stim is None else (1 if stim.ndim == 1 else stim.shape[1])
 
-            def variant(ne):
-                return _capi.eval4_plan(self.B, self.D, self.N_model, disc, ne,
+            def variant(ne, ghost):
+                return _capi.eval_plan(self.B, self.D, self.N_model, disc, ne, ghost,
                                         rm_array=isinstance(self.RM, np.ndarray), rm_full=np.ndim(self.RM) == 3,
                                         rf_array=isinstance(self.RF0, np.ndarray), rf_full=np.ndim(self.RF0) == 3,
                                         merr_nskip=self.merr_nskip,
