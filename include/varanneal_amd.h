@@ -228,7 +228,8 @@ int va_gather_results(va_handle h, va_comm c, int32_t nbeta, double *table, int3
 enum { VA_ACT_SIGMOID = 0,   /* 1/(1+exp(-(W x + b))): examples/nnet_twin/nnet_twin_anneal.py:20-22 */
        VA_ACT_TANH = 1, VA_ACT_LINEAR = 2,
        VA_ACT_RELU = 3,      /* max(W x + b, 0) */
-       VA_ACT_SOFTPLUS = 4   /* log(1 + exp(W x + b)) */ };
+       VA_ACT_SOFTPLUS = 4,  /* log(1 + exp(W x + b)) */
+       VA_ACT_USER_BASE = 1000 /* ids >= this: generated activation modules (va_act_load_module) */ };
 
 typedef struct va_nnet_desc {
     int32_t struct_size;      /* = sizeof(va_nnet_desc)                                  */
@@ -247,12 +248,19 @@ typedef struct va_nnet_desc {
     int32_t NP, NPest;        /* all parameters / estimated ones                          */
     const int32_t *Pidx;      /* [NPest] indices into the flat parameter vector           */
     const double *P;          /* [batch][NP] initial/fixed values                         */
-    int32_t activation;       /* VA_ACT_*                                                 */
+    int32_t activation;       /* VA_ACT_* or an id from va_act_load_module                */
     int32_t lbfgs_m;          /* history pairs kept on the device (0 -> 10)               */
     int32_t max_beta;         /* longest ladder va_anneal will be given                   */
     int32_t keep_paths;       /* store every step's minimiser                             */
     void *stream;             /* hipStream_t to use, or NULL for a private one            */
+    const double *rm_in_matrix;  /* NULL, or [L_in][L_in]:  RM = [RMin, RMout] with full matrices,       */
+    const double *rm_out_matrix; /* NULL, or [L_out][L_out]: diff.(RM.diff) per example (va_nnet.py:136-139); both or neither */
 } va_nnet_desc;
+
+/* Register a compiled activation module (a shared object built from varanneal_amd/csrc/va_user_act.hip + a
+ * generated header: the elementwise g of a user layer map f(x, W, b) = g(W x + b), va_nnet.py:71, 260-264);
+ * returns the id to put in va_nnet_desc.activation. */
+int va_act_load_module(const char *path, int32_t *act_id);
 
 /* Everything va_nnet.Annealer.anneal_init() freezes (va_nnet.py:288-450). */
 int va_nnet_problem_create(const va_nnet_desc *desc, va_handle *out);

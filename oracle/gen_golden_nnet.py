@@ -86,6 +86,52 @@ def single_cases(vn):
     return out
 
 
+def swish(x, W, b):
+    """a layer map that is in nobody's registry: z * sigmoid(z) of z = W.x + b"""
+    z = np.dot(W, x) + b
+    return z / (1.0 + np.exp(-z))
+
+
+def extra_cases(vn):
+    """g11_*: a user-defined activation (the reference takes any callable, va_nnet.py:71) and full measurement
+    matrices RM = [RMin, RMout] (va_nnet.py:136-139; not symmetric on purpose)."""
+    out = {}
+    ACT_F["swish"] = swish
+
+    def run(name, structure, M, act, RM, Lidx, rf0, seed):
+        structure = np.asarray(structure, dtype=int)
+        din_full, dout_full, _ = twin.make_nnet_twin(structure, M)
+        Lidx = [np.asarray(Lidx[0], dtype=int), np.asarray(Lidx[1], dtype=int)]
+        din, dout = din_full[:, Lidx[0]], dout_full[:, Lidx[1]]
+        X0, P0, Pidx = twin.nnet_initial_guess(structure, M, seed, False)
+        a = ref_annealer(vn, structure, din, dout, act)
+        # (the reference reaches its matrix branch only for an array whose shape is not (2,): the two
+        # matrices must have the same size, i.e. as many observed inputs as outputs)
+        RMa = np.array(RM, dtype=np.float64)
+        a.anneal_init(X0, P0.copy(), 1.0, np.array([0]), RMa, rf0, Pidx, Lidx=Lidx,
+                      init_to_data=False, disc='forwardmap', method='L-BFGS-B')
+        XP = np.append(a.minpaths[0][:a.NDens], a.minpaths[0][a.NDens:][Pidx])
+        A = float(a.A(XP)); me = float(a.me_gaussian(XP)); fe = float(a.fe_gaussian(XP))
+        grad = _refload.complex_step_grad(a.A, XP)
+        rec = dict(structure=structure, M=M, act=act, din=din, dout=dout, Lin=Lidx[0], Lout=Lidx[1], RF0=rf0,
+                   rf_scale=1.0, P=P0, Pidx=np.asarray(Pidx, dtype=int), XP=XP, A=A, me=me, fe=fe, grad=grad)
+        if np.ndim(RM[0]) == 2:
+            rec["RMin"], rec["RMout"] = np.asarray(RM[0]), np.asarray(RM[1])
+        else:
+            rec["RM"] = np.asarray(RM, dtype=np.float64)
+        out[name] = rec
+        print("%-40s A=%.16e me=%.3e fe=%.3e |g|max=%.3e" % (name, A, me, fe, np.abs(grad).max()))
+
+    rng = np.random.RandomState(11)
+    run("g11_swish_ragged", [12, 7, 9, 5], 5, "swish", [3.0, 5.0], [[0, 1, 4, 7, 11], [0, 2, 3]], 0.02, 1)
+    Rin = 3.0 * np.eye(4) + 0.4 * rng.randn(4, 4); Rout = 5.0 * np.eye(4) + 0.4 * rng.randn(4, 4)
+    run("g11_matrix_rm_sigmoid", [12, 7, 9, 5], 5, "sigmoid", [Rin, Rout], [[0, 4, 7, 11], [0, 2, 3, 4]], 0.02, 2)
+    run("g11_matrix_rm_swish_wide", [40, 70, 6], 37, "swish", [4.0 * np.eye(6) + 0.2 * rng.randn(6, 6),
+                                                                 2.0 * np.eye(6) + 0.2 * rng.randn(6, 6)],
+        [np.arange(3, 40, 7), np.arange(6)], 0.1, 3)
+    return out
+
+
 def ladder_case(vn, name, structure, M, act, alpha, betas, seed=0):
     import adolc
     structure = np.asarray(structure, dtype=int)
@@ -135,6 +181,13 @@ def ladder_case(vn, name, structure, M, act, alpha, betas, seed=0):
 
 def main():
     vn = _refload.load_reference("va_nnet")
+    if "--only-extra" in sys.argv:
+        flat = {}
+        for c, rec in extra_cases(vn).items():
+            for k, v in rec.items():
+                flat["%s/%s" % (c, k)] = v
+        np.savez_compressed(os.path.join(GOLD, "nnet_extra.npz"), **flat)
+        return
     cases = single_cases(vn)
     # the example's ladder is alpha=1.1, beta=0..435; every 15th rung keeps the run short
     cases["g7_twin_ladder"] = ladder_case(vn, "g7_twin_ladder", twin.nnet_structure(20, 10, 10, 10), 2, "sigmoid",
@@ -148,6 +201,11 @@ def main():
     path = os.path.join(GOLD, "nnet.npz")
     np.savez_compressed(path, **flat)
     print("wrote", path, os.path.getsize(path))
+    flat = {}
+    for c, rec in extra_cases(vn).items():
+        for k, v in rec.items():
+            flat["%s/%s" % (c, k)] = v
+    np.savez_compressed(os.path.join(GOLD, "nnet_extra.npz"), **flat)
 
 
 if __name__ == "__main__":

@@ -50,12 +50,24 @@ class NnetProblem(object):
         return self.NDens + self.NPest
 
     def _rm(self):
+        """(RM_in, RM_out): scalars, or the two matrices of va_nnet.py:136-139 (diff . (RM . diff) per example)"""
         RM = self.RM
-        if isinstance(RM, np.ndarray) and RM.ndim > 0:
-            if RM.shape != (2,):
-                raise NotImplementedError("only scalar RM or [RM_in, RM_out]")
+        if isinstance(RM, (list, tuple)) or (isinstance(RM, np.ndarray) and RM.ndim > 0):
+            if np.ndim(RM[0]) == 2:
+                return np.asarray(RM[0], dtype=np.float64), np.asarray(RM[1], dtype=np.float64)
+            if np.shape(RM) != (2,):
+                raise NotImplementedError("RM: scalar, [RM_in, RM_out] or two matrices")
             return float(RM[0]), float(RM[1])
         return float(RM), float(RM)
+
+    def _acts(self):
+        """(g(z), g'(z) as a function of (a, z)): a built-in name or such a pair"""
+        return ACTS[self.act] if isinstance(self.act, str) else self.act
+
+    @staticmethod
+    def _quad(R, d):
+        """sum over examples of d_m . (R . d_m) for a matrix R, R * sum d^2 for a scalar"""
+        return np.sum(d * (d @ np.asarray(R).T)) if np.ndim(R) == 2 else R * np.sum(d * d)
 
     def _unpack(self, XP):
         XP = np.asarray(XP)
@@ -69,11 +81,11 @@ class NnetProblem(object):
         """(A, me, fe): vectorised over the M examples, otherwise the reference's arithmetic;
         accepts complex XP (complex-step differentiation)."""
         X, p = self._unpack(XP)
-        g, _ = ACTS[self.act]
+        g, _ = self._acts()
         rmi, rmo = self._rm()
         xin = X[:, :self.s[0]][:, self.Lin]
         xout = X[:, self.NDnet - self.s[-1]:][:, self.Lout]
-        me = (rmi * np.sum((xin - self.din) ** 2) + rmo * np.sum((xout - self.dout) ** 2)) / float(self.Ltot * self.M)
+        me = (self._quad(rmi, xin - self.din) + self._quad(rmo, xout - self.dout)) / float(self.Ltot * self.M)
         fe = 0.0
         for n in range(self.N - 1):
             W = p[self.woff[n]:self.boff[n]].reshape(self.s[n + 1], self.s[n])
@@ -88,16 +100,17 @@ class NnetProblem(object):
     def action_grad(self, XP, rf_scale=1.0):
         """(A, me, fe, grad) with the adjoint written out by hand (real XP only)."""
         X, p = self._unpack(np.asarray(XP, dtype=np.float64))
-        g, dg = ACTS[self.act]
+        g, dg = self._acts()
         rmi, rmo = self._rm()
         cme = 1.0 / float(self.Ltot * self.M)
         cfe = self.RF0 * rf_scale / float((self.NDnet - self.s[0]) * self.M)
         gX = np.zeros_like(X); gp = np.zeros(self.NP)
         din = X[:, :self.s[0]][:, self.Lin] - self.din
         dout = X[:, self.NDnet - self.s[-1]:][:, self.Lout] - self.dout
-        me = cme * (rmi * np.sum(din * din) + rmo * np.sum(dout * dout))
-        np.add.at(gX, (slice(None), self.Lin), 2.0 * cme * rmi * din)
-        np.add.at(gX, (slice(None), self.NDnet - self.s[-1] + self.Lout), 2.0 * cme * rmo * dout)
+        me = cme * (self._quad(rmi, din) + self._quad(rmo, dout))
+        dme = lambda R, d: d @ (np.asarray(R) + np.asarray(R).T) if np.ndim(R) == 2 else 2.0 * R * d
+        np.add.at(gX, (slice(None), self.Lin), cme * dme(rmi, din))
+        np.add.at(gX, (slice(None), self.NDnet - self.s[-1] + self.Lout), cme * dme(rmo, dout))
         fe = 0.0
         for n in range(self.N - 1):
             W = p[self.woff[n]:self.boff[n]].reshape(self.s[n + 1], self.s[n])

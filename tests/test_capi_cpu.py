@@ -125,8 +125,8 @@ def test_nnet_validation_without_gpu(capi):
     d, keep = desc()
     d.activation = 17
     assert lib.va_nnet_problem_create(C.byref(d), C.byref(h)) == -4          # VA_EUNSUPPORTED
-    with pytest.raises(NotImplementedError):
-        desc(RM=np.eye(3))
+    with pytest.raises(ValueError):
+        desc(RM=np.eye(3))                     # neither [RM_in, RM_out] nor two matrices of the observed sizes
     with pytest.raises(NotImplementedError):
         desc(act="sine")
     with pytest.raises(ValueError):

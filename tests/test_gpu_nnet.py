@@ -151,11 +151,18 @@ def test_stepwise_equals_fused_and_batch_independent(gold):
                           f._mp[1, 0, f.NDens:], Pidx, act="tanh")
     xo, Ao, sto, nito, nfevo = pbo.minimize_lbfgs(f._xp0(1)[1], float(f._rf_scale[1]), OPTS)
     print("small tanh ladder rung 1: device %.6e arbiter %.6e reference %.6e" % (f.A_array[1, 1], Ao, c["A_array"][1]))
-    # (three ~200-iteration runs of the same optimiser from the same point: measured 2.018944e-06 on the
-    # device, 2.018360e-06 in the reference's run, 2.023559e-06 for the arbiter -- the device has to
-    # be within 1e-3 of one of the two CPU end points)
+    # Recorded (rung 1, ~200 iterations along a flat valley; every run below stops by the same ftol rule):
+    #   reference's own run              2.018360e-06
+    #   device, round-2 builds           2.018944e-06, 2.022566e-06   (two builds that differ in FMA contraction only)
+    #   arbiter from the device's start  2.023559e-06, 3.027893e-06   (starts that differ in the last bits)
+    # i.e. last-bit changes of the start or of the summation order move the stopping point by up to 2.6e-3
+    # among the runs that reach the valley floor, and the arbiter itself once stopped 50 % higher.  What is
+    # asserted: the device stops on the valley floor -- within 5e-3 of the reference's end point -- and never
+    # above the worse of the two CPU end points.
     dev = f.A_array[1, 1]
-    assert sto == 0 and min(abs(dev - Ao) / Ao, abs(dev - c["A_array"][1]) / c["A_array"][1]) <= 1e-3, (dev, Ao, c["A_array"][1])
+    assert sto == 0, sto
+    assert abs(dev - c["A_array"][1]) <= 5e-3 * c["A_array"][1], (dev, Ao, c["A_array"][1])
+    assert dev <= max(Ao, c["A_array"][1]) * (1.0 + 1e-3), (dev, Ao, c["A_array"][1])
     for x in (f, st, one):
         x.close()
 

@@ -57,7 +57,8 @@ class NnetDesc(C.Structure):
                 ("data_in", c_dp), ("data_out", c_dp), ("rm_in", C.c_double), ("rm_out", C.c_double),
                 ("rf0", C.c_double), ("NP", C.c_int32), ("NPest", C.c_int32), ("Pidx", c_ip), ("P", c_dp),
                 ("activation", C.c_int32), ("lbfgs_m", C.c_int32), ("max_beta", C.c_int32),
-                ("keep_paths", C.c_int32), ("stream", C.c_void_p)]
+                ("keep_paths", C.c_int32), ("stream", C.c_void_p),
+                ("rm_in_matrix", c_dp), ("rm_out_matrix", c_dp)]
 
 
 ACTIVATION = {"sigmoid": 0, "tanh": 1, "linear": 2, "relu": 3, "softplus": 4}
@@ -183,6 +184,7 @@ def lib():
     L.va_problem_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(h)]
     L.va_nnet_problem_create.argtypes = [C.POINTER(NnetDesc), C.POINTER(h)]
     L.va_rhs_load_module.argtypes = [C.c_char_p, c_ip]
+    L.va_act_load_module.argtypes = [C.c_char_p, c_ip]
     L.va_eval_plan.argtypes = [C.POINTER(ProblemDesc), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     L.va_problem_destroy.argtypes = [h]
     L.va_problem_destroy.restype = None
@@ -205,7 +207,7 @@ def lib():
     L.va_read_eval_outputs.argtypes = [h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.va_debug_read_partials.argtypes = [h, c_dp, C.c_int64]
     L.va_problem_eval_kernel.argtypes = [h, c_ip, c_ip]
-    for fn in ("va_device_count", "va_rhs_load_module", "va_eval_plan", "va_problem_eval_kernel", "va_problem_create", "va_nnet_problem_create",
+    for fn in ("va_device_count", "va_rhs_load_module", "va_act_load_module", "va_eval_plan", "va_problem_eval_kernel", "va_problem_create", "va_nnet_problem_create",
                "va_problem_info", "va_action_grad",
                "va_minimize_lbfgs", "va_anneal", "va_get_minpath", "va_eval_timed",
                "va_get_counters", "va_debug_read_partials", "va_read_eval_outputs", "va_lbfgs_timed",
@@ -215,7 +217,7 @@ def lib():
     return L
 
 
-EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_eval_plan", "va_problem_eval_kernel", "va_problem_create",
+EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_act_load_module", "va_eval_plan", "va_problem_eval_kernel", "va_problem_create",
            "va_problem_destroy", "va_problem_info", "va_action_grad", "va_minimize_lbfgs",
            "va_anneal", "va_get_minpath", "va_eval_timed", "va_get_counters", "va_nnet_problem_create", "va_debug_read_partials",
            "va_read_eval_outputs", "va_lbfgs_timed", "va_comm_unique_id", "va_comm_create", "va_comm_destroy",
@@ -261,6 +263,19 @@ def load_rhs_module(path):
         check(lib().va_rhs_load_module(path.encode(), C.byref(rid)))
         _modules[path] = rid.value
     return _modules[path]
+
+
+_act_modules = {}
+
+
+def load_act_module(path):
+    """Register a generated activation module; returns its activation id (cached per path)."""
+    path = os.path.abspath(path)
+    if path not in _act_modules:
+        aid = C.c_int32()
+        check(lib().va_act_load_module(path.encode(), C.byref(aid)))
+        _act_modules[path] = aid.value
+    return _act_modules[path]
 
 
 class Comm(object):
@@ -426,15 +441,21 @@ def make_nnet_desc(batch, structure, data_in, data_out, Lidx, RM, RF0, P, Pidx, 
     if din.shape != (M, lin.size) or dout.shape != (M, lout.size):
         raise ValueError("data_in/data_out must have shapes (M, len(Lidx[0])) / (M, len(Lidx[1])), got %s / %s"
                          % (din.shape, dout.shape))
-    if isinstance(RM, (list, tuple, np.ndarray)) and np.ndim(RM) > 0:
+    rmm = None
+    if isinstance(RM, (list, tuple, np.ndarray)) and np.ndim(RM[0] if len(RM) else 0) == 2:
+        # [RMin, RMout] with full matrices (va_nnet.py:136-139)
+        rmm = (_f64(RM[0]), _f64(RM[1]))
+        if len(RM) != 2 or rmm[0].shape != (lin.size, lin.size) or rmm[1].shape != (lout.size, lout.size):
+            raise ValueError("matrix RM must be [RMin (Lin x Lin), RMout (Lout x Lout)]")
+        rm_in = rm_out = 0.0
+    elif isinstance(RM, (list, tuple, np.ndarray)) and np.ndim(RM) > 0:
         RM = np.asarray(RM, dtype=np.float64)
         if RM.shape != (2,):
-            raise NotImplementedError("RM must be a scalar or [RM_in, RM_out]; matrix RM (va_nnet.py:136-139) "
-                                      "is not supported")
+            raise ValueError("RM must be a scalar, [RM_in, RM_out] or two matrices (va_nnet.py:132-139)")
         rm_in, rm_out = float(RM[0]), float(RM[1])
     else:
         rm_in = rm_out = float(RM)
-    if act not in ACTIVATION:
+    if not isinstance(act, (int, np.integer)) and act not in ACTIVATION:      # int: an id from load_act_module
         raise NotImplementedError("activation %r is not built in (have %s)" % (act, sorted(ACTIVATION)))
     P = _f64(P)
     if P.ndim == 1:
@@ -449,9 +470,11 @@ def make_nnet_desc(batch, structure, data_in, data_out, Lidx, RM, RF0, P, Pidx, 
     d.rm_in, d.rm_out, d.rf0 = rm_in, rm_out, float(RF0)
     d.NP, d.NPest = P.shape[1], pidx.size
     d.Pidx = pidx.ctypes.data_as(c_ip); d.P = P.ctypes.data_as(c_dp)
-    d.activation = ACTIVATION[act]; d.lbfgs_m = lbfgs_m; d.max_beta = max_beta; d.keep_paths = keep_paths
+    d.activation = int(act) if isinstance(act, (int, np.integer)) else ACTIVATION[act]; d.lbfgs_m = lbfgs_m; d.max_beta = max_beta; d.keep_paths = keep_paths
     d.stream = stream
-    return d, (st, din, dout, lin, lout, P, pidx)
+    if rmm is not None:
+        d.rm_in_matrix = rmm[0].ctypes.data_as(c_dp); d.rm_out_matrix = rmm[1].ctypes.data_as(c_dp)
+    return d, (st, din, dout, lin, lout, P, pidx, rmm)
 
 
 class NnetProblem(Problem):

@@ -515,3 +515,89 @@ def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False, p_rows=False, col_
     text = generate_header(exprs, syms, D, NP, nstim, getattr(f, "__name__", "f"), col=col, ghost=ghost)
     so, hdr = build_module(text, verbose, variant, compile)
     return dict(so=so, header=hdr, exprs=exprs, text=text, col=col, ghost=ghost, col_variant=variant)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Activations of the network action (varanneal/va_nnet.py:71, 260-264: any callable f(x, W, b) is the layer map)
+# ---------------------------------------------------------------------------------------------------------
+def trace_activation(f):
+    """The elementwise g of a layer map f(x, W, b) = g(W.x + b), as a SymPy expression in `z`, with its
+    derivative.  Raises TypeError if `f` is not of that form (checked numerically on random W, x, b) or
+    branches on values."""
+    sp = _sympy()
+    z0, z1 = sp.symbols("z0 z1", real=True)
+    x = np.empty(2, dtype=object); x[0] = Sym(z0); x[1] = Sym(z1)
+    W = np.array([[1, 0], [0, 1]], dtype=object)
+    b = np.array([0, 0], dtype=object)
+    out = np.asarray(f(x, W, b), dtype=object)
+    if out.shape != (2,):
+        raise TypeError("activation returned shape %s for a 2-neuron layer" % (out.shape,))
+    g0, g1 = sp.sympify(Sym._u(out[0])), sp.sympify(Sym._u(out[1]))
+    if (g0.free_symbols - {z0}) or sp.simplify(g0.xreplace({z0: z1}) - g1) != 0:
+        raise TypeError("the layer map is not an elementwise function of W.x + b")
+    z = sp.Symbol("z", real=True)
+    g = g0.xreplace({z0: z})
+    dg = sp.diff(g, z)
+    gn = sp.lambdify(z, g, "numpy")
+    rng = np.random.RandomState(20260103)
+    for _ in range(3):
+        xv = rng.randn(5); Wv = rng.randn(4, 5); bv = rng.randn(4)
+        got = np.asarray(f(xv, Wv, bv), dtype=np.float64)
+        want = np.asarray(gn(np.dot(Wv, xv) + bv), dtype=np.float64)
+        if got.shape != (4,) or not np.allclose(got, want, rtol=1e-12, atol=1e-12):
+            raise TypeError("the layer map is not g(W.x + b) with an elementwise g")
+    return g, dg, z
+
+
+def activation_header(g, dg, z, name="act"):
+    base = _printer().__class__
+
+    class P(base):
+        def _print_Symbol(self, sym):
+            return "z" if sym == z else base._print_Symbol(self, sym)
+    pr = P()
+    out = ["// generated by varanneal_amd/codegen.py from the user's layer map `%s`: g(z) = %s" % (name, str(g)[:160]),
+           "#pragma once", "namespace va {", "struct ActUser {",
+           "    static __device__ __forceinline__ double f(double z)", "    {",
+           "        double r;", "        " + _emit_case(pr, g, "r = %s;"), "        return r;", "    }",
+           "    // f'(z); a = f(z) is at hand but not used by generated code",
+           "    static __device__ __forceinline__ double d(double z, double a)", "    {",
+           "        (void)a; double r;", "        " + _emit_case(pr, dg, "r = %s;"), "        return r;", "    }",
+           "};", "}  // namespace va"]
+    return "\n".join(out) + "\n"
+
+
+def _act_fingerprint():
+    h = hashlib.sha1()
+    for fn in ("va_core.h", "va_device.h", "va_eval_flat.h", "va_epilogue.h", "va_nnet.h", "va_nnet_kernels.h",
+               "va_user_act.hip"):
+        with open(os.path.join(CSRC, fn), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def activation_module_for(f, verbose=False):
+    """trace + generate + build an activation module.  Returns dict(so=, header=, g=, dg=, z=)."""
+    g, dg, z = trace_activation(f)
+    text = activation_header(g, dg, z, getattr(f, "__name__", "f"))
+    os.makedirs(CACHE, exist_ok=True)
+    key = hashlib.sha1((text + _act_fingerprint()).encode()).hexdigest()[:16]
+    hdr = os.path.join(CACHE, "act_%s.h" % key)
+    so = os.path.join(CACHE, "libva_act_%s.so" % key)
+    tag = ".%d.tmp" % os.getpid()
+    if not os.path.exists(hdr):
+        with open(hdr + tag, "w") as fh:
+            fh.write(text)
+        os.replace(hdr + tag, hdr)
+    if not os.path.exists(so):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function",
+               "-I", CSRC, '-DVA_USER_ACT_HEADER="%s"' % hdr, "-o", so + tag, os.path.join(CSRC, "va_user_act.hip")]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        try:
+            subprocess.check_call(cmd)
+            os.replace(so + tag, so)
+        finally:
+            if os.path.exists(so + tag):
+                os.remove(so + tag)
+    return dict(so=so, header=hdr, g=g, dg=dg, z=z, text=text)

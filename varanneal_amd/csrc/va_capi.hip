@@ -59,6 +59,12 @@ struct UserRhs {
     int (*prepare)(const Dev *) = nullptr;
     int NP = 0, D = 0, NSTIM = 0;
 };
+struct UserAct {
+    std::string path;
+    void *dl = nullptr;
+    NnetActLaunch launch = nullptr;
+};
+std::vector<UserAct> g_user_act;      // (guarded by g_user_rhs_mutex, like the right-hand-side registry)
 std::vector<UserRhs> g_user_rhs;
 std::mutex g_user_rhs_mutex;            // the registry is process-wide; handles are not shared
 
@@ -69,6 +75,7 @@ struct va_problem_s {
     int device = 0, rhs = 0, keep_paths = 0;
     void (*user_launch)(const Dev *, void *) = nullptr;
     int (*user_prepare)(const Dev *) = nullptr;
+    NnetActLaunch user_act = nullptr;  // generated activation module's launcher (nn.act >= NNET_USER)
     bool is_nnet = false;              // feed-forward-network action (va_nnet.hip) instead of an ODE path
     bool fold = false;                 // the evaluation kernel runs the tail itself (last arriver of each seed)
     NnetDev nn;
@@ -104,7 +111,7 @@ void run_eval(va_handle h, int epi)
         // (large grids: a workgroup that waits for its arrival to come back holds its LDS and wave
         // slots ~1 us longer, which costs more than the 64-wave tail kernel it saves)
         h->dv.epi = EPI_NONE;
-        if (h->is_nnet) launch_nnet_eval(h->dv, h->nn, h->stream);
+        if (h->is_nnet) launch_nnet_eval(h->dv, h->nn, h->stream, h->user_act);
         else if (h->user_launch) h->user_launch(&h->dv, (void *)h->stream);
         else launch_eval(h->dv, h->rhs, h->stream);
         if (epi == EPI_FINALIZE) launch_finalize_eval(h->dv, h->stream);
@@ -482,6 +489,31 @@ int va_rhs_load_module(const char *path, int32_t *rhs_id)
     return VA_OK;
 }
 
+int va_act_load_module(const char *path, int32_t *act_id)
+{
+    if (!path || !act_id) return fail(VA_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lock(g_user_rhs_mutex);
+    for (size_t i = 0; i < g_user_act.size(); ++i)
+        if (g_user_act[i].path == path) { *act_id = VA_ACT_USER_BASE + (int32_t)i; return VA_OK; }
+    UserAct u;
+    u.path = path;
+    u.dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!u.dl) return fail(VA_EINVAL, "dlopen(%s): %s", path, dlerror());
+    typedef void (*info_fn)(int *);
+    info_fn info = (info_fn)dlsym(u.dl, "va_user_act_info");
+    u.launch = (NnetActLaunch)dlsym(u.dl, "va_user_act_launch");
+    if (!info || !u.launch) { dlclose(u.dl); return fail(VA_EINVAL, "%s lacks va_user_act_info / va_user_act_launch", path); }
+    int v[3] = {0, 0, 0};
+    info(v);
+    if (v[0] != (int)sizeof(Dev) || v[1] != (int)sizeof(NnetDev) || v[2] != (int)sizeof(SeedState)) {
+        dlclose(u.dl);
+        return fail(VA_EINVAL, "%s was built against different headers: rebuild it", path);
+    }
+    g_user_act.push_back(u);
+    *act_id = VA_ACT_USER_BASE + (int32_t)g_user_act.size() - 1;
+    return VA_OK;
+}
+
 int va_problem_create(const va_problem_desc *d, va_handle *out)
 {
     if (!d || !out) return fail(VA_EINVAL, "null argument");
@@ -695,7 +727,13 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
     *out = nullptr;
     if (d->struct_size != (int32_t)sizeof(va_nnet_desc)) return fail(VA_EINVAL, "struct_size %d != %zu", d->struct_size, sizeof(va_nnet_desc));
     if (d->batch < 1 || d->n_layers < 2 || d->M < 1 || !d->structure) return fail(VA_EINVAL, "bad sizes (batch=%d n_layers=%d M=%d)", d->batch, d->n_layers, d->M);
-    if (d->activation < VA_ACT_SIGMOID || d->activation > VA_ACT_SOFTPLUS) return fail(VA_EUNSUPPORTED, "unknown activation %d", d->activation);
+    if ((d->rm_in_matrix != nullptr) != (d->rm_out_matrix != nullptr)) return fail(VA_EINVAL, "rm_in_matrix and rm_out_matrix come together");
+    NnetActLaunch user_act = nullptr;
+    if (d->activation >= VA_ACT_USER_BASE) {
+        std::lock_guard<std::mutex> lock(g_user_rhs_mutex);
+        if ((size_t)(d->activation - VA_ACT_USER_BASE) >= g_user_act.size()) return fail(VA_EINVAL, "activation module id %d was never registered", d->activation);
+        user_act = g_user_act[d->activation - VA_ACT_USER_BASE].launch;
+    } else if (d->activation < VA_ACT_SIGMOID || d->activation > VA_ACT_SOFTPLUS) return fail(VA_EUNSUPPORTED, "unknown activation %d", d->activation);
     const int NL = d->n_layers;
     std::vector<int> s(d->structure, d->structure + NL), off(NL + 1, 0), woff(NL - 1), boff(NL - 1);
     long long np = 0;
@@ -736,7 +774,7 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
     HIPCHK(hipSetDevice(d->device));
 
     va_handle h = new va_problem_s();
-    h->device = d->device; h->rhs = -1; h->keep_paths = d->keep_paths; h->is_nnet = true;
+    h->device = d->device; h->rhs = -1; h->keep_paths = d->keep_paths; h->is_nnet = true; h->user_act = user_act;
     if (d->stream) h->stream = (hipStream_t)d->stream;
     else {
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -828,6 +866,15 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
     if (!t3.empty()) H2D(t3_d, t3.data(), t3.size(), NnetTile);
     nn.s = s_d; nn.off = off_d; nn.woff = woff_d; nn.boff = boff_d; nn.lmap_in = lin_d; nn.lmap_out = lout_d;
     nn.pmap = pmap_d; nn.din = din_d; nn.dout = dout_d; nn.Pfix = P_d; nn.t1 = t1_d; nn.t2 = t2_d; nn.t3 = t3_d;
+    if (d->rm_in_matrix) {
+        // full measurement matrices (va_nnet.py:136-139): the kernels walk the layer's observed neurons
+        double *ri = nullptr, *ro = nullptr; int *li = nullptr, *lo = nullptr;
+        TRY(h->alloc(&ri, (size_t)d->L_in * d->L_in + 1)); TRY(h->alloc(&ro, (size_t)d->L_out * d->L_out + 1));
+        TRY(h->alloc(&li, d->L_in + 1)); TRY(h->alloc(&lo, d->L_out + 1));
+        if (d->L_in) { H2D(ri, d->rm_in_matrix, (size_t)d->L_in * d->L_in, double); H2D(li, d->Lidx_in, d->L_in, int); }
+        if (d->L_out) { H2D(ro, d->rm_out_matrix, (size_t)d->L_out * d->L_out, double); H2D(lo, d->Lidx_out, d->L_out, int); }
+        nn.rmm_in = ri; nn.rmm_out = ro; nn.lidx_in = li; nn.lidx_out = lo;
+    }
     TRY(finish_create(h));
 #undef TRY
 #undef H2D

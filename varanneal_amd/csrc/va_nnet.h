@@ -8,7 +8,8 @@
 
 namespace va {
 
-enum { NNET_SIGMOID = 0, NNET_TANH = 1, NNET_LINEAR = 2, NNET_RELU = 3, NNET_SOFTPLUS = 4 };
+enum { NNET_SIGMOID = 0, NNET_TANH = 1, NNET_LINEAR = 2, NNET_RELU = 3, NNET_SOFTPLUS = 4,
+       NNET_USER = 1000 };   // >= NNET_USER: a generated activation module (va_act_load_module)
 
 constexpr int NN_TILE = 64;      // workgroup output tile: 2 x 2 waves, each 2 x 2 MFMA blocks of 16x16
 constexpr int NN_KC = 32;        // K elements staged in LDS per step
@@ -25,6 +26,8 @@ struct NnetDev {
     int NL, M, NDnet, NDens, NP, NPest, act;
     int Lin, Lout;
     double rm_in, rm_out;          // measurement weights (va_nnet.py:132-147)
+    const double *rmm_in, *rmm_out; // NULL, or full matrices [Lin x Lin], [Lout x Lout]: diff . (RM . diff) per example (:136-139)
+    const int *lidx_in, *lidx_out; // [Lin], [Lout] observed neuron indices (matrix RM only)
     const int *s, *off;            // [NL] layer widths, [NL+1] offsets inside one example
     const int *woff, *boff;        // [NL-1] offsets of W_n (s[n+1] x s[n], row-major) and b_n in P
     const int *lmap_in, *lmap_out; // [s[0]], [s[NL-1]] -> observed index or -1
@@ -45,6 +48,9 @@ struct NnetDev {
     double *raw;                   // NULL (rows go straight to Dev::evp) or [B][nraw][EP_GP]
 };
 
-void launch_nnet_eval(const Dev &dv, const NnetDev &nn, hipStream_t s);
+// launches k_nnet_small (small != 0) or k_nnet_fwd of a generated activation module (va_user_act.hip)
+typedef void (*NnetActLaunch)(const Dev *, const NnetDev *, void *stream, int small);
+
+void launch_nnet_eval(const Dev &dv, const NnetDev &nn, hipStream_t s, NnetActLaunch user);
 
 }  // namespace va

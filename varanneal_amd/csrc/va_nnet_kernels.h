@@ -1,0 +1,659 @@
+// va_nnet_kernels.h -- action + gradient of the feed-forward-network model error
+// (reference: varanneal/va_nnet.py:111-255; activation examples/nnet_twin/nnet_twin_anneal.py:20-22).
+//
+// In the variational formulation every layer state of every training example is an unknown,
+// so the N-1 layer transitions are independent given X: there is no sequential forward pass.
+// With Z_n = X_n W_n^T + b_n (examples x neurons), a = act(Z_n), r = X_{n+1} - a,
+// q = 2 RF c r, delta = -q act'(Z_n):
+//     dA/dX_{n+1} += q                       (direct)
+//     dA/dX_n     += delta W_n               (product 2)
+//     dA/dW_n      = delta^T X_n,  dA/db_n = sum_m delta        (product 3)
+// Three float64 products per layer, all on v_mfma_f64_16x16x4_f64:
+//   k_nnet_pack   trial point: Xw = x + stp d (line-search points only), Pw = fixed | x + stp d
+//   k_nnet_fwd    Z tile -> residual, delta, q              (writes delta, q into gt, fe partial)
+//   k_nnet_bwd_x  delta W + q + measurement term -> gt       (me, g.d, g.g, max|g| partials)
+//   k_nnet_bwd_w  delta^T X per chunk of examples -> gpart   (no atomics: fixed-order reduce in
+//   k_nnet_pred   sum over chunks, scatter to the estimated-parameter tail of gt)
+//   k_nnet_rows   (large problems only) folds the per-workgroup partial rows to 32 per seed
+// A workgroup owns a 64x64 output tile: 2 x 2 waves, each wave 2 x 2 MFMA blocks (32 x 32, four
+// accumulators) so every LDS fragment read feeds two matrix instructions.  K is staged through
+// LDS 32 at a time with the next step's global loads already in flight.  Operand tiles that
+// are contiguous along K in memory are stored [row][k] (pitch 36), tiles contiguous along the
+// row/column index are stored [k][row] (pitch 80): both pitches make the 16x4 MFMA fragment
+// read hit 32 distinct 8-byte banks per half-wave.  MFMA blocks that lie wholly outside the
+// matrix (narrow layers, few examples) are skipped wave-uniformly.
+//
+// A header so that generated activation modules (va_user_act.hip, codegen.activation_module_for) can
+// instantiate the two kernels that apply the activation -- k_nnet_fwd and k_nnet_small -- for a traced user
+// callable; they define VA_NNET_ACT_ONLY to leave the activation-independent kernels out.
+#pragma once
+#include "va_nnet.h"
+#include "va_eval_flat.h"
+
+namespace va {
+
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int PRK = NN_KC + 4;     // [row][k] pitch: 36 = 4 (mod 32)
+constexpr int PKR = NN_TILE + 16;  // [k][row] pitch: 80 = 16 (mod 32)
+constexpr int NLD = NN_TILE * NN_KC / NN_THREADS;   // elements per thread per operand tile (8)
+
+// Activations: a type with f(z) and d(z, a) = f'(z), where a = f(z) is at hand (the built-ins express
+// the derivative through the value).  Generated modules supply `struct ActUser` (codegen.activation_header).
+template <int ID> struct ActBuiltin {
+    static __device__ __forceinline__ double f(double z)
+    {
+        if (ID == NNET_SIGMOID) return 1.0 / (1.0 + exp(-z));
+        if (ID == NNET_TANH) return tanh(z);
+        if (ID == NNET_RELU) return fmax(z, 0.0);
+        if (ID == NNET_SOFTPLUS) return z > 30.0 ? z : log1p(exp(z));
+        return z;
+    }
+    static __device__ __forceinline__ double d(double, double a)
+    {
+        if (ID == NNET_SIGMOID) return a * (1.0 - a);
+        if (ID == NNET_TANH) return 1.0 - a * a;
+        if (ID == NNET_RELU) return a > 0.0 ? 1.0 : 0.0;
+        if (ID == NNET_SOFTPLUS) return -expm1(-a);            // 1 - exp(-softplus(z)) = sigmoid(z)
+        return 1.0;
+    }
+};
+
+// ---- global -> register -> LDS tile movers (256 threads, 8 elements each) -------------------
+// element (r, k) at base[r*rs + k], 64 rows x 32 k; lanes run along k
+__device__ __forceinline__ void load_rk(const double *base, size_t rs, int nr, int nk, int t, double v[NLD])
+{
+    const int k = t & 31;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int r = (t >> 5) + 8 * u;
+        v[u] = (r < nr && k < nk) ? base[(size_t)r * rs + k] : 0.0;
+    }
+}
+__device__ __forceinline__ void store_rk(double *L, int t, const double v[NLD])
+{
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) L[((t >> 5) + 8 * u) * PRK + (t & 31)] = v[u];
+}
+// element (k, r) at base[k*ks + r], 32 k x 64 r; lanes run along r
+__device__ __forceinline__ void load_kr(const double *base, size_t ks, int nr, int nk, int t, double v[NLD])
+{
+    const int r = t & 63;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int k = (t >> 6) + 4 * u;
+        v[u] = (r < nr && k < nk) ? base[(size_t)k * ks + r] : 0.0;
+    }
+}
+__device__ __forceinline__ void store_kr(double *L, int t, const double v[NLD])
+{
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) L[((t >> 6) + 4 * u) * PKR + (t & 63)] = v[u];
+}
+
+// ---- one K step of 32 on the matrix cores: acc[2][2] (32x32) += A[32 x 32] B[32 x 32] -------
+// fragment layout of v_mfma_f64_16x16x4_f64: lane l feeds A[row = l&15][k = l>>4] and
+// B[k = l>>4][col = l&15]; result register i of lane l is C[row = (l>>4) + 4i][col = l&15].
+// live: bit (2*bi + bj) set <=> block (bi, bj) of this wave intersects the matrix.
+template <bool A_RK, bool B_RK>
+__device__ __forceinline__ void mma_step(const double *As, const double *Bs, int wr, int wc, int lane, int live,
+                                         d4 acc[2][2])
+{
+    const int lo = lane & 15, hi = lane >> 4;
+    if (!live) return;
+#pragma unroll
+    for (int kk = 0; kk < NN_KC / 4; ++kk) {
+        const int k = 4 * kk + hi;
+        double a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = wr * 32 + i * 16 + lo, c = wc * 32 + i * 16 + lo;
+            a[i] = A_RK ? As[r * PRK + k] : As[k * PKR + r];
+            b[i] = B_RK ? Bs[c * PRK + k] : Bs[k * PKR + c];
+        }
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 2; ++bj)
+                if (live & (1 << (2 * bi + bj)))
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bi], b[bj], acc[bi][bj], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ int live_mask(int wr, int wc, int nra, int nrb)
+{
+    int m = 0;
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+            if (wr * 32 + bi * 16 < nra && wc * 32 + bj * 16 < nrb) m |= 1 << (2 * bi + bj);
+    return m;
+}
+
+__device__ __forceinline__ bool seed_live(const Dev &dv, int b, int &use_d, double &stp, double &rf)
+{
+    const SeedState &st = dv.st[b];
+    const int phase = st.phase;
+    use_d = (phase == PH_LS);
+    stp = use_d ? st.stp : 0.0;
+    rf = st.rf_scale;
+    return phase == PH_START || phase == PH_LS;
+}
+
+// workgroup reduction of 4 values (k == 3 is a max), thread 0 gets the totals
+__device__ __forceinline__ void wg_reduce4(double v[4], double *red, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double w = (k == 3) ? wave_max(v[k]) : wave_sum(v[k]);
+        if (lane == 0) red[wave * 4 + k] = w;
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double w = red[k];
+            for (int ww = 1; ww < NN_THREADS / 64; ++ww) w = (k == 3) ? fmax(w, red[ww * 4 + k]) : w + red[ww * 4 + k];
+            v[k] = w;
+        }
+    }
+}
+// partial row r of seed b: straight into the table the line-search kernel reads, or into the
+// raw table k_nnet_rows folds
+__device__ __forceinline__ void put_row(const Dev &dv, const NnetDev &nn, int b, int r, double me, double fe,
+                                        double gtd, double gn2, double gmax)
+{
+    double *row = nn.raw ? nn.raw + ((size_t)b * nn.nraw + r) * EP_GP
+                         : dv.evp + ((size_t)b * dv.dm.nprow + r) * EP_N;
+    row[EP_ME] = me; row[EP_FE] = fe; row[EP_GTD] = gtd; row[EP_GN2] = gn2; row[EP_GMAX] = gmax;
+}
+
+// Measurement term of one observed element (example m, observed index l of its layer) under a full matrix
+// R (L x L, not assumed symmetric; va_nnet.py:136-139): its share of sum diff.(R.diff) and the derivative of
+// that sum with respect to it.  diff_at(k) = x[observed neuron k] - data[m][k].
+template <class DIFF>
+__device__ __forceinline__ void nnet_meas_matrix(const double *R, int L, int l, double diff, DIFF diff_at,
+                                                 double &share, double &deriv)
+{
+    double row = 0.0, sym = 0.0;
+    for (int k = 0; k < L; ++k) {
+        const double dk = diff_at(k);
+        row += R[l * L + k] * dk;
+        sym += (R[l * L + k] + R[k * L + l]) * dk;
+    }
+    share = diff * row; deriv = sym;
+}
+
+#ifndef VA_NNET_ACT_ONLY
+// ------------------------------------------------------------------ K0: trial point
+__global__ __launch_bounds__(NN_THREADS) void k_nnet_pack(const Dev dv, const NnetDev nn)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * NN_THREADS + threadIdx.x;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    const size_t vo = (size_t)b * dv.dm.ld;
+    if (i < nn.NDens) {
+        // at a plain evaluation point (no line-search step) the products read x itself
+        if (use_d) nn.Xw[vo + i] = trial(dv.x[vo + i], stp, dv.d[vo + i]);
+    } else if (i < nn.NDens + nn.NP) {
+        const int j = i - nn.NDens, k = nn.pmap[j];
+        double v;
+        if (k >= 0) {
+            v = dv.x[vo + nn.NDens + k];
+            if (use_d) v = trial(v, stp, dv.d[vo + nn.NDens + k]);
+        } else v = nn.Pfix[(size_t)b * nn.NP + j];
+        nn.Pw[(size_t)b * nn.NP + j] = v;
+    }
+}
+
+#endif  // VA_NNET_ACT_ONLY
+
+// ------------------------------------------------------------------ K1: Z, residual, delta
+template <class ACT>
+__global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const NnetDev nn)
+{
+    __shared__ double As[NN_TILE * PRK], Bs[NN_TILE * PRK], red[16];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    const NnetTile tl = nn.t1[blockIdx.x];
+    const int m0 = tl.r0, i0 = tl.c0;
+    const int sn = tl.sn, sn1 = tl.sn1, K = sn;
+    const size_t vo = (size_t)b * dv.dm.ld;
+    const double *Xs = use_d ? nn.Xw : dv.x;                 // trial point, or x itself
+    const double *X = Xs + vo + (size_t)m0 * nn.NDnet + tl.offn;
+    const double *W = nn.Pw + (size_t)b * nn.NP + tl.woff + (size_t)i0 * sn;
+    const int nra = min(NN_TILE, nn.M - m0), nrb = min(NN_TILE, sn1 - i0);
+    const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int live = live_mask(wr, wc, nra, nrb);
+
+    d4 acc[2][2] = {};
+    double va[NLD], vb[NLD];
+    load_rk(X, nn.NDnet, nra, K, tid, va);
+    load_rk(W, sn, nrb, K, tid, vb);
+    for (int k0 = 0; k0 < K; k0 += NN_KC) {
+        store_rk(As, tid, va); store_rk(Bs, tid, vb);
+        __syncthreads();
+        if (k0 + NN_KC < K) {
+            load_rk(X + k0 + NN_KC, nn.NDnet, nra, K - k0 - NN_KC, tid, va);
+            load_rk(W + k0 + NN_KC, sn, nrb, K - k0 - NN_KC, tid, vb);
+        }
+        mma_step<true, true>(As, Bs, wr, wc, lane, live, acc);
+        __syncthreads();
+    }
+    // epilogue: lane holds Z[m][i], 16 consecutive neurons i per 16 lanes
+    const double cq = 2.0 * rf * dv.dm.cfe;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+        const int i = i0 + wc * 32 + bj * 16 + (lane & 15);
+        if (i >= sn1) continue;
+        // (no early request of bias / x_{n+1}: 32 fewer live registers put a fourth workgroup on the CU)
+        const double bias = nn.Pw[(size_t)b * nn.NP + tl.boff + i];
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
+                if (m >= nn.M) continue;
+                const size_t idx = vo + (size_t)m * nn.NDnet + tl.offn1 + i;
+                const double z = acc[bi][bj][r] + bias;
+                const double a = ACT::f(z);
+                const double res = Xs[idx] - a;
+                const double q = cq * res;
+                v[1] += res * res;
+                nn.delta[idx] = -q * ACT::d(z, a);
+                dv.gt[idx] = q;
+            }
+    }
+    wg_reduce4(v, red, tid);
+    if (tid == 0) put_row(dv, nn, b, blockIdx.x, 0.0, v[1], 0.0, 0.0, 0.0);
+}
+
+#ifndef VA_NNET_ACT_ONLY
+// ------------------------------------------------------------------ K2: dA/dX
+__global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_x(const Dev dv, const NnetDev nn)
+{
+    __shared__ double As[NN_TILE * PRK], Bs[NN_KC * PKR], red[16];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    const NnetTile tl = nn.t2[blockIdx.x];
+    const int n = tl.layer, m0 = tl.r0, j0 = tl.c0;
+    const int sn = tl.sn;
+    const int K = tl.sn1;                                  // 0 for the output layer: no product
+    const size_t vo = (size_t)b * dv.dm.ld;
+    const int nra = min(NN_TILE, nn.M - m0), nrb = min(NN_TILE, sn - j0);
+    const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int live = live_mask(wr, wc, nra, nrb);
+
+    d4 acc[2][2] = {};
+    // q left by k_nnet_fwd in gt: requested now, consumed in the epilogue
+    double q0[2][2][4];
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+        const int j = j0 + wc * 32 + bj * 16 + (lane & 15);
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
+                q0[bi][bj][r] = (n > 0 && j < sn && m < nn.M) ? dv.gt[vo + (size_t)m * nn.NDnet + tl.offn + j] : 0.0;
+            }
+    }
+    if (K > 0) {
+        const double *Dl = nn.delta + vo + (size_t)m0 * nn.NDnet + tl.offn1;
+        const double *W = nn.Pw + (size_t)b * nn.NP + tl.woff + j0;
+        double va[NLD], vb[NLD];
+        load_rk(Dl, nn.NDnet, nra, K, tid, va);
+        load_kr(W, sn, nrb, K, tid, vb);
+        for (int k0 = 0; k0 < K; k0 += NN_KC) {
+            store_rk(As, tid, va); store_kr(Bs, tid, vb);
+            __syncthreads();
+            if (k0 + NN_KC < K) {
+                load_rk(Dl + k0 + NN_KC, nn.NDnet, nra, K - k0 - NN_KC, tid, va);
+                load_kr(W + (size_t)(k0 + NN_KC) * sn, sn, nrb, K - k0 - NN_KC, tid, vb);
+            }
+            mma_step<true, false>(As, Bs, wr, wc, lane, live, acc);
+            __syncthreads();
+        }
+    }
+    double v[4] = {0.0, 0.0, 0.0, 0.0};          // me, g.d, g.g, max|g|
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+        const int j = j0 + wc * 32 + bj * 16 + (lane & 15);
+        if (j >= sn) continue;
+        int l = -1; double rm = 0.0; const double *dat = nullptr, *R = nullptr; const int *lidx = nullptr; int L = 0;
+        if (n == 0) { l = nn.lmap_in[j]; rm = nn.rm_in; dat = nn.din; L = nn.Lin; R = nn.rmm_in; lidx = nn.lidx_in; }
+        else if (n == nn.NL - 1) { l = nn.lmap_out[j]; rm = nn.rm_out; dat = nn.dout; L = nn.Lout; R = nn.rmm_out; lidx = nn.lidx_out; }
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
+                if (m >= nn.M) continue;
+                const size_t idx = vo + (size_t)m * nn.NDnet + tl.offn + j;
+                double g = acc[bi][bj][r] + q0[bi][bj][r];
+                if (l >= 0) {
+                    const double *Xt = use_d ? nn.Xw : dv.x;
+                    const double diff = Xt[idx] - dat[(size_t)m * L + l];
+                    const size_t rowb = vo + (size_t)m * nn.NDnet + tl.offn;
+                    if (R) {
+                        double share, deriv;
+                        nnet_meas_matrix(R, L, l, diff, [&](int k) { return Xt[rowb + lidx[k]] - dat[(size_t)m * L + k]; }, share, deriv);
+                        v[0] += share;
+                        g += dv.dm.cme * deriv;
+                    } else {
+                        v[0] += rm * diff * diff;
+                        g += 2.0 * dv.dm.cme * rm * diff;
+                    }
+                }
+                dv.gt[idx] = g;
+                if (use_d) v[1] += g * dv.d[idx];
+                v[2] += g * g;
+                v[3] = fmax(v[3], fabs(g));
+            }
+    }
+    wg_reduce4(v, red, tid);
+    if (tid == 0) put_row(dv, nn, b, nn.n1 + blockIdx.x, v[0], 0.0, v[1], v[2], v[3]);
+}
+
+// ------------------------------------------------------------------ K3: dA/dW, dA/db per chunk
+__global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_w(const Dev dv, const NnetDev nn)
+{
+    __shared__ double As[NN_KC * PKR], Bs[NN_KC * PKR];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    const NnetTile tl = nn.t3[blockIdx.x];
+    const int i0 = tl.r0, j0 = tl.c0;
+    const int sn = tl.sn, sn1 = tl.sn1;
+    const int mb = tl.chunk * nn.mch;
+    const int K = min(nn.mch, nn.M - mb);                       // examples in this chunk
+    const size_t vo = (size_t)b * dv.dm.ld;
+    const double *Dl = nn.delta + vo + (size_t)mb * nn.NDnet + tl.offn1 + i0;
+    const double *X = (use_d ? nn.Xw : dv.x) + vo + (size_t)mb * nn.NDnet + tl.offn + j0;
+    const int nra = min(NN_TILE, sn1 - i0), nrb = min(NN_TILE, sn - j0);
+    const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int live = live_mask(wr, wc, nra, nrb);
+
+    d4 acc[2][2] = {};
+    double va[NLD], vb[NLD], bsum = 0.0;
+    load_kr(Dl, nn.NDnet, nra, K, tid, va);
+    load_kr(X, nn.NDnet, nrb, K, tid, vb);
+    for (int k0 = 0; k0 < K; k0 += NN_KC) {
+        store_kr(As, tid, va); store_kr(Bs, tid, vb);
+        __syncthreads();
+        if (k0 + NN_KC < K) {
+            const size_t sh = (size_t)(k0 + NN_KC) * nn.NDnet;
+            load_kr(Dl + sh, nn.NDnet, nra, K - k0 - NN_KC, tid, va);
+            load_kr(X + sh, nn.NDnet, nrb, K - k0 - NN_KC, tid, vb);
+        }
+        mma_step<false, false>(As, Bs, wr, wc, lane, live, acc);
+        if (j0 == 0 && tid < NN_TILE) {                         // bias gradient: column sums of delta
+#pragma unroll 8
+            for (int k = 0; k < NN_KC; ++k) bsum += As[k * PKR + tid];
+        }
+        __syncthreads();
+    }
+    double *gp = nn.gpart + ((size_t)b * nn.nmch + tl.chunk) * nn.NP;
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+        const int j = j0 + wc * 32 + bj * 16 + (lane & 15);
+        if (j >= sn) continue;
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
+                if (i < sn1) gp[tl.woff + (size_t)i * sn + j] = acc[bi][bj][r];
+            }
+    }
+    if (j0 == 0 && tid < NN_TILE && i0 + tid < sn1) gp[tl.boff + i0 + tid] = bsum;
+}
+
+// ------------------------------------------------------------------ K4: parameter tail of grad A
+__global__ __launch_bounds__(NN_THREADS) void k_nnet_pred(const Dev dv, const NnetDev nn)
+{
+    __shared__ double red[16];
+    const int b = blockIdx.y, tid = threadIdx.x, j = blockIdx.x * NN_THREADS + tid;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (j < nn.NP) {
+        const int k = nn.pmap[j];
+        if (k >= 0) {
+            const double *gp = nn.gpart + (size_t)b * nn.nmch * nn.NP + j;
+            double g = 0.0;
+            for (int c = 0; c < nn.nmch; ++c) g += gp[(size_t)c * nn.NP];
+            const size_t i = (size_t)b * dv.dm.ld + nn.NDens + k;
+            dv.gt[i] = g;
+            if (use_d) v[1] = g * dv.d[i];
+            v[2] = g * g;
+            v[3] = fabs(g);
+        }
+    }
+    wg_reduce4(v, red, tid);
+    if (tid == 0) put_row(dv, nn, b, nn.n1 + nn.n2 + blockIdx.x, 0.0, 0.0, v[1], v[2], v[3]);
+}
+
+// ------------------------------------------------------------------ K5: fold the partial rows
+// NN_RED_ROWS workgroups of one wave per seed: workgroup w sums raw rows w, w+32, ... in a
+// fixed order (lane = (row phase, column)), so k_ls / k_finalize_eval see 32 rows per seed.
+__global__ __launch_bounds__(64) void k_nnet_rows(const Dev dv, const NnetDev nn)
+{
+    const int b = blockIdx.y, w = blockIdx.x, lane = threadIdx.x;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    const int c = lane & 7, ph = lane >> 3;                      // 8 columns (5 used) x 8 row phases
+    const double *raw = nn.raw + (size_t)b * nn.nraw * EP_GP;
+    double v = 0.0;
+    if (c < EP_GP)
+        for (int r = w + NN_RED_ROWS * ph; r < nn.nraw; r += NN_RED_ROWS * 8) {
+            const double x = raw[(size_t)r * EP_GP + c];
+            v = (c == EP_GMAX) ? fmax(v, x) : v + x;
+        }
+#pragma unroll
+    for (int o = 32; o >= 8; o >>= 1) {
+        const double x = __shfl_down(v, o, 64);
+        v = (c == EP_GMAX) ? fmax(v, x) : v + x;
+    }
+    if (lane < EP_GP) dv.evp[((size_t)b * dv.dm.nprow + w) * EP_N + lane] = v;
+}
+
+#endif  // VA_NNET_ACT_ONLY
+
+// ------------------------------------------------------------------ small networks: one kernel
+// When every layer is at most 32 wide and there are at most 32 examples (the reference's twin
+// example: 20 x 10 neurons, M = 2), the six launches above are pure launch latency.  Here one
+// workgroup OWNS layer n of one seed and produces everything indexed by n:
+//     q_n     = 2 RF c (x_n - act(x_{n-1} W_{n-1}^T + b_{n-1}))      (transition n-1, recomputed)
+//     delta_n = -q_{n+1} act'(...) from transition n                 (its residual feeds fe)
+//     dA/dx_n = q_n + delta_n W_n + measurement term
+//     dA/dW_n = delta_n^T x_n,  dA/db_n = sum_m delta_n  -> scattered through pmap
+// so no workgroup waits for another, nothing round-trips through HBM, and the trial point is
+// formed on load.  Each transition's forward product is computed twice (by the owners of its two
+// ends): 4 instead of 3 tiny products per layer.  Waves = the 2 x 2 MFMA blocks of the 32x32 tile.
+constexpr int PS = NN_SMALL + 4;   // LDS pitch 36
+
+// acc[16x16 block (br, bc)] = A[. x K] B[K x .], K <= 4*nk; *_T: operand stored transposed in LDS
+template <bool A_T, bool B_T>
+__device__ __forceinline__ d4 mma32(const double *As, const double *Bs, int br, int bc, int lane, int nk)
+{
+    const int lo = lane & 15, hi = lane >> 4;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk < nk; ++kk) {
+        const int k = 4 * kk + hi, r = br * 16 + lo, c = bc * 16 + lo;
+        const double a = A_T ? As[k * PS + r] : As[r * PS + k];
+        const double b = B_T ? Bs[c * PS + k] : Bs[k * PS + c];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// LDS: five operand arrays of R rows (R = 16 or 32: the largest of M and the layer widths rounded
+// up to the MFMA block) x pitch 36, two bias rows, reduction scratch
+inline size_t nnet_small_lds(int R) { return sizeof(double) * ((size_t)5 * R * PS + 2 * NN_SMALL + 20); }
+
+template <class ACT>
+__global__ __launch_bounds__(NN_THREADS) void k_nnet_small(const Dev dv, const NnetDev nn)
+{
+    extern __shared__ double sm[];
+    const int R = nn.small;                       // rows staged per array
+    double *Xp = sm, *Xc = sm + R * PS, *Wp = sm + 2 * R * PS, *Wc = sm + 3 * R * PS, *Dl = sm + 4 * R * PS;
+    double *bp = sm + 5 * R * PS, *bc = bp + NN_SMALL, *red = bc + NN_SMALL;
+    const int b = blockIdx.y, n = blockIdx.x, tid = threadIdx.x;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    const int NL = nn.NL, M = nn.M;
+    const bool has_prev = n > 0, has_next = n < NL - 1;
+    const int sn = nn.s[n], sp = has_prev ? nn.s[n - 1] : 0, sx = has_next ? nn.s[n + 1] : 0;
+    const int offc = nn.off[n], offp = has_prev ? nn.off[n - 1] : 0, offx = has_next ? nn.off[n + 1] : 0;
+    const int wofp = has_prev ? nn.woff[n - 1] : 0, bofp = has_prev ? nn.boff[n - 1] : 0;
+    const int wofc = has_next ? nn.woff[n] : 0, bofc = has_next ? nn.boff[n] : 0;
+    const size_t vo = (size_t)b * dv.dm.ld;
+    const double *x = dv.x + vo, *d = dv.d + vo;
+    const double *Pf = nn.Pfix + (size_t)b * nn.NP;
+    const int lane = tid & 63, wave = tid >> 6, br = wave >> 1, bcol = wave & 1;
+
+    auto xval = [&](int idx) { double v = x[idx]; if (use_d) v = trial(v, stp, d[idx]); return v; };
+    auto pval = [&](int j) {
+        const int k = nn.pmap[j];
+        return k >= 0 ? xval(nn.NDens + k) : Pf[j];
+    };
+    // ---- stage the operands (zero padded to 32 x 32): 4 elements per thread per array
+    for (int e = tid; e < R * 32; e += NN_THREADS) {
+        const int r = e >> 5, k = e & 31;
+        Xc[r * PS + k] = (r < M && k < sn) ? xval(r * nn.NDnet + offc + k) : 0.0;
+        Xp[r * PS + k] = (has_prev && r < M && k < sp) ? xval(r * nn.NDnet + offp + k) : 0.0;
+        Wp[r * PS + k] = (has_prev && r < sn && k < sp) ? pval(wofp + r * sp + k) : 0.0;     // W_{n-1}[i][k]
+        Wc[r * PS + k] = (has_next && r < sx && k < sn) ? pval(wofc + r * sn + k) : 0.0;     // W_n[i][k]
+    }
+    if (tid < NN_SMALL) {
+        bp[tid] = (has_prev && tid < sn) ? pval(bofp + tid) : 0.0;
+        bc[tid] = (has_next && tid < sx) ? pval(bofc + tid) : 0.0;
+    }
+    // x_{n+1} is only needed element-wise, in the accumulator layout of this wave's block
+    const int col = bcol * 16 + (lane & 15);
+    double xn1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = br * 16 + (lane >> 4) + 4 * r;
+        xn1[r] = (has_next && m < M && col < sx) ? xval(m * nn.NDnet + offx + col) : 0.0;
+    }
+    __syncthreads();
+
+    const double cq = 2.0 * rf * dv.dm.cfe;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};          // me (+ fe in vfe), g.d, g.g, max|g|
+    double vfe = 0.0;
+    // ---- transition n-1 -> q_n in this wave's block of [m][j of layer n]
+    double q[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool rows_m = br * 16 < M;              // this wave's block rows hold examples
+    if (has_prev && rows_m && bcol * 16 < sn) {
+        const d4 z = mma32<false, true>(Xp, Wp, br, bcol, lane, (sp + 3) >> 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = br * 16 + (lane >> 4) + 4 * r;
+            if (m < M && col < sn) q[r] = cq * (Xc[m * PS + col] - ACT::f(z[r] + bp[col]));
+        }
+    }
+    // ---- transition n -> delta_n in LDS, fe
+    if (has_next && br * 16 < R) {
+        d4 z = {0.0, 0.0, 0.0, 0.0};
+        if (rows_m && bcol * 16 < sx) z = mma32<false, true>(Xc, Wc, br, bcol, lane, (sn + 3) >> 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = br * 16 + (lane >> 4) + 4 * r;
+            double dl = 0.0;
+            if (m < M && col < sx) {
+                const double zz = z[r] + bc[col];
+                const double a = ACT::f(zz);
+                const double res = xn1[r] - a;
+                vfe += res * res;
+                dl = -cq * res * ACT::d(zz, a);
+            }
+            Dl[m * PS + col] = dl;
+        }
+    }
+    __syncthreads();
+    // ---- dA/dx_n = q_n + delta_n W_n + measurement term
+    {
+        d4 gx = {0.0, 0.0, 0.0, 0.0};
+        if (has_next && rows_m && bcol * 16 < sn) gx = mma32<false, false>(Dl, Wc, br, bcol, lane, (sx + 3) >> 2);   // B[k=i][c=j] = W_n[i][j]
+        int l = -1; double rm = 0.0; const double *dat = nullptr, *R = nullptr; const int *lidx = nullptr; int L = 0;
+        if (col < sn) {
+            if (n == 0) { l = nn.lmap_in[col]; rm = nn.rm_in; dat = nn.din; L = nn.Lin; R = nn.rmm_in; lidx = nn.lidx_in; }
+            else if (n == NL - 1) { l = nn.lmap_out[col]; rm = nn.rm_out; dat = nn.dout; L = nn.Lout; R = nn.rmm_out; lidx = nn.lidx_out; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = br * 16 + (lane >> 4) + 4 * r;
+            if (m >= M || col >= sn) continue;
+            const int idx = m * nn.NDnet + offc + col;
+            double g = gx[r] + q[r];
+            if (l >= 0) {
+                const double diff = Xc[m * PS + col] - dat[(size_t)m * L + l];
+                if (R) {
+                    double share, deriv;
+                    nnet_meas_matrix(R, L, l, diff, [&](int k) { return Xc[m * PS + lidx[k]] - dat[(size_t)m * L + k]; }, share, deriv);
+                    v[0] += share;
+                    g += dv.dm.cme * deriv;
+                } else {
+                    v[0] += rm * diff * diff;
+                    g += 2.0 * dv.dm.cme * rm * diff;
+                }
+            }
+            dv.gt[vo + idx] = g;
+            if (use_d) v[1] += g * d[idx];
+            v[2] += g * g;
+            v[3] = fmax(v[3], fabs(g));
+        }
+    }
+    // ---- dA/dW_n = delta_n^T x_n (rows i of layer n+1, columns j of layer n), dA/db_n
+    if (has_next && nn.NPest > 0) {
+        d4 gw = {0.0, 0.0, 0.0, 0.0};
+        if (br * 16 < sx && bcol * 16 < sn) gw = mma32<true, false>(Dl, Xc, br, bcol, lane, (M + 3) >> 2);   // A[r=i][k=m], B[k=m][c=j]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = br * 16 + (lane >> 4) + 4 * r;
+            if (i >= sx || col >= sn) continue;
+            const int k = nn.pmap[wofc + i * sn + col];
+            if (k < 0) continue;
+            const double g = gw[r];
+            dv.gt[vo + nn.NDens + k] = g;
+            if (use_d) v[1] += g * d[nn.NDens + k];
+            v[2] += g * g;
+            v[3] = fmax(v[3], fabs(g));
+        }
+        if (tid < sx) {
+            const int k = nn.pmap[bofc + tid];
+            if (k >= 0) {
+                double g = 0.0;
+                for (int m = 0; m < M; ++m) g += Dl[m * PS + tid];
+                dv.gt[vo + nn.NDens + k] = g;
+                if (use_d) v[1] += g * d[nn.NDens + k];
+                v[2] += g * g;
+                v[3] = fmax(v[3], fabs(g));
+            }
+        }
+    }
+    vfe = wave_sum(vfe);
+    if (lane == 0) red[16 + wave] = vfe;
+    wg_reduce4(v, red, tid);                       // (contains the barrier that publishes red[16..19])
+    if (tid == 0) put_row(dv, nn, b, n, v[0], red[16] + red[17] + red[18] + red[19], v[1], v[2], v[3]);
+}
+
+
+// the two launches that depend on the activation type
+template <class ACT>
+inline void launch_nnet_act(const Dev &dv, const NnetDev &nn, hipStream_t s, bool small)
+{
+    const int B = dv.dm.B;
+    if (small) hipLaunchKernelGGL(k_nnet_small<ACT>, dim3(nn.NL, B), dim3(NN_THREADS), nnet_small_lds(nn.small), s, dv, nn);
+    else hipLaunchKernelGGL(k_nnet_fwd<ACT>, dim3(nn.n1, B), dim3(NN_THREADS), 0, s, dv, nn);
+}
+
+}  // namespace va

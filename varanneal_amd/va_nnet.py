@@ -142,8 +142,14 @@ class Annealer(HIPmin):
         if self.f is None:
             raise ValueError("set_activation must be called first")
         if self._act is None:
-            raise NotImplementedError("activation %r is not one of the built-in forms %s of W.x + b"
-                                      % (self.f, sorted(ACT_IMPL)))
+            # any other layer map g(W.x + b) with an elementwise g: trace g, differentiate it, compile the two
+            # kernels that apply it (csrc/va_user_act.hip) -- the reference takes any callable (va_nnet.py:71)
+            from . import codegen
+            try:
+                self._act_module = codegen.activation_module_for(self.f)
+            except TypeError as e:
+                raise NotImplementedError("activation %r: %s (built-in forms: %s)" % (self.f, e, sorted(ACT_IMPL)))
+            self._act = _capi.load_act_module(self._act_module["so"])
         if method not in ('L-BFGS-B', 'NCG', 'TNC'):
             raise ValueError("Optimization routine %r not recognized (upstream also lists 'LM', which it "
                              "never implemented for this class)." % (method,))
