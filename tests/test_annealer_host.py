@@ -117,8 +117,7 @@ def test_unsupported_inputs_fail_loudly(fake_device, golden_ladders):
                       disc="euler")
     with pytest.raises(ValueError):                  # ... and one row per model time point
         a.anneal_init(c["X0"].copy(), np.ones((199, 1)), 1.5, np.arange(3), 4.0, 4e-6, list(c["Lidx"]), [0])
-    with pytest.raises(NotImplementedError):         # full RF matrix (the upstream branch is wrong, va_ode.py:222)
-        a.anneal_init(c["X0"].copy(), c["P0"].copy(), 1.5, np.arange(3), 4.0, np.eye(20), list(c["Lidx"]), [0])
+    # (full RF matrices, (D, D) / (N-1, D, D), are accepted since round 2: tests/test_rffull.py)
     with pytest.raises(ValueError):
         a.anneal_init(c["X0"].copy(), c["P0"].copy(), 1.5, np.arange(3), 4.0, np.ones(3), list(c["Lidx"]), [0])
     with pytest.raises(ValueError):

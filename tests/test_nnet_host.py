@@ -161,7 +161,7 @@ def test_bad_inputs_fail_loudly(fake_device):
     with pytest.raises(ValueError):
         a.anneal(X0, P0, 2.0, np.arange(2), 1.0, 1e-3, Pidx)
     a.set_structure(s); a.set_input_data(din); a.set_output_data(dout)
-    a.set_activation(lambda x, W, b: np.sin(np.dot(W, x) + b))
+    a.set_activation(lambda x, W, b: np.sin(np.dot(W, x)) + b)      # not g(W.x + b): cannot become a kernel epilogue
     with pytest.raises(NotImplementedError):
         a.anneal(X0, P0, 2.0, np.arange(2), 1.0, 1e-3, Pidx)
     a.set_activation(twin.sigmoid)
