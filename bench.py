@@ -185,6 +185,30 @@ def extra_c4(device, steps=60):
             "achieved_GBs": balg / ks / 1e9, "frac": balg / ks / 1e9 / HBM_PEAK_GBS}
 
 
+def extra_nnet(device, key, steps):
+    """The network action (BASELINE config 5, va_nnet) as a sub-record: `c5` = the reference's twin example
+    (20 layers x 10 neurons, M = 2: one small kernel per evaluation), `c5x` = layers that fill the matrix cores
+    (8 x 128 neurons, M = 2048).  Complete evaluations (A formed), HIP events."""
+    from varanneal_amd import _capi, twin
+    w = NNET_WORKLOADS[key]
+    s, M, B = np.array(w["structure"]), w["M"], w["B"]
+    din, dout, _ = twin.make_nnet_twin(s, M)
+    RM = 1.0 / 0.005 ** 2
+    RF0 = 1.0e-8 * RM * float(np.sum(s) - s[0]) / float(s[0] + s[-1])
+    g = [twin.nnet_initial_guess(s, M, b) for b in range(B)]
+    Pidx = g[0][2]
+    P = np.array([x[1] for x in g])
+    XP = np.array([np.append(x[0], x[1][Pidx]) for x in g])
+    rf = 1.1 ** 100
+    with _capi.NnetProblem(B, s, din, dout, [np.arange(s[0]), np.arange(s[-1])], RM, RF0, P, Pidx, device=device) as pb:
+        pb.action_grad(XP, rf)
+        pb.eval_timed(rf, max(steps // 10, 2))
+        ks = pb.eval_timed(rf, steps) * 1e-3 / steps
+    flops = B * M * float(np.sum(3 * 2 * s[1:] * s[:-1]))
+    return {"workload": w["name"], "us_per_eval_launch": ks * 1e6, "evals_per_s": B / ks, "flops_alg_per_launch": flops,
+            "achieved_TFLOPs": flops / ks / 1e12, "frac_of_f64_mfma_peak": flops / ks / 1e12 / F64_MFMA_PEAK_TFLOPS}
+
+
 def extra_ladder(device, D, N, B, Y, Lidx, XP, P, nbeta=30):
     """The C3 ladder end to end (alpha = 1.5, beta = 0..nbeta-1, SciPy-equal stopping rules): every
     kernel of the three-launch L-BFGS cycle counted; then the two vector kernels alone with full
@@ -443,7 +467,8 @@ def main():
         if world == 1 and args.workload == "c3" and not args.no_extra:
             pb.close()
             out["extra"] = {"ladder": extra_ladder(local_rank, D, N, B, Y, Lidx, XP, P),
-                            "c4": extra_c4(local_rank)}
+                            "c4": extra_c4(local_rank),
+                            "c5": extra_nnet(local_rank, "c5", 2000), "c5x": extra_nnet(local_rank, "c5x", 40)}
         print(json.dumps(out), flush=True)
     pb.close()
     if dist is not None:

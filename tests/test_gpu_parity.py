@@ -324,6 +324,47 @@ def test_c4_shape_properties(capi):
     pb2.close()
 
 
+def test_c4_all_512_seeds_on_one_gpu(capi):
+    """BASELINE config 4 in full -- D=200, N=5000, L=80, 512 seeds -- as ONE handle on one 288 GB device (the
+    reference spreads it over 8 GPUs' worth of processes; here 64 per GPU is the sharded form and this is the
+    whole).  4.1 GB per state vector: three seeds against the oracle, every seed through size-independent
+    properties, then three L-BFGS iterations of all 512 seeds at once (history of 3 pairs: ~45 GB resident)."""
+    import va_oracle
+    from varanneal_amd import twin
+    D, N, B = 200, 5000, 512
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    rng = np.random.RandomState(45)
+    XP = np.empty((B, N * D + 1))
+    for b0 in range(0, B, 64):                                               # (generated in slabs: bounded temporaries)
+        blk = 3.0 * rng.randn(64, N, D)
+        blk[:, :, Lidx] = Y
+        blk += 0.1 * rng.randn(64, N, D)
+        XP[b0:b0 + 64, :N * D] = blk.reshape(64, N * D)
+    XP[:, -1] = 6.0 + 4.0 * rng.rand(B)
+    P = XP[:, -1:].copy()
+    pb = capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", lbfgs_m=3)
+    assert pb.info()["n_var"] == 1000001 and pb.info()["eval_kernel"] == 3
+    A1, me1, fe1, _ = pb.action_grad(XP, 1.0, want_grad=False)
+    A2, me2, fe2, g2 = pb.action_grad(XP, 1000.0)
+    assert np.array_equal(me1, me2) and np.allclose(fe2, 1000.0 * fe1, rtol=1e-13)
+    assert np.allclose(A2, me2 + fe2, rtol=1e-15) and np.all(np.isfinite(g2))
+    for b in (0, 255, 511):
+        opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[b], [0], disc="trapezoid")
+        Ao, meo, feo, go = opb.action_grad(XP[b], 1000.0)
+        assert abs(A2[b] - Ao) <= RTOL_A * abs(Ao) and abs(me2[b] - meo) <= RTOL_A * abs(Ao)
+        assert np.abs(g2[b] - go).max() <= RTOL_G * np.abs(go).max()
+    # independence: two seeds with equal inputs give equal outputs, whatever else is in the batch
+    XP[300] = XP[7]; P[300] = P[7]
+    pb.close()
+    pb = capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", lbfgs_m=3)
+    A3, _, _, g3 = pb.action_grad(XP, 1000.0)
+    assert A3[300] == A3[7] == A2[7] and np.array_equal(g3[300], g3[7]) and np.array_equal(g3[7], g2[7])
+    del g2, g3
+    r = pb.minimize_lbfgs(XP, 1000.0, {'maxiter': 3, 'maxfun': 20, 'gtol': 1e-12, 'ftol': 1e-14})
+    assert np.all(r["A"] < A3) and np.all(r["nit"] == 3) and r["A"][300] == r["A"][7]
+    pb.close()
+
+
 @pytest.mark.parametrize("D,disc", [(7, "trapezoid"), (36, "SimpsonHermite"), (64, "euler"),
                                     (100, "forwardmap"), (200, "trapezoid"), (200, "SimpsonHermite"),
                                     (130, "SimpsonHermite"), (255, "SimpsonHermite"), (256, "euler"),

@@ -75,6 +75,7 @@ struct va_problem_s {
     int device = 0, rhs = 0, keep_paths = 0;
     void (*user_launch)(const Dev *, void *) = nullptr;
     int (*user_prepare)(const Dev *) = nullptr;
+    unsigned long long epoch = 0;      // launches of folded evaluations so far (Dev::epoch)
     NnetActLaunch user_act = nullptr;  // generated activation module's launcher (nn.act >= NNET_USER)
     bool is_nnet = false;              // feed-forward-network action (va_nnet.hip) instead of an ODE path
     bool fold = false;                 // the evaluation kernel runs the tail itself (last arriver of each seed)
@@ -107,7 +108,7 @@ namespace {
 // evaluation is several kernels, so its tail stays a launch of its own.
 void run_eval(va_handle h, int epi)
 {
-    if (h->is_nnet || !h->fold) {
+    if (h->is_nnet ? !h->nn.small : !h->fold) {
         // (large grids: a workgroup that waits for its arrival to come back holds its LDS and wave
         // slots ~1 us longer, which costs more than the 64-wave tail kernel it saves)
         h->dv.epi = EPI_NONE;
@@ -119,6 +120,8 @@ void run_eval(va_handle h, int epi)
         return;
     }
     h->dv.epi = epi;
+    h->dv.epoch = (double)(++h->epoch);       // (kernel arguments are copied at launch; S1 launches are never graph-replayed)
+    if (h->is_nnet) { launch_nnet_eval(h->dv, h->nn, h->stream, h->user_act); return; }   // (small nets: k_nnet_small carries the tail)
     if (h->user_launch) h->user_launch(&h->dv, (void *)h->stream);
     else launch_eval(h->dv, h->rhs, h->stream);
 }
@@ -622,6 +625,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dv.evcols = EP_GP + d->NP <= 8 ? 8 : (EP_GP + d->NP <= 16 ? 16 : 32);
     { const char *e = getenv("VA_GRAD_SC1"); dv.gaux = e ? atoi(e) : 1; }
     { const char *e = getenv("VA_PRIO"); dv.prio = e ? atoi(e) : 1; }
+    { const char *e = getenv("VA_SPEC"); dv.spec = e ? atoi(e) : 1; }
     dv.o.m = m; dv.o.maxiter = 15000; dv.o.maxls = 20; dv.o.maxfun = 15000; dv.o.ftol = 2.2204460492503131e-09; dv.o.gtol = 1e-5;
 
     {
@@ -823,7 +827,7 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
                 for (int j0 = 0; j0 < s[n]; j0 += NN_TILE) t3.push_back(tile(n, i0, j0, c));
     nn.n1 = (int)t1.size(); nn.n2 = (int)t2.size(); nn.n3 = (int)t3.size();
     nn.n4 = (d->NP + NN_THREADS - 1) / NN_THREADS;
-    nn.n0 = (nn.NDens + d->NP + NN_THREADS - 1) / NN_THREADS;
+    nn.n0 = (nn.NDens + d->NP + NN_THREADS * NN_PACK - 1) / (NN_THREADS * NN_PACK);
     nn.nraw = nn.n1 + nn.n2 + nn.n4;
     // small networks: one workgroup per layer does the whole evaluation (k_nnet_small)
     {

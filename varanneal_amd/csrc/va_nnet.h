@@ -14,6 +14,7 @@ enum { NNET_SIGMOID = 0, NNET_TANH = 1, NNET_LINEAR = 2, NNET_RELU = 3, NNET_SOF
 constexpr int NN_TILE = 64;      // workgroup output tile: 2 x 2 waves, each 2 x 2 MFMA blocks of 16x16
 constexpr int NN_KC = 32;        // K elements staged in LDS per step
 constexpr int NN_THREADS = 256;
+constexpr int NN_PACK = 8;       // elements per thread of the trial-point kernel (k_nnet_pack)
 
 constexpr int NN_SMALL = 32;         // widest layer / most examples the single-kernel path handles
 constexpr int NN_ROWS_DIRECT = 64;   // partial rows per seed the line-search kernel reduces itself

@@ -22,7 +22,8 @@ void launch_nnet_eval(const Dev &dv, const NnetDev &nn, hipStream_t s, NnetActLa
     if (nn.small) { launch_act(dv, nn, s, true, user); return; }
     hipLaunchKernelGGL(k_nnet_pack, dim3(nn.n0, B), blk, 0, s, dv, nn);
     launch_act(dv, nn, s, false, user);
-    hipLaunchKernelGGL(k_nnet_bwd_x, dim3(nn.n2, B), blk, 0, s, dv, nn);
+    if (nn.rmm_in) hipLaunchKernelGGL(k_nnet_bwd_x<true>, dim3(nn.n2, B), blk, 0, s, dv, nn);
+    else hipLaunchKernelGGL(k_nnet_bwd_x<false>, dim3(nn.n2, B), blk, 0, s, dv, nn);
     if (nn.NPest > 0) {
         hipLaunchKernelGGL(k_nnet_bwd_w, dim3(nn.n3, B), blk, 0, s, dv, nn);
         hipLaunchKernelGGL(k_nnet_pred, dim3(nn.n4, B), blk, 0, s, dv, nn);

@@ -188,24 +188,31 @@ __device__ __forceinline__ void nnet_meas_matrix(const double *R, int L, int l, 
 
 #ifndef VA_NNET_ACT_ONLY
 // ------------------------------------------------------------------ K0: trial point
+// NN_PACK elements per thread, strided by the workgroup: at a plain evaluation point only the workgroups that
+// reach the parameter tail have work, and there are NN_PACK times fewer to dispatch and retire
 __global__ __launch_bounds__(NN_THREADS) void k_nnet_pack(const Dev dv, const NnetDev nn)
 {
     const int b = blockIdx.y;
-    const int i = blockIdx.x * NN_THREADS + threadIdx.x;
     int use_d; double stp, rf;
     if (!seed_live(dv, b, use_d, stp, rf)) return;
+    const int base = blockIdx.x * (NN_THREADS * NN_PACK);
+    if (!use_d && base + NN_THREADS * NN_PACK <= nn.NDens) return;          // workgroup-uniform
     const size_t vo = (size_t)b * dv.dm.ld;
-    if (i < nn.NDens) {
-        // at a plain evaluation point (no line-search step) the products read x itself
-        if (use_d) nn.Xw[vo + i] = trial(dv.x[vo + i], stp, dv.d[vo + i]);
-    } else if (i < nn.NDens + nn.NP) {
-        const int j = i - nn.NDens, k = nn.pmap[j];
-        double v;
-        if (k >= 0) {
-            v = dv.x[vo + nn.NDens + k];
-            if (use_d) v = trial(v, stp, dv.d[vo + nn.NDens + k]);
-        } else v = nn.Pfix[(size_t)b * nn.NP + j];
-        nn.Pw[(size_t)b * nn.NP + j] = v;
+#pragma unroll
+    for (int u = 0; u < NN_PACK; ++u) {
+        const int i = base + u * NN_THREADS + threadIdx.x;
+        if (i < nn.NDens) {
+            // at a plain evaluation point (no line-search step) the products read x itself
+            if (use_d) nn.Xw[vo + i] = trial(dv.x[vo + i], stp, dv.d[vo + i]);
+        } else if (i < nn.NDens + nn.NP) {
+            const int j = i - nn.NDens, k = nn.pmap[j];
+            double v;
+            if (k >= 0) {
+                v = dv.x[vo + nn.NDens + k];
+                if (use_d) v = trial(v, stp, dv.d[vo + nn.NDens + k]);
+            } else v = nn.Pfix[(size_t)b * nn.NP + j];
+            nn.Pw[(size_t)b * nn.NP + j] = v;
+        }
     }
 }
 
@@ -275,6 +282,8 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const Nne
 
 #ifndef VA_NNET_ACT_ONLY
 // ------------------------------------------------------------------ K2: dA/dX
+// RMM: full measurement matrices (their row walk costs registers the scalar-weight instantiation does not pay)
+template <bool RMM>
 __global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_x(const Dev dv, const NnetDev nn)
 {
     __shared__ double As[NN_TILE * PRK], Bs[NN_KC * PKR], red[16];
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_x(const Dev dv, const N
                     const double *Xt = use_d ? nn.Xw : dv.x;
                     const double diff = Xt[idx] - dat[(size_t)m * L + l];
                     const size_t rowb = vo + (size_t)m * nn.NDnet + tl.offn;
-                    if (R) {
+                    if (RMM) {
                         double share, deriv;
                         nnet_meas_matrix(R, L, l, diff, [&](int k) { return Xt[rowb + lidx[k]] - dat[(size_t)m * L + k]; }, share, deriv);
                         v[0] += share;
@@ -478,6 +487,9 @@ __global__ __launch_bounds__(64) void k_nnet_rows(const Dev dv, const NnetDev nn
 // formed on load.  Each transition's forward product is computed twice (by the owners of its two
 // ends): 4 instead of 3 tiny products per layer.  Waves = the 2 x 2 MFMA blocks of the 32x32 tile.
 constexpr int PS = NN_SMALL + 4;   // LDS pitch 36
+#ifndef NN_SMALL_WAVES
+#define NN_SMALL_WAVES 5
+#endif
 
 // acc[16x16 block (br, bc)] = A[. x K] B[K x .], K <= 4*nk; *_T: operand stored transposed in LDS
 template <bool A_T, bool B_T>
@@ -498,8 +510,12 @@ __device__ __forceinline__ d4 mma32(const double *As, const double *Bs, int br, 
 // up to the MFMA block) x pitch 36, two bias rows, reduction scratch
 inline size_t nnet_small_lds(int R) { return sizeof(double) * ((size_t)5 * R * PS + 2 * NN_SMALL + 20); }
 
-template <class ACT>
-__global__ __launch_bounds__(NN_THREADS) void k_nnet_small(const Dev dv, const NnetDev nn)
+// (5 waves per SIMD -- 1280 workgroups of the twin example = one resident round -- at 96 registers: the evaluation
+// itself needs 52; the folded tail, run by ONE wave per seed,
+// is what the allocator would otherwise size the whole kernel for (113), and spills a little instead.  Measured,
+// complete evaluation of the twin: 12.8 us; 13.1 at 8 waves / 64 registers; 13.7 with a separate tail launch)
+template <class ACT, bool RMM>
+__global__ __launch_bounds__(NN_THREADS, NN_SMALL_WAVES) void k_nnet_small(const Dev dv, const NnetDev nn)
 {
     extern __shared__ double sm[];
     const int R = nn.small;                       // rows staged per array
@@ -596,7 +612,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_small(const Dev dv, const N
             double g = gx[r] + q[r];
             if (l >= 0) {
                 const double diff = Xc[m * PS + col] - dat[(size_t)m * L + l];
-                if (R) {
+                if (RMM) {
                     double share, deriv;
                     nnet_meas_matrix(R, L, l, diff, [&](int k) { return Xc[m * PS + lidx[k]] - dat[(size_t)m * L + k]; }, share, deriv);
                     v[0] += share;
@@ -643,7 +659,19 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_small(const Dev dv, const N
     vfe = wave_sum(vfe);
     if (lane == 0) red[16 + wave] = vfe;
     wg_reduce4(v, red, tid);                       // (contains the barrier that publishes red[16..19])
-    if (tid == 0) put_row(dv, nn, b, n, v[0], red[16] + red[17] + red[18] + red[19], v[1], v[2], v[3]);
+    if (tid == 0) {
+        // the layer's partial row, written through: the seed's last workgroup reads the rows in this launch
+        double *row = dv.evp + ((size_t)b * dv.dm.nprow + n) * EP_N;
+        st_sc1(row + EP_ME, v[0]); st_sc1(row + EP_FE, red[16] + red[17] + red[18] + red[19]);
+        st_sc1(row + EP_GTD, v[1]); st_sc1(row + EP_GN2, v[2]); st_sc1(row + EP_GMAX, v[3]);
+    }
+    // the workgroup that completes the seed's NL rows forms A / runs the line-search step (va_epilogue.h):
+    // a small network's evaluation -- and its L-BFGS cycle's first launch -- is this one kernel
+#ifndef VA_NN_NOFOLD
+    if (dv.epi == EPI_NONE || wave != 0) return;
+    if (arrive_last(dv.cnt_eval + (size_t)b * CNT_STRIDE, (unsigned)NL, lane))
+        eval_epilogue<true>(dv, b, lane, reinterpret_cast<SeedHot *>(sm), dv.epi);
+#endif
 }
 
 
@@ -652,8 +680,10 @@ template <class ACT>
 inline void launch_nnet_act(const Dev &dv, const NnetDev &nn, hipStream_t s, bool small)
 {
     const int B = dv.dm.B;
-    if (small) hipLaunchKernelGGL(k_nnet_small<ACT>, dim3(nn.NL, B), dim3(NN_THREADS), nnet_small_lds(nn.small), s, dv, nn);
-    else hipLaunchKernelGGL(k_nnet_fwd<ACT>, dim3(nn.n1, B), dim3(NN_THREADS), 0, s, dv, nn);
+    if (small) {
+        if (nn.rmm_in) hipLaunchKernelGGL((k_nnet_small<ACT, true>), dim3(nn.NL, B), dim3(NN_THREADS), nnet_small_lds(nn.small), s, dv, nn);
+        else hipLaunchKernelGGL((k_nnet_small<ACT, false>), dim3(nn.NL, B), dim3(NN_THREADS), nnet_small_lds(nn.small), s, dv, nn);
+    } else hipLaunchKernelGGL(k_nnet_fwd<ACT>, dim3(nn.n1, B), dim3(NN_THREADS), 0, s, dv, nn);
 }
 
 }  // namespace va
