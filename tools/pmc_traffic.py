@@ -32,4 +32,4 @@ allrec[workload] = {"hbm_bytes_per_launch": int(round((2.0 * fetch_kb + write_kb
                     "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc.sh); "
                            "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md"}
 json.dump(allrec, open(path, "w"), indent=1, sort_keys=True)
-print(json.dumps(allrec[workload]))
+print(json.dumps({workload: allrec[workload]}))       # (copy this into profiles/pmc_traffic.json)

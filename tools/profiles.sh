@@ -8,7 +8,7 @@ cp $out/trace_eval/*/*kernel_stats.csv $out/eval_c3_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_ladder -- python3 bench.py --mode ladder --no-cpu > $out/ladder_c3.json 2> $out/trace_ladder.log
 cp $out/trace_ladder/*/*kernel_stats.csv $out/ladder_c3_kernel_stats.csv
 ./tools/pmc.sh $tag > $out/pmc_c3.txt 2>&1; grep "k_eval" $out/pmc_c3.txt | cut -c1-400
-python tools/pmc_traffic.py $tag lorenz96_D20_N1000_L7_B64_trapezoid > $out/pmc_traffic_c3.json; cat $out/pmc_traffic_c3.json
+python tools/pmc_traffic.py $tag lorenz96_D20_N1000_L7_B64_trapezoid > $out/pmc_traffic.json; cat $out/pmc_traffic.json     # -> profiles/pmc_traffic.json
 for w in c3 c3x4 c3x16 c3x64; do ./tools/sweep.sh $w 300 "0" 0; done > $out/sweep_batch.txt 2>&1; cat $out/sweep_batch.txt
 # state widths: built-in / traced + generated on the kernel the geometry picks / generated on the flat kernel
 for w in c3 w100 c4 w500; do st=300; [ $w = c3 ] || st=40; ./tools/sweep.sh $w $st "0" 0; ./tools/sweep.sh $w $st "0" 0 gen; ./tools/sweep.sh $w $st "0" 1 gen; done > $out/sweep_width.txt 2>&1; cat $out/sweep_width.txt
