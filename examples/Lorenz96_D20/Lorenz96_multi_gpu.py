@@ -18,7 +18,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-from varanneal_amd import parallel, twin, va_ode  # noqa: E402
+from varanneal_amd import twin, va_ode  # noqa: E402
 
 
 def main():
@@ -42,21 +42,22 @@ def main():
 
     D, N = args.D, args.N
     t, Y, _, Lidx = twin.make_twin(D, N)                          # identical bytes on every rank
-    lo, hi = parallel.seed_range(args.seeds, rank, world)
-    X0 = np.empty((hi - lo, N, D)); P0 = np.empty((hi - lo, 1))
-    for b, s in enumerate(range(lo, hi)):                         # RNG keyed by the GLOBAL seed index
-        X0[b], P0[b] = twin.initial_guess(N, D, s)
+    X0 = np.empty((args.seeds, N, D)); P0 = np.empty((args.seeds, 1))
+    for s in range(args.seeds):                                   # RNG keyed by the GLOBAL seed index: every
+        X0[s], P0[s] = twin.initial_guess(N, D, s)                # rank builds the same arrays, uses its block
 
     a = va_ode.Annealer()
     a.set_model(twin.l96, D)
     a.set_data(Y, t=t)
     t0 = time.time()
+    # n_seeds=: this rank anneals seeds [rank*n/world, (rank+1)*n/world) on its GPU as one batch; the single
+    # all-gather (RCCL) leaves every seed's tables on every rank in a.gathered
     a.anneal(X0, P0, 1.5, np.arange(args.nbeta), 4.0, 4e-6, Lidx, [0], dt_model=twin.DT, init_to_data=True,
              disc='trapezoid', method='L-BFGS-B',
              opt_args={'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000000, 'maxiter': 1000000},
-             device=local_rank, verbose=False)
-    local = {"A": a.A_array, "flags": a.exitflags.astype(np.int32), "k": a.minpaths[:, :, -1], "nfev": a.nfev_array}
-    res = parallel.gather_tables(local, args.seeds)               # the single RCCL gather
+             verbose=False, n_seeds=args.seeds, devices=[local_rank])
+    res = {"A": a.gathered["A"], "flags": a.gathered["exitflags"], "k": a.gathered["params"][:, :, 0],
+           "nfev": a.gathered["nfev"]}
     dt = time.time() - t0
     if rank == 0:
         best = int(np.argmin(res["A"][:, -1]))
