@@ -158,7 +158,17 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
         int K = 6;
         auto ntl = [&](int k) { return (long)d->batch * ((N + rows1 * k - 1) / (rows1 * k)); };
         if (ntl(K) < 256) K = 4;
-        else if (ntl(K) < 8 * 256) {
+        else if (ntl(K) >= 8 * 256) {
+            // many rounds of workgroups: the run length that stages the fewest rows (own + halo) per seed,
+            // longest on ties, up to 7 (8 drops the kernel to two waves per SIMD).  N = 1000, D = 20: K = 7
+            // (12 tiles x 9 rows per lane against 14 x 8 for K = 6): 370 vs 409 us at 4096 seeds
+            long best = -1;
+            for (int k = 5; k <= 7; ++k) {
+                if (sh && (k & 1)) continue;
+                const long cost = (long)((N + rows1 * k - 1) / (rows1 * k)) * (k + (sh ? 3 : 2));
+                if (best < 0 || cost <= best) { best = cost; K = k; }
+            }
+        } else {
             long best = -1;
             for (int k = 5; k <= 8; ++k) {
                 if (sh && (k & 1)) continue;              // Simpson-Hermite runs start on even rows
@@ -623,7 +633,9 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dm.rm = d->rm; dm.rf0 = d->rf0;
     dv.ups = UP_OLD + 4 * m; dv.max_beta = max_beta; dv.nbeta = 1;
     dv.evcols = EP_GP + d->NP <= 8 ? 8 : (EP_GP + d->NP <= 16 ? 16 : 32);
-    { const char *e = getenv("VA_GRAD_SC1"); dv.gaux = e ? atoi(e) : 1; }
+    // write-through gradient stores pay where the grid is one resident round and the end-of-kernel write-back
+    // of 10 MB is on the critical path (C3: -1.3 us); on large grids they cost 10 % (4096 seeds: 446 vs 404 us)
+    { const char *e = getenv("VA_GRAD_SC1"); dv.gaux = e ? atoi(e) : (h->fold ? 1 : 0); }
     { const char *e = getenv("VA_PRIO"); dv.prio = e ? atoi(e) : 1; }
     { const char *e = getenv("VA_SPEC"); dv.spec = e ? atoi(e) : 1; }
     dv.o.m = m; dv.o.maxiter = 15000; dv.o.maxls = 20; dv.o.maxfun = 15000; dv.o.ftol = 2.2204460492503131e-09; dv.o.gtol = 1e-5;
