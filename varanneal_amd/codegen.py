@@ -212,6 +212,19 @@ def generate_header(exprs, syms, D, NP, nstim, name="user", col=None, ghost=None
     return "\n".join(out) + "\n"
 
 
+def _translation_invariant(exprs, xs, D):
+    """every f_i is f_0 with the state indices shifted cyclically by i (structural comparison first: expressions
+    traced from one vectorised callable come out in the same form; SymPy's simplify only where that fails)"""
+    sp = _sympy()
+    if D < 3:
+        return False
+    for i in range(1, D):
+        e = exprs[0].xreplace({xs[j]: xs[(j + i) % D] for j in range(D)})
+        if e != exprs[i] and sp.simplify(e - exprs[i]) != 0:
+            return False
+    return True
+
+
 def _local_printer(xmap):
     """C printer that writes state symbols as the column kernel sees them: the lane's own value `x0`
     and the neighbour values `xn[k]` (xmap: symbol -> C text)."""
@@ -225,7 +238,7 @@ def _local_printer(xmap):
     return P()
 
 
-def column_form(exprs, syms, D, NP, nstim, max_dense=8):
+def column_form(exprs, syms, D, NP, nstim, max_dense=8, uniform=None):
     """The model in the form the wave-private column-run kernel wants (csrc/va_tile4.h), or None.
 
     A lane owns ONE state column i of a run of time rows; it reads its own value and NB neighbour
@@ -239,9 +252,7 @@ def column_form(exprs, syms, D, NP, nstim, max_dense=8):
     xs, ps = list(syms["x"]), list(syms["p"])
     uses_t = any(e.has(syms["t"]) for e in exprs)
 
-    def shifted(e, i):
-        return e.xreplace({xs[j]: xs[(j + i) % D] for j in range(D)})
-    uniform = D >= 3 and all(sp.simplify(shifted(exprs[0], i) - exprs[i]) == 0 for i in range(1, D))
+    uniform = _translation_invariant(exprs, xs, D) if uniform is None else uniform
     if uniform:
         cols = [j for j in range(1, D) if sp.diff(exprs[0], xs[j]) != 0]
         offs = sorted(((j + D // 2) % D) - D // 2 for j in cols)          # signed cyclic offsets
@@ -353,7 +364,7 @@ def column_form(exprs, syms, D, NP, nstim, max_dense=8):
     return dict(text="\n".join(out), uniform=uniform, offsets=offs, NE=NE, NB=NB)
 
 
-def ghost_form(exprs, syms, D, NP, nstim):
+def ghost_form(exprs, syms, D, NP, nstim, uniform=None):
     """A translation-invariant, autonomous stencil in the ghosted column form of the workgroup column-run
     kernel (csrc/va_tile3.h, k_eval3: wide states), or None.  A lane owns one column of rows staged with
     GHOST cyclic ghost columns on each side: f reads xc[off], and the adjoint is the GATHER
@@ -364,9 +375,7 @@ def ghost_form(exprs, syms, D, NP, nstim):
     if nstim > 0 or any(e.has(syms["t"]) for e in exprs) or D < 8:
         return None
 
-    def shifted(e, i):
-        return e.xreplace({xs[j]: xs[(j + i) % D] for j in range(D)})
-    if not all(sp.simplify(shifted(exprs[0], i) - exprs[i]) == 0 for i in range(1, D)):
+    if not (_translation_invariant(exprs, xs, D) if uniform is None else uniform):
         return None
     rel = lambda j: ((j + D // 2) % D) - D // 2
     f0 = exprs[0]
@@ -505,8 +514,9 @@ def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False, p_rows=False, col_
     col = ghost = None
     variant = None
     if col_variant is not None and not p_rows:
-        col = column_form(exprs, syms, D, NP, nstim)
-        ghost = ghost_form(exprs, syms, D, NP, nstim)
+        uniform = _translation_invariant(exprs, list(syms["x"]), D)
+        col = column_form(exprs, syms, D, NP, nstim, uniform=uniform) if D <= 64 else None   # (k_eval4: D <= 64)
+        ghost = ghost_form(exprs, syms, D, NP, nstim, uniform=uniform)
         variant = col_variant(col["NE"] if col else 0, ghost["GHOST"] if ghost else 0) if (col or ghost) else None
         if variant is None or variant[0] != 4:
             col = None
