@@ -75,7 +75,6 @@ struct va_problem_s {
     int device = 0, rhs = 0, keep_paths = 0;
     void (*user_launch)(const Dev *, void *) = nullptr;
     int (*user_prepare)(const Dev *) = nullptr;
-    unsigned long long epoch = 0;      // launches of folded evaluations so far (Dev::epoch)
     NnetActLaunch user_act = nullptr;  // generated activation module's launcher (nn.act >= NNET_USER)
     bool is_nnet = false;              // feed-forward-network action (va_nnet.hip) instead of an ODE path
     bool fold = false;                 // the evaluation kernel runs the tail itself (last arriver of each seed)
@@ -120,7 +119,6 @@ void run_eval(va_handle h, int epi)
         return;
     }
     h->dv.epi = epi;
-    h->dv.epoch = (double)(++h->epoch);       // (kernel arguments are copied at launch; S1 launches are never graph-replayed)
     if (h->is_nnet) { launch_nnet_eval(h->dv, h->nn, h->stream, h->user_act); return; }   // (small nets: k_nnet_small carries the tail)
     if (h->user_launch) h->user_launch(&h->dv, (void *)h->stream);
     else launch_eval(h->dv, h->rhs, h->stream);
@@ -637,7 +635,6 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     // of 10 MB is on the critical path (C3: -1.3 us); on large grids they cost 10 % (4096 seeds: 446 vs 404 us)
     { const char *e = getenv("VA_GRAD_SC1"); dv.gaux = e ? atoi(e) : (h->fold ? 1 : 0); }
     { const char *e = getenv("VA_PRIO"); dv.prio = e ? atoi(e) : 1; }
-    { const char *e = getenv("VA_SPEC"); dv.spec = e ? atoi(e) : 1; }
     dv.o.m = m; dv.o.maxiter = 15000; dv.o.maxls = 20; dv.o.maxfun = 15000; dv.o.ftol = 2.2204460492503131e-09; dv.o.gtol = 1e-5;
 
     {

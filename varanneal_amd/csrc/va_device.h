@@ -30,9 +30,6 @@ struct Dev {
     int prio;                      // 1: later-dispatched workgroups of a CU issue at higher priority
     int sticky;                    // measurement only (va_lbfgs_timed): last arrivers leave upd / dir set
     int evcols;                    // 8, 16 or 32 >= EP_GP + NP: columns of the eval partial rows in use
-    int spec;                      // k_eval4, S1: request the seed's partial rows at publish time (env VA_SPEC, default on)
-    double epoch;                  // S1 evaluations: a number the host changes with every launch; k_eval4 stamps the partial
-                                   // rows with it (column EP_GTD, unused there) so that rows read early can be told from stale ones
     ProblemPtrs pp;
     Opts o;
     // per-seed vectors, stride dm.ld (multiple of 16 doubles -> 128-byte aligned rows)

@@ -120,13 +120,7 @@ __device__ __forceinline__ void reduce_eval_block(const Dev &dv, int b, int lane
 
 // parameter tail of grad A (sum over tiles of the per-tile parameter partials) and its
 // share of the line-search sums.
-// What the calling kernel already holds in scalar registers (loaded in its prologue), so that the tail does
-// not start with a scalar-memory round trip: Pidx[0] (or -1) and the seed's rf_scale (valid if have).
-// have_rows: the calling wave requested the seed's partial rows earlier and checked them (k_eval4, S1): lane
-// (r, k) holds rows r and r + ng of column k in v0, v1.
-struct EpiHint { int pidx0; double rf_scale; bool have; bool have_rows; double v0, v1; };
-
-__device__ __forceinline__ void eval_tail(const Dev &dv, int b, int use_d, double *ev, double stp = 0.0, int pidx0 = -1)
+__device__ __forceinline__ void eval_tail(const Dev &dv, int b, int use_d, double *ev, double stp = 0.0)
 {
     const Dims &dm = dv.dm;
     double *gt = dv.gt + (size_t)b * dm.ld;
@@ -134,7 +128,7 @@ __device__ __forceinline__ void eval_tail(const Dev &dv, int b, int use_d, doubl
     for (int k = 0; k < dm.NPest; ++k) {
         // (select chain, not ev[EP_GP + idx]: a run-time index would put ev[] -- and with it every wave
         // of the evaluation kernel -- on scratch memory)
-        const int idx = (k == 0 && pidx0 >= 0) ? pidx0 : as_const(dv.pp.Pidx)[k];
+        const int idx = as_const(dv.pp.Pidx)[k];
         double g = 0.0;
 #pragma unroll
         for (int j = 0; j < RHS_MAX_NP; ++j) g = (idx == j) ? ev[EP_GP + j] : g;
@@ -151,31 +145,12 @@ __device__ __forceinline__ void eval_tail(const Dev &dv, int b, int use_d, doubl
     }
 }
 
-// The same reduction when the wave already holds the rows: lane (r, k) has rows r and r + ng of column k in
-// v0, v1 (0.0 where there is no such row; at most 2 * ng rows).  Same operations in the same order as
-// reduce_eval, hence the same bits.
-__device__ __forceinline__ void reduce_eval_regs(const Dev &dv, int lane, double v0, double v1, double *ev)
-{
-    const int nc = dv.evcols, ng = 64 / nc;
-    const int k = lane & (nc - 1);
-    double v = 0.0;
-    v = (k == EP_GMAX) ? fmax(v, v0) : v + v0;
-    v = (k == EP_GMAX) ? fmax(v, v1) : v + v1;
-    double tot = __shfl(v, k, 64);
-    for (int gi = 1; gi < ng; ++gi) {
-        const double o = __shfl(v, k + gi * nc, 64);
-        tot = (k == EP_GMAX) ? fmax(tot, o) : tot + o;
-    }
-#pragma unroll
-    for (int c = 0; c < EP_N; ++c) ev[c] = c < nc ? __shfl(tot, c, 64) : 0.0;
-}
-
 // The tail of one evaluation of seed b, run by ONE whole wave.  `sh`: 512 bytes of LDS private to
 // the calling wave.  SC1: the partial rows were written in this launch (read them around L1).
 // One memory round trip: the partial rows and the seed's state are requested together.
 template <bool SC1>
 __device__ __forceinline__ void eval_epilogue(const Dev &dv, int b, int lane, SeedHot *sh, int mode,
-                                              const double *ev_ready = nullptr, EpiHint hint = EpiHint{-1, 0.0, false, false, 0.0, 0.0})
+                                              const double *ev_ready = nullptr)
 {
     const Dims &dm = dv.dm;
     constexpr int NW8 = sizeof(SeedHot) / 8;
@@ -186,13 +161,11 @@ __device__ __forceinline__ void eval_epilogue(const Dev &dv, int b, int lane, Se
     if (ev_ready) {
 #pragma unroll
         for (int c = 0; c < EP_N; ++c) ev[c] = ev_ready[c];
-    } else if (hint.have_rows) reduce_eval_regs(dv, lane, hint.v0, hint.v1, ev);
-    else reduce_eval<SC1>(dv, b, lane, ev);
+    } else reduce_eval<SC1>(dv, b, lane, ev);
     if (mode == EPI_FINALIZE) {
         if (lane != 0) return;
-        eval_tail(dv, b, 0, ev, 0.0, hint.pidx0);
-        const double rfs = hint.have ? hint.rf_scale : as_const(static_cast<const SeedHot *>(dv.st + b))->rf_scale;
-        const double me = ev[EP_ME] * dm.cme, fe = ev[EP_FE] * dm.cfe * rfs;
+        eval_tail(dv, b, 0, ev);
+        const double me = ev[EP_ME] * dm.cme, fe = ev[EP_FE] * dm.cfe * as_const(static_cast<const SeedHot *>(dv.st + b))->rf_scale;
         dv.outA[b] = me + fe; dv.outme[b] = me; dv.outfe[b] = fe;
         return;
     }

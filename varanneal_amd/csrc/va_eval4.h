@@ -168,8 +168,6 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : (K <= 7 ? 3 : 2)) void k_eval4(c
     }
     const bool lsq = dv.epi != EPI_FINALIZE;                                  // launch-uniform
     unsigned old = 0;
-    double rv0 = 0.0, rv1 = 0.0;              // wave 0, S1: the seed's partial rows, requested at publish time
-    const bool spec_ok = dv.spec && dm.ntiles <= 2 * (64 / dv.evcols);
     double gvv[SUB][K];                       // the gradient stays in registers until the partial sums are out
     // The workgroup's row of partial sums: every wave reduces through the matrix pipe (max|g| through
     // DPP row moves) and lane 0 leaves the totals in the wave's LDS strip; after a workgroup barrier
@@ -191,7 +189,6 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : (K <= 7 ? 3 : 2)) void k_eval4(c
                 const double r0 = strip[lane], r1 = strip[g.WAVE + lane], r2 = strip[2 * g.WAVE + lane], r3 = strip[3 * g.WAVE + lane];
                 double v = (lane == EP_GMAX) ? fmax(fmax(r0, r1), fmax(r2, r3)) : ((r0 + r1) + r2) + r3;
                 if ((lane == EP_GTD && !use_d) || ((lane == EP_GTD || lane == EP_GN2 || lane == EP_GMAX) && !lsq)) v = 0.0;
-                if (lane == EP_GTD && !lsq) v = dv.epoch;        // S1: the unused column carries the launch's stamp
                 st_sc1(dv.evp + ((size_t)b * dm.ntiles + tile) * EP_N + lane, v);
             }
             if (dv.epi != EPI_NONE) {
@@ -199,17 +196,6 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : (K <= 7 ? 3 : 2)) void k_eval4(c
                 // is on its way while the wave goes on (gather phase / gradient stores)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) old = __hip_atomic_fetch_add(dv.cnt_eval + (size_t)b * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!lsq && spec_ok) {
-                    // S1: ask for the seed's rows NOW.  If this workgroup turns out to be the last to arrive,
-                    // every other row was complete before its own count -- almost always before these loads
-                    // too; the stamps say whether that held, and the rows are then at hand when the gradient
-                    // stores have been issued instead of one more round trip later.
-                    const int nc = dv.evcols, ng = 64 / nc;
-                    const int k = lane & (nc - 1), r = lane / nc;
-                    const double *p = dv.evp + (size_t)b * dm.ntiles * EP_N + k;
-                    if (k < EP_N && r < dm.ntiles) rv0 = ld_sc1(p + (size_t)r * EP_N);
-                    if (k < EP_N && r + ng < dm.ntiles) rv1 = ld_sc1(p + (size_t)(r + ng) * EP_N);
-                }
             }
         }
     };
@@ -281,18 +267,7 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : (K <= 7 ? 3 : 2)) void k_eval4(c
         STAMP(7);
         if (last) {
             if (lane == 0) __hip_atomic_store(dv.cnt_eval + (size_t)b * CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bool have_rows = false;
-            if (!lsq && spec_ok) {
-                const int nc = dv.evcols, ng = 64 / nc;
-                const int k = lane & (nc - 1), r = lane / nc;
-                bool ok = true;
-                if (k == EP_GTD) ok = (r >= dm.ntiles || rv0 == dv.epoch) && (r + ng >= dm.ntiles || rv1 == dv.epoch);
-                have_rows = __all(ok) != 0;
-            }
-            // (handing the tail Pidx[0] / rf_scale from the prologue's scalar registers as well was measured
-            // 0.35 us SLOWER at C3 -- 9.96 vs 9.60 us, same box -- and is not done)
-            const EpiHint hint{-1, 0.0, false, have_rows, rv0, rv1};
-            eval_epilogue<true>(dv, b, lane, reinterpret_cast<SeedHot *>(xsw), dv.epi, nullptr, hint);
+            eval_epilogue<true>(dv, b, lane, reinterpret_cast<SeedHot *>(xsw), dv.epi);
         }
     }
 #ifdef VA_STAMPS
