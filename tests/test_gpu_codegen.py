@@ -338,3 +338,39 @@ def test_wide_stencil_with_four_ghost_columns_on_device(disc):
         z[i] = XP[i]
         assert abs(g[0, i] - gi) <= 1e-10 * np.abs(g[0]).max()
     pr.close(); pf.close()
+
+
+def _stencil_5p(t, x, p):
+    """five parameters: more partial-sum columns than one 8-value reduction row of the workgroup kernel holds"""
+    return (p[0] * np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - p[1] * x + p[2]
+            + p[3] * np.roll(x, -1, 1) - p[4] * x ** 2)
+
+
+def test_ghosted_stencil_with_five_parameters_on_device():
+    D, NP, N, B = 100, 5, 120, 2
+    rng = np.random.RandomState(100)
+    Lidx = list(range(0, D, 9))
+    Y = rng.randn(N, len(Lidx)); P = np.array([1.0, 1.0, 8.0, 0.1, 0.02])
+    XP = np.append(2.0 * rng.randn(N * D), P)
+    m = codegen.module_for(_stencil_5p, D, NP, col_variant=lambda ne, gh: _capi.eval_plan(B, D, N, "trapezoid", ne, gh))
+    assert m["ghost"] is not None and m["col_variant"][0] == 3
+    rid = _capi.load_rhs_module(m["so"])
+    out = {}
+    for ek in (0, 1):
+        pr = _capi.Problem(B, D, N, Y, Lidx, 0.025, 4.0, 0.3, np.tile(P, (B, 1)), list(range(NP)), disc="trapezoid",
+                           rhs=rid, eval_kernel=ek)
+        assert pr.info()["eval_kernel"] == (3 if ek == 0 else 1)
+        out[ek] = pr.action_grad(np.stack([XP, XP * 0.99]), 2.0)
+        pr.close()
+    fun = lambda z: va_oracle.numpy_action_generic(_stencil_5p, z, D, N, Y, Lidx, 0.025, 4.0, 0.3 * 2.0, NP, list(range(NP)),
+                                                   P, "trapezoid")
+    A0 = fun(XP)[0]
+    for ek in (0, 1):
+        assert abs(out[ek][0][0] - A0) <= 1e-12 * A0
+    assert np.abs(out[0][3] - out[1][3]).max() <= 1e-12 * np.abs(out[1][3]).max()
+    z = XP.astype(complex)
+    for i in range(N * D, N * D + NP):                      # the five parameter derivatives against complex step
+        z[i] += 1e-30j
+        gi = fun(z)[0].imag / 1e-30
+        z[i] = XP[i]
+        assert abs(out[0][3][0, i] - gi) <= 1e-10 * np.abs(out[0][3][0]).max(), (i, out[0][3][0, i], gi)

@@ -623,7 +623,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
         const char *e = getenv("VA_FOLD");
         h->fold = e ? atoi(e) != 0 : (long)dm.B * dm.ntiles <= 8L * 256;
     }
-    dm.nprow = dm.emode == 3 ? dm.ntiles * (dm.NT / 64) : dm.ntiles;      // one partial row per wave (column-run kernel) / per workgroup
+    dm.nprow = dm.ntiles;                                                    // one partial row per workgroup
     dm.chunk = VEC_CHUNK; dm.nchunks = (dm.ld + VEC_CHUNK - 1) / VEC_CHUNK;
     dm.dt = d->dt_model;
     dm.cme = d->L > 0 ? 1.0 / ((double)dm.L * dm.N_data) : 0.0;

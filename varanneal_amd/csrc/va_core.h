@@ -57,7 +57,7 @@ struct Dims {
     int ghost;                 // column-run kernel (emode 3): ghost columns per side = RHS::GHOST (2 for Lorenz-96)
     int emode, RY, NT, maxr;   // eval kernel: 1 = flat-mapped, 3 = column-run (va_tile3.h), 4 = wave-private column runs (va_tile4.h)
     unsigned long long obsmask; // bit i set <=> state column i is observed (D <= 64; Lidx ascending on the device)
-    int nprow;                 // eval partial rows per seed (ntiles, or ntiles*4 when every wave writes its own)
+    int nprow;                 // eval partial rows per seed (= ntiles: one per workgroup; the network kernels have their own count)
     // time-dependent parameters (va_ode.py:170-188): P is (N, NPt) per seed and the vector is
     // [X (N*D) | p_est (N*NPe), time-major].  Then ND = N*D + N*NPe and NP = NPest = 0 for the
     // L-BFGS kernels (one flat run), and the flat tile kernel uses NPt / NPe.  Static: tdp = 0,

@@ -9,6 +9,10 @@
 
 namespace va {
 
+// per-wave reduction strip of k_eval3: 4 rows of ST totals + ST wave totals, ST = 8 values for models with up to
+// 3 parameters (EP_GP + NP <= 8), else 32 (EP_N <= 32)
+VA_HD constexpr int t3_strip_stride(int np) { return EP_GP + np <= 8 ? 8 : 32; }
+
 // ------------------------------------------------------------------ K1 (wide states): column-run
 template <class RHS, int DISC, int K, int DC, int NTMAX>
 __global__ __launch_bounds__(NTMAX) void k_eval3(const Dev dv)
@@ -100,36 +104,46 @@ __global__ __launch_bounds__(NTMAX) void k_eval3(const Dev dv)
         else tile3_grad<RHS, DISC, K, false, DC>(dm, t, rg, acc);
     }
 
-    // every wave writes its own partial row (no workgroup barrier: a __syncthreads here would
-    // also wait for the gradient stores to land).  Rows of 16 lanes reduce through DPP moves (no
-    // LDS latency); the four row totals of each value meet in a wave-private LDS strip, and
-    // lane k finishes value k.
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *prow = dv.evp + (((size_t)b * dm.ntiles + tile) * (nt >> 6) + wave) * EP_N;
-    double *strip = smem + SE + tile3_s_elems(K, D, G, RY) + wave * 64;      // [4 rows][8 values]; 512 B per wave
+    // ONE row of partial sums per workgroup.  Rows of 16 lanes reduce through DPP moves (no LDS latency);
+    // the four row totals of each value meet in a wave-private LDS strip and lane k finishes value k of
+    // the wave; after a workgroup barrier wave 0 adds the waves' values in wave order and stores the row
+    // (write-through: the tail reads it in this launch when folded).  A quarter (a sixteenth for
+    // 1024-thread groups) of the rows every tail has to read back.
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nt >> 6;
+    double *strips = smem + SE + tile3_s_elems(K, D, G, RY);
+    constexpr int ST = t3_strip_stride(RHS::NP);
+    double *strip = strips + wave * (5 * ST);             // [4 rows of 16 lanes][ST values], then the wave's ST totals
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
         const double r = (k == EP_GMAX) ? row16_reduce<true>(acc.v[k]) : row16_reduce<false>(acc.v[k]);
-        if ((lane & 15) == 0) strip[(lane >> 4) * 8 + k] = r;
+        if ((lane & 15) == 0) strip[(lane >> 4) * ST + k] = r;
     }
     wave_sync_lds();
     if (lane < KP) {
-        const double r0 = strip[lane], r1 = strip[8 + lane], r2 = strip[16 + lane], r3 = strip[24 + lane];
-        st_sc1(prow + lane, (lane == EP_GMAX) ? fmax(fmax(r0, r1), fmax(r2, r3)) : ((r0 + r1) + r2) + r3);
+        const double r0 = strip[lane], r1 = strip[ST + lane], r2 = strip[2 * ST + lane], r3 = strip[3 * ST + lane];
+        strip[4 * ST + lane] = (lane == EP_GMAX) ? fmax(fmax(r0, r1), fmax(r2, r3)) : ((r0 + r1) + r2) + r3;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    if (lane < KP) {
+        double v = strips[4 * ST + lane];
+        for (int w2 = 1; w2 < nw; ++w2) {
+            const double o = strips[w2 * (5 * ST) + 4 * ST + lane];
+            v = (lane == EP_GMAX) ? fmax(v, o) : v + o;
+        }
+        st_sc1(dv.evp + ((size_t)b * dm.ntiles + tile) * EP_N + lane, v);
     }
     if (dv.epi == EPI_NONE) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wave == 0 && arrive_last(dv.cnt_eval + (size_t)b * CNT_STRIDE, (unsigned)dm.ntiles, lane))
-        eval_epilogue<true>(dv, b, lane, reinterpret_cast<SeedHot *>(strip), dv.epi);
+    if (arrive_last(dv.cnt_eval + (size_t)b * CNT_STRIDE, (unsigned)dm.ntiles, lane))
+        eval_epilogue<true>(dv, b, lane, reinterpret_cast<SeedHot *>(strips), dv.epi);
 }
-
 
 inline size_t eval3_lds_bytes(const Dims &dm)
 {
     const int HL = dm.disc == DISC_SH ? 2 : 1;
     const size_t elems = (size_t)tile3_stage_elems(dm.maxr, dm.D, dm.ghost, dm.RY, HL + 1) + tile3_s_elems(dm.maxr, dm.D, dm.ghost, dm.RY);
-    return sizeof(double) * (elems + (size_t)(dm.NT / 64) * 64);
+    const size_t strips = (size_t)(dm.NT / 64) * 5 * t3_strip_stride(dm.NP);      // (>= 512 B: the tail stages the seed's state there)
+    return sizeof(double) * (elems + (strips < 64 ? 64 : strips));
 }
 
 // launch one instantiation (the caller has checked that dv.dm's geometry matches it)

@@ -33,7 +33,8 @@ size_t eval_lds_bytes(const Dev &dv)
     if (dm.emode == 1) return eval_flat_lds_bytes(dm);
     const int HL = dm.disc == DISC_SH ? 2 : 1;
     const size_t elems = (size_t)tile3_stage_elems(dm.maxr, dm.D, dm.ghost, dm.RY, HL + 1) + tile3_s_elems(dm.maxr, dm.D, dm.ghost, dm.RY);
-    return sizeof(double) * (elems + (size_t)(dm.NT / 64) * 64);
+    const size_t strips = (size_t)(dm.NT / 64) * 5 * t3_strip_stride(dm.NP);      // (>= 512 B: the tail stages the seed's state there)
+    return sizeof(double) * (elems + (strips < 64 ? 64 : strips));
 }
 
 int eval_grid(const Dims &dm) { return ((dm.B * dm.ntiles + 7) / 8) * 8; }
