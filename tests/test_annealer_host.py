@@ -238,10 +238,18 @@ def test_nakl_bounded_ladder_host_flow(monkeypatch):
     from models.nakl import nakl
     c = load_npz_cases("nakl.npz")["g5_nakl_ladder_SH_N101"]
 
+    from varanneal_amd import codegen
+    built, real_module_for = {}, codegen.module_for
+
+    def recording_module_for(*a, **k):                      # remember the generated header of the module just built
+        built["last"] = real_module_for(*a, **k)
+        return built["last"]
+
     def fake_load(path):
-        d, b = os.path.split(path)                          # libva_rhs_<key>.so -> rhs_<key>.h
-        EmulBackedProblem.headers[1000 + len(EmulBackedProblem.headers)] = os.path.join(d, b[6:-3] + ".h")
+        assert path == built["last"]["so"]
+        EmulBackedProblem.headers[1000 + len(EmulBackedProblem.headers)] = built["last"]["header"]
         return 1000 + len(EmulBackedProblem.headers) - 1
+    monkeypatch.setattr(codegen, "module_for", recording_module_for)
     monkeypatch.setattr(_capi, "load_rhs_module", fake_load)
     monkeypatch.setattr(_capi, "Problem", EmulBackedProblem)
     a = va_ode.Annealer()

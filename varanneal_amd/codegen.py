@@ -474,8 +474,10 @@ def build_module(header_text, verbose=False, col_variant=None, compile=True):
     if col_variant is not None:
         defs = ["-DVA_USER_EK=%d" % col_variant[0], "-DVA_USER_DISC=%d" % col_variant[1], "-DVA_USER_K=%d" % col_variant[2],
                 "-DVA_USER_W=%d" % col_variant[3]]
+    # (the header is named by its text alone: the same model built for several kernel variants shares it)
+    hkey = hashlib.sha1((header_text + _core_fingerprint()).encode()).hexdigest()[:16]
     key = hashlib.sha1((header_text + _core_fingerprint() + " ".join(defs)).encode()).hexdigest()[:16]
-    hdr = os.path.join(CACHE, "rhs_%s.h" % key)
+    hdr = os.path.join(CACHE, "rhs_%s.h" % hkey)
     so = os.path.join(CACHE, "libva_rhs_%s.so" % key)
     # Several ranks may build the same module at once (one process per GPU, each calling
     # anneal_init): every process writes to names of its own and publishes with an atomic rename, so
