@@ -456,8 +456,11 @@ def check_against(f, exprs, syms, D, NP, nstim, stim_ndim=1, trials=3, rtol=1e-1
                                  "(does it branch on its inputs?): %s vs %s" % (got, want[r]))
 
 
+BUILD_TAG = "sched=iterative-maxocc"      # part of every module's cache key: a flag change rebuilds them
+
+
 def _core_fingerprint():
-    h = hashlib.sha1()
+    h = hashlib.sha1(BUILD_TAG.encode())
     for fn in ("va_core.h", "va_device.h", "va_eval_flat.h", "va_eval3.h", "va_eval4.h", "va_epilogue.h", "va_tile2.h", "va_tile3.h",
                "va_tile4.h", "va_user_rhs.hip"):
         with open(os.path.join(CSRC, fn), "rb") as fh:
@@ -490,7 +493,8 @@ def build_module(header_text, verbose=False, col_variant=None, compile=True):
     if not compile:
         return None, hdr                                   # (header only: the CPU emulator of the tests compiles it itself)
     if not os.path.exists(so):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
+               "-amdgpu-sched-strategy=iterative-maxocc",            # (as the library: varanneal_amd/_build.py)
                "-Wno-unused-function", "-I", CSRC, '-DVA_USER_RHS_HEADER="%s"' % hdr] + defs + [
                "-o", so + tag, os.path.join(CSRC, "va_user_rhs.hip")]
         if verbose:
@@ -580,7 +584,7 @@ def activation_header(g, dg, z, name="act"):
 
 
 def _act_fingerprint():
-    h = hashlib.sha1()
+    h = hashlib.sha1(BUILD_TAG.encode())
     for fn in ("va_core.h", "va_device.h", "va_eval_flat.h", "va_epilogue.h", "va_nnet.h", "va_nnet_kernels.h",
                "va_user_act.hip"):
         with open(os.path.join(CSRC, fn), "rb") as fh:
@@ -603,6 +607,7 @@ def activation_module_for(f, verbose=False):
         os.replace(hdr + tag, hdr)
     if not os.path.exists(so):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function",
+               "-mllvm", "-amdgpu-sched-strategy=iterative-maxocc",
                "-I", CSRC, '-DVA_USER_ACT_HEADER="%s"' % hdr, "-o", so + tag, os.path.join(CSRC, "va_user_act.hip")]
         if verbose:
             print(" ".join(cmd), flush=True)
