@@ -71,11 +71,11 @@ int va_user_prepare_variant(const va::Dev *dv)
 #elif defined(VA_USER_VARIANT)
 void va_user_launch_variant(const va::Dev *dv, void *stream)
 {
-    va::launch_eval3_one<va::RhsUserG, VA_USER_DISC, VA_USER_K, 0, VA_USER_W>(*dv, (hipStream_t)stream);
+    va::launch_eval3_one<va::RhsUserG, VA_USER_DISC, VA_USER_K, va::RhsUserG::D, VA_USER_W>(*dv, (hipStream_t)stream);     // (D compiled in, as the built-in's D = 200)
 }
 int va_user_prepare_variant(const va::Dev *dv)
 {
-    return (int)va::prepare_eval3_one<va::RhsUserG, VA_USER_DISC, VA_USER_K, 0, VA_USER_W>(*dv);
+    return (int)va::prepare_eval3_one<va::RhsUserG, VA_USER_DISC, VA_USER_K, va::RhsUserG::D, VA_USER_W>(*dv);
 }
 #endif
 
