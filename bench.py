@@ -71,12 +71,15 @@ def kernel_name(D, info, generated=False):
 
 
 def kernel_source_hash():
-    """content hash of the device sources: stamps a counter measurement with the code it was taken on"""
+    """content hash of what the ODE evaluation kernels are built from (their sources and the build flags):
+    stamps a counter measurement with the code it was taken on.  The translation units of generated modules and
+    of the network action are not part of the measured kernels and do not invalidate it."""
     import hashlib
-    h = hashlib.sha1()
+    from varanneal_amd import _build
+    h = hashlib.sha1(" ".join(_build.FLAGS).encode())
     d = os.path.join(ROOT, "varanneal_amd", "csrc")
     for fn in sorted(os.listdir(d)):
-        if fn.endswith((".h", ".hip")):
+        if fn.endswith((".h", ".hip")) and not fn.startswith(("va_user_", "va_nnet")):
             with open(os.path.join(d, fn), "rb") as fh:
                 h.update(fn.encode()); h.update(fh.read())
     return h.hexdigest()[:16]
