@@ -92,3 +92,29 @@ def test_c_abi_gather_of_result_tables():
     assert table.shape == (B, nb, 4) and np.array_equal(table[:, :, 0], r["A"]) and np.array_equal(table[:, :, 1], r["me"])
     assert np.array_equal(table[:, :, 2], r["fe"]) and np.array_equal(table[:, :, 3], r["pest"][:, :, 0])
     assert np.array_equal(st, r["status"])
+
+
+def test_wide_builtin_model_runs_a_module_with_the_width_compiled_in(monkeypatch):
+    """set_model(l96, D = 100): the Annealer generates a module from the registry's own callable (state width
+    compiled into the workgroup kernel); VARANNEAL_AMD_JIT_WIDE=0 keeps the library's run-time-D kernel.  Same
+    kernel phases, same arithmetic up to the order of three additions: one rung agrees to 1e-9."""
+    from varanneal_amd import twin, va_ode
+    D, N, B = 100, 160, 4
+    Lidx = list(range(0, D, 4))
+    t, Y, _, _ = twin.make_twin(D, N, Lidx=Lidx)
+    X0 = np.empty((B, N, D)); P0 = np.empty((B, 1))
+    for s in range(B):
+        X0[s], P0[s] = twin.initial_guess(N, D, s, Y, Lidx)
+    res = {}
+    for jit in ("1", "0"):
+        monkeypatch.setenv("VARANNEAL_AMD_JIT_WIDE", jit)
+        a = va_ode.Annealer()
+        a.set_model(twin.l96, D)
+        a.set_data(Y, t=t)
+        a.anneal(X0.copy(), P0.copy(), 1.5, [0], 4.0, 4e-6, Lidx, [0], disc="trapezoid",
+                 opt_args={'gtol': 1e-8, 'ftol': 1e-8, 'maxiter': 20, 'maxfun': 1000}, verbose=False)
+        assert a._pb.info()["eval_kernel"] == 3
+        assert (getattr(a, "_rhs_module", None) is not None) == (jit == "1")
+        res[jit] = (a.A_array.copy(), a.nit_array.copy())
+        a.close()
+    assert np.array_equal(res["1"][1], res["0"][1]) and np.allclose(res["1"][0], res["0"][0], rtol=1e-9)
