@@ -313,7 +313,8 @@ def nnet_main(args, rank, local_rank, world, dist, torch):
         "data": "synthetic (sigmoid twin network, sigma=0.005, seeded)",
         "config": {"workload": w["name"], "seeds_per_gpu": B, "structure": [int(v) for v in s], "M": M,
                    "n_var": int(XP.shape[1]), "parallelism": "seeds sharded, %d per GPU" % B,
-                   "final_gather_ms": gather_ms},
+                   "final_gather_ms": gather_ms, "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+                   "env": bench_env()},
         "roofline": {"bound": "mfma", "achieved": flops / ks / 1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": flops / ks / 1e12 / F64_MFMA_PEAK_TFLOPS, "traffic": None,
                      "kernel": "k_nnet_fwd + k_nnet_bwd_x + k_nnet_bwd_w (+ pack, pred): one evaluation",
@@ -379,6 +380,49 @@ def ladder_mode(args, pb0, XP, P, D, N, B, Y, Lidx, device):
     pb.close()
 
 
+def launch_ranks(n, argv, port=None):
+    """Run this script as n ranks of ONE node under torch.distributed.run (the same command line the driver uses)
+    and return the job's exit code.  Called before anything has touched the GPU: the ranks are child processes."""
+    import socket
+    import subprocess
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def bench_env():
+    """every VA_* / VARANNEAL_AMD_* variable set in this process: they select kernels or code paths, so they are
+    part of what was measured (config.env)"""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith(("VA_", "VARANNEAL_AMD_"))}
+
+
+def dry_run(args, rank, world, env_set):
+    """The launcher / rank bookkeeping without a GPU (tests/test_bench_launcher.py): joins the process group, counts
+    its ranks with an all-reduce, and rank 0 prints the fields of the contract line that depend on the launch."""
+    ranks = 1
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+        one = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(one)
+        ranks = int(one[0])
+        assert ranks == dist.get_world_size() == args.gpus
+        dist.destroy_process_group()
+    if rank == 0:
+        w = WORKLOADS.get(args.workload) or NNET_WORKLOADS[args.workload]
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "scaling": "weak", "config": {"workload": w["name"], "seeds_per_gpu": w["B"],
+                                                        "rccl_ranks": ranks, "env": env_set}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -396,18 +440,44 @@ def main():
                     help="run the workload's Lorenz-96 as a user would supply it: a Python callable traced and "
                          "compiled by varanneal_amd.codegen (not the built-in right-hand side)")
     ap.add_argument("--eval-kernel", type=int, default=0, help="0 auto, 1 flat-mapped, 3 workgroup column runs, 4 wave-private column runs")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher rehearsal without a GPU: every rank joins the process group (--backend gloo), "
+                         "rank 0 prints the contract line's bookkeeping fields (n_gpus, config.rccl_ranks) and nothing is timed")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of a multi-rank run (nccl = RCCL; gloo only for the CPU rehearsal "
+                         "of the launcher in tests/)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
-    import torch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks (one process per GPU) as CHILD processes of a
+        # launcher that never touches the GPU, and leave with their exit code.  The reference's counterpart of
+        # this fan-out is its array job: examples/nnet_barimages/SGEcluster/submit_multiM.sh:14-30.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the job has WORLD_SIZE=%d ranks\n" % (args.gpus, world))
+        sys.exit(2)
+    env_set = bench_env()
+
+    if args.dry_run:
+        dry_run(args, rank, world, env_set)
+        return
+
+    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            sys.stderr.write("bench.py: process group has %d ranks, --gpus %d\n" % (dist.get_world_size(), args.gpus))
+            sys.exit(2)
     torch.cuda.set_device(local_rank)
 
     if args.workload in NNET_WORKLOADS:
@@ -456,7 +526,8 @@ def main():
             "data": "synthetic (Lorenz-96 twin experiment, k=8.17, sigma=0.5, seeded)",
             "config": {"workload": w["name"], "seeds_per_gpu": B, "D": D, "N": N, "L": len(Lidx),
                        "disc": "trapezoid", "tile_rows": info["tile_rows"], "ntiles": info["ntiles"],
-                       "parallelism": "seeds sharded, %d per GPU" % B, "final_gather_ms": gather_ms},
+                       "parallelism": "seeds sharded, %d per GPU" % B, "final_gather_ms": gather_ms,
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "env": env_set},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "step": "complete S1 evaluation: A, me, fe formed in the same launch (va_epilogue.h)",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(w["name"]),
