@@ -65,6 +65,8 @@ def kernel_name(D, info, generated=False):
     ek, K = info["eval_kernel"], info["run_rows"]
     if ek == 4:
         return "k_eval4<%s,trapezoid,K=%d,D=%d>" % ("RhsUserCol" if generated else "RhsL96s", K, D)
+    if ek == 5:
+        return "k_eval5<%s,trapezoid,D=%d>" % ("RhsUserCol" if generated else "RhsL96s", D)
     if ek == 3:
         return "k_eval3<%s,trapezoid,K=%d,D=%d>" % ("RhsUserG" if generated else "RhsL96g", K, D)
     return "k_eval<%s,trapezoid>" % ("RhsUser" if generated else "RhsL96")
@@ -439,7 +441,7 @@ def main():
     ap.add_argument("--generated", action="store_true",
                     help="run the workload's Lorenz-96 as a user would supply it: a Python callable traced and "
                          "compiled by varanneal_amd.codegen (not the built-in right-hand side)")
-    ap.add_argument("--eval-kernel", type=int, default=0, help="0 auto, 1 flat-mapped, 3 workgroup column runs, 4 wave-private column runs")
+    ap.add_argument("--eval-kernel", type=int, default=0, help="0 auto, 1 flat-mapped, 3 workgroup column runs, 4 wave-private column runs, 5 streaming column strips")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal without a GPU: every rank joins the process group (--backend gloo), "
                          "rank 0 prints the contract line's bookkeeping fields (n_gpus, config.rccl_ranks) and nothing is timed")

@@ -107,6 +107,7 @@ namespace {
 // evaluation is several kernels, so its tail stays a launch of its own.
 void run_eval(va_handle h, int epi)
 {
+    h->dv.lsrun = epi == EPI_LS ? 1 : 0;       // (S1 evaluations put every seed in PH_START: no line-search points)
     if (h->is_nnet ? !h->nn.small : !h->fold) {
         // (large grids: a workgroup that waits for its arrival to come back holds its LDS and wave
         // slots ~1 us longer, which costs more than the 64-wave tail kernel it saves)
@@ -129,7 +130,9 @@ void run_eval(va_handle h, int epi)
 // module's RhsUserCol::NE), or 0 when the model has none; ghost: ghost columns per side of its ghosted
 // form for the workgroup column-run kernel (RhsL96g::GHOST; a module's RhsUserG::GHOST), or 0.  A model
 // with neither runs the flat kernel.
-void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, int ghost)
+// reach5: {xl, xr, gl, gr} of a column form that the streaming kernel (emode 5, va_tile5.h) may run, or NULL.
+void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, int ghost,
+                        const int *reach5 = nullptr, Geo5 *g5 = nullptr, std::vector<int> *ystrip = nullptr)
 {
     bool user_rhs = ne <= 0 && ghost <= 0;
     dm.ghost = ghost > 0 ? ghost : 2;
@@ -142,8 +145,54 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
     // auto: wave-private column runs for narrow states that fill a wave, workgroup column runs up
     // to 1024 columns, flat mapping beyond
     if (dm.emode == 2) dm.emode = 3;                      // (the row-strided kernel of round 1 is gone)
-    if (dm.emode < 1 || dm.emode > 4) dm.emode = (tile4_ok(D) && ne > 0) ? 4 : ((D <= 1024 && ghost > 0) ? 3 : 1);
+    // streaming column strips: wide even states, a column form, a one-step discretisation, scalar weights with
+    // data at every model time (what every BASELINE config has); anything else keeps the tile kernels
+    const bool ws5 = d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1 && d->L >= 1;
+    const bool can5 = reach5 && g5 && ystrip && !user_rhs && ne > 0 && !sh && ws5 && D > 64 &&
+                      tile5_ok(D, reach5[0], reach5[1], reach5[2], reach5[3]);
+    if (dm.emode == 5 && !can5) dm.emode = 0;
+    if (dm.emode < 1 || dm.emode > 5) dm.emode = (tile4_ok(D) && ne > 0) ? 4 : (can5 ? 5 : ((D <= 1024 && ghost > 0) ? 3 : 1));
     if (user_rhs) dm.emode = 1;                           // no column form (or a case only the flat kernel carries)
+    if (dm.emode == 5) {
+        Geo5 g = tile5_cols(D, reach5[0], reach5[1], reach5[2], reach5[3]);
+        // segments: as many workgroups as the chip holds at once (four 4-wave groups per CU: 128 registers, 40 KiB
+        // of LDS each), every one with the same number of rows; at least 32 rows per segment
+        const long per_row = (long)d->batch * g.NSG;
+        long nseg = (4L * 256) / per_row;
+        if (d->tile_rows > 0) nseg = (N + d->tile_rows - 1) / d->tile_rows;
+        if (nseg > N / 32) nseg = N / 32;
+        if (nseg < 1) nseg = 1;
+        g.SEGL = (int)((N + nseg - 1) / nseg);
+        g.SEGL = (g.SEGL + 1) & ~1;
+        g.NSEG = (N + g.SEGL - 1) / g.SEGL;
+        // observation rows per strip: the data columns of the strip's own state columns (Lidx ascending on the device)
+        std::vector<int> ls(d->Lidx, d->Lidx + d->L);
+        std::sort(ls.begin(), ls.end());
+        ystrip->assign(2 * g.NS, 0);
+        g.YPMAX = 1;
+        for (int s5 = 0; s5 < g.NS; ++s5) {
+            const int c0 = s5 * g.CW, c1 = std::min(D, c0 + g.CW);
+            const int l0 = (int)(std::lower_bound(ls.begin(), ls.end(), c0) - ls.begin());
+            const int l1 = (int)(std::lower_bound(ls.begin(), ls.end(), c1) - ls.begin());
+            int start = l0 & ~1;
+            int yp = (l1 - start + 1) / 2;
+            if (yp < 1) yp = 1;                           // (every staging instruction has an active lane: the queue counts are exact)
+            (*ystrip)[2 * s5] = start; (*ystrip)[2 * s5 + 1] = yp;
+            if (yp > g.YPMAX) g.YPMAX = yp;
+        }
+        // ring depth: the deepest that still lets four workgroups share a CU's 160 KiB
+        auto fits = [&](int nslot, bool lsr) { return (size_t)g.WPG * tile5_wave_doubles(g, nslot, lsr, ne) * sizeof(double) <= 40 * 1024; };
+        g.nslot = fits(8, false) ? 8 : (fits(6, false) ? 6 : 4);
+        g.nslot_ls = fits(6, true) ? 6 : (fits(4, true) ? 4 : 3);
+        if (const char *e = getenv("VA_E5_NSLOT")) { const int v = atoi(e); if (v == 4 || v == 6 || v == 8) g.nslot = v; }
+        if (g.YPMAX <= 32 && !(d->L & 1)) {          // (odd L: data rows alternate between 16-byte phases -- not staged by 16-byte pieces)
+            *g5 = g;
+            dm.RY = 0; dm.NT = 64 * g.WPG; dm.maxr = 2; dm.T = g.SEGL;
+            dm.ntiles = g.NSEG * g.NSG;
+            return;
+        }
+        dm.emode = (D <= 1024 && ghost > 0) ? 3 : 1;
+    }
     if (dm.emode == 4 && (!tile4_ok(D) || ne <= 0)) dm.emode = 3;
     if (dm.emode == 3 && ghost <= 0) dm.emode = 1;
     if (dm.emode == 3 && D > 1024) dm.emode = 1;          // column runs: a lane per column
@@ -602,7 +651,11 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dm.bounded = (d->lower && d->upper) ? 1 : 0;
     if (tdp) { dm.ND = dm.N * (dm.D + dm.NPe); dm.NP = 0; dm.NPest = 0; }   // one flat run for the L-BFGS kernels
     dm.ld = ((dm.ND + dm.NPest + 15) / 16) * 16;
-    if (!user) pick_eval_geometry(d, dm, dv.g4, RhsL96s::NE, RhsL96g::GHOST);
+    std::vector<int> ystrip_h;
+    if (!user) {
+        const int reach5[4] = {t5_xl<RhsL96s>(), t5_xr<RhsL96s>(), t5_gl<RhsL96s>(), t5_gr<RhsL96s>()};
+        pick_eval_geometry(d, dm, dv.g4, RhsL96s::NE, RhsL96g::GHOST, reach5, &dv.g5, &ystrip_h);
+    }
     else {
         // the module holds ONE instantiation of a column-run kernel (va_eval_plan named it when the module
         // was generated); a problem that calls for any other geometry runs the module's flat kernel
@@ -639,7 +692,8 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
 
     {
         // the flat kernel keeps 3 staged arrays of (T + halo) rows: up to the CU's 160 KiB
-        const size_t need = eval_lds_bytes(dv);
+        size_t need = eval_lds_bytes(dv);
+        if (dm.emode == 5) { dv.lsrun = 1; need = std::max(need, eval_lds_bytes(dv)); dv.lsrun = 0; }
         const size_t cap = 160 * 1024;
         if (need > cap) {
             const int T = dm.T, D = dm.D;
@@ -661,7 +715,10 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     double *Y_d = nullptr, *rm_d = nullptr, *rf_d = nullptr, *P_d = nullptr, *t_d = nullptr, *st_d = nullptr;
 #define TRY(x) do { rc = (x); if (rc) { va_problem_destroy(h); return rc; } } while (0)
     TRY(h->alloc(&lmap_d, dm.D));
-    TRY(h->alloc(&Y_d, (size_t)dm.N_data * dm.L));
+    // (two rows + a line of padding: the streaming kernel stages observation rows by whole 16-byte pieces, two rows at a time)
+    TRY(h->alloc(&Y_d, (size_t)dm.N_data * dm.L + 2 * (size_t)dm.L + 16));
+    int *ystrip_d = nullptr;
+    if (dm.emode == 5) TRY(h->alloc(&ystrip_d, ystrip_h.size()));
     const size_t np_seed = tdp ? (size_t)dm.N * dm.NPt : (size_t)dm.NPt;       // parameters stored per seed
     TRY(h->alloc(&pidx_d, dm.NPe));
     TRY(h->alloc(&P_d, B * np_seed));
@@ -710,6 +767,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
 #define H2D(dst, src, n, T) do { hipError_t e_ = hipMemcpyAsync(dst, src, sizeof(T) * (n), hipMemcpyHostToDevice, h->stream); \
         if (e_ != hipSuccess) { va_problem_destroy(h); return fail(VA_EHIP, "H2D %s: %s", #dst, hipGetErrorString(e_)); } } while (0)
     H2D(lmap_d, lmap.data(), dm.D, int);
+    if (dm.emode == 5) { H2D(ystrip_d, ystrip_h.data(), ystrip_h.size(), int); dv.ystrip = ystrip_d; }
     H2D(Y_d, Ys.data(), (size_t)dm.N_data * dm.L, double);
     if (dm.NPe) H2D(pidx_d, d->Pidx, dm.NPe, int);
     H2D(P_d, d->P, B * np_seed, double);

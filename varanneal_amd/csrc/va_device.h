@@ -6,6 +6,7 @@
 #include "va_tile2.h"
 #include "va_tile3.h"
 #include "va_tile4.h"
+#include "va_tile5.h"
 
 namespace va {
 
@@ -24,6 +25,9 @@ enum { EPI_NONE = 0, EPI_FINALIZE = 1, EPI_LS = 2 };
 struct Dev {
     Dims dm;
     Geo4 g4;                       // wave-private column-run geometry (emode 4)
+    Geo5 g5;                       // streaming column-strip geometry (emode 5)
+    const int *ystrip;             // [NS][2] per strip: first data column staged (even), 16-byte pieces per observation row
+    int lsrun;                     // this launch may hold line-search points (seeds in PH_LS): stage d as well
     int epi;                       // EPI_*: tail folded into the evaluation kernel
     unsigned ntiles_magic;         // floor(w / ntiles) == umulhi(w, ntiles_magic) for w < B*ntiles
     int gaux;                      // 1: gradient stores write through (sc1)
@@ -68,5 +72,9 @@ size_t eval_lds_bytes(const Dev &dv);
 size_t update_lds_bytes(const Dims &dm);
 hipError_t prepare_eval(const Dev &dv, int rhs);   // once per handle: opt the kernel in to > 64 KiB of LDS on this device
 int eval_grid(const Dims &dm);
+// streaming column strips (va_eval5.hip)
+void launch_eval5(const Dev &dv, hipStream_t s);
+hipError_t prepare_eval5(const Dev &dv);
+size_t eval5_lds(const Dev &dv);
 
 }  // namespace va

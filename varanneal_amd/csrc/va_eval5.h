@@ -1,0 +1,304 @@
+// va_eval5.h -- the STREAMING evaluation kernel k_eval5<RHS, DISC, D, NSLOT, LSRUN> for wide states
+// (BASELINE config 4: Lorenz-96 D = 200, N = 5000) and its launcher.  Geometry: va_tile5.h.
+//
+// Reference arithmetic (va_core.h header): fe_gaussian va_ode.py:160-234 with disc_trapezoid :358-380,
+// disc_euler :341-356 or disc_forwardmap :439-454, me_gaussian :138-158; gradient by the hand-coded adjoint of
+// the stencil.  One wave = one strip of state columns of one seed over one segment of time rows:
+//
+//   ring      NSLOT slots of two staged rows each; slot k+NSLOT-1 is requested (global_load_lds_dwordx4:
+//             x rows, the observation rows, at a line-search point the rows of d) before slot k is touched, and
+//             a counted s_waitcnt vmcnt(N) retires exactly slot k.  No load in the walk returns to a register,
+//             so nothing else ever waits on the vector-memory queue;
+//   step(j)   reads row j (own column + the stencil's neighbours, ds_read_b64 at immediate offsets), evaluates
+//             f_j, the residual of the interval (j-1, j), its adjoint weight q_{j-1}, then finishes row j-1:
+//             direct term, s_{j-1}, the scatter products (published to the wave's LDS arrays, gathered back from
+//             the neighbour lanes -- LDS is in order within a wave), the measurement term, the gradient store
+//             (16 B per lane pair, joined by a DPP quad permutation) and the partial sums.
+//
+// Every row of x is read once per strip (+ the strip's ghost columns), every gradient row written once; the
+// only recomputation is one row per segment (the row before it) and 3 ghost columns per 50.
+#pragma once
+#include "va_eval4.h"
+#include "va_tile5.h"
+
+namespace va {
+
+#define VA_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <class RHS, int DISC, int DC, int NSLOT, bool LSRUN>
+__global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
+{
+    static_assert(DISC != DISC_SH, "one-step discretisations only");
+    static_assert(!RHS::USES_T && RHS::NSTIM == 0, "autonomous right-hand sides only");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const Dims &dm = dv.dm;
+    const int nwork = dm.B * dm.ntiles;
+    const int w = xcd_swizzle(blockIdx.x, nwork);
+    if (w >= nwork) return;
+    const int b = w / dm.ntiles, tile = w - b * dm.ntiles;
+
+    constexpr int NE = RHS::NE, NB = RHS::NB, NG = RHS::NG, NV = EP_GP + RHS::NP;
+    constexpr int P = NSLOT - 1;                              // slots requested ahead of the one in use
+    // column geometry: constant when D is
+    constexpr Geo5 gcc = tile5_cols_rhs<RHS>(DC > 0 ? DC : 128);
+    const Geo5 gc = DC > 0 ? gcc : dv.g5;
+    const int D = DC > 0 ? DC : dv.g5.D;
+    const int PR = gc.PR, CW = gc.CW, GL = gc.GL, XL = gc.XL, PW = gc.PW, PL = gc.PL;
+    const int NSG = gc.NSG, WPG = gc.WPG;
+    const int SEGL = dv.g5.SEGL, YPMAX = dv.g5.YPMAX;
+    const int SLOTX = 4 * PR, SLOTY = 4 * YPMAX;              // doubles per ring slot
+    const int sg = tile / NSG, grp = tile - sg * NSG;
+
+    const auto *st = as_const(static_cast<const SeedHot *>(dv.st + b));
+    const int phase = st->phase;
+    if (phase != PH_START && phase != PH_LS) return;
+    const bool use_d = LSRUN && phase == PH_LS;
+    const double stp = st->stp;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int strip = grp * WPG + wave;
+    const bool wave_on = strip < gc.NS;                       // (the last workgroup of a row may have idle waves)
+    const int WAVE = tile5_wave_doubles(dv.g5, NSLOT, LSRUN, NE);
+    double *xring = smem + wave * WAVE;
+    double *dring = xring + NSLOT * SLOTX;
+    double *yring = dring + (LSRUN ? NSLOT * SLOTX : 0);
+    double *prod = yring + NSLOT * SLOTY;
+    double *strip_red = xring;                                // after the walk
+
+    ThreadAcc acc;
+    acc.clear();
+    if (wave_on) {
+        const int N = dm.N, L = dm.L;
+        const int c0 = strip * CW;
+        const int cws = (D - c0) < CW ? (D - c0) : CW;
+        const int n0 = sg * SEGL, n1 = (n0 + SEGL) < N ? (n0 + SEGL) : N;
+        const int rs = n0 > 0 ? n0 - 1 : 0, re = n1 < N ? n1 + 1 : N;
+        const int SR = re - rs;                               // rows of the stream (>= 2)
+        const int nslots = (SR + 1) >> 1;
+        const double *xg = dv.x + (size_t)b * dm.ld;
+        const double *dg = dv.d + (size_t)b * dm.ld;
+
+        // ---- per-lane constants
+        // staging: lane -> (row of the slot, piece of the image row); the image is the cyclic column window
+        // [c0 - XL, c0 - XL + 2 PR)
+        const int rr = lane >= PR ? 1 : 0, pc = lane - rr * PR;
+        const bool dma_on = lane < 2 * PR;
+        const unsigned xoff = (unsigned)(rr * D + t5_wrap(c0 - XL + 2 * pc, D)) * 8u;
+        const int l_start = as_const(dv.ystrip)[2 * strip], YP = as_const(dv.ystrip)[2 * strip + 1];
+        const int yrr = lane >= YP ? 1 : 0, ypc = lane - yrr * YP;
+        const bool ydma_on = lane < 2 * YP;
+        const unsigned yoff = (unsigned)(yrr * L + l_start + 2 * ypc) * 8u;
+        // arithmetic: lane -> column c0 - GL + lane
+        const int col = t5_wrap(c0 - GL + lane, D);
+        const bool own = lane >= GL && lane < GL + cws;
+        const int lm = dv.pp.lmap[col];
+        const bool obs = own && lm >= 0;
+        const double wobs = obs ? dm.rm : 0.0;
+        const int xlane = XL - GL + lane;                     // own column inside a staged row
+        const int ylane = obs ? lm - l_start : 0;
+        const int gvoff = (own && (lane & 1) == 0) ? (c0 + lane - GL) * 8 : 0x7ffffff0;
+        const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(dv.gt + (size_t)b * dm.ld), 0, (int)(sizeof(double) * N * D), 0x00020000);
+
+        double p[RHS::NP > 0 ? RHS::NP : 1];
+        {   // parameters (estimated ones from the trial point), all uniform
+#pragma unroll
+            for (int k = 0; k < RHS::NP; ++k) p[k] = as_const(dv.pp.Pfull)[(size_t)b * dm.NP + k];
+            for (int k = 0; k < dm.NPest; ++k) {
+                double v = as_const(xg)[dm.ND + k];
+                if (use_d) v = trial(v, stp, as_const(dg)[dm.ND + k]);
+                const int dst = as_const(dv.pp.Pidx)[k];
+#pragma unroll
+                for (int j = 0; j < RHS::NP; ++j) p[j] = (dst == j) ? v : p[j];
+            }
+        }
+        const double dt = dm.dt, hdt = 0.5 * dm.dt;
+        const double cw = 2.0 * st->rf_scale * dm.cfe * dm.rf0;
+        const double c2 = 2.0 * dm.cme * wobs;
+
+        // ---- staging
+        const char *xrow = reinterpret_cast<const char *>(xg + (size_t)rs * D);      // uniform: first row of slot 0
+        const char *drow = reinterpret_cast<const char *>(dg + (size_t)rs * D);
+        const char *yrow = reinterpret_cast<const char *>(dv.pp.Y + (size_t)rs * L);
+        const size_t xstep = (size_t)2 * D * 8, ystep = (size_t)2 * L * 8;
+        auto issue = [&](int k, int pos) {
+            if (dma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(xrow + k * xstep + xoff), (lds_void_t *)(xring + pos * SLOTX), 16, 0, 0);
+            if (LSRUN && use_d) {
+                if (dma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(drow + k * xstep + xoff), (lds_void_t *)(dring + pos * SLOTX), 16, 0, 0);
+            }
+            if (ydma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(yrow + k * ystep + yoff), (lds_void_t *)(yring + pos * SLOTY), 16, 0, 0);
+        };
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+            if (k < nslots) issue(k, k);
+
+        // ---- the walk
+        double x0p = 0.0, fp = 0.0, qp = 0.0, yp = 0.0, dp = 0.0, xnp[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) xnp[k] = 0.0;
+        double fe = 0.0, me = 0.0, gtd = 0.0, gn2 = 0.0, gmax = 0.0, gp[RHS::NP > 0 ? RHS::NP : 1];
+#pragma unroll
+        for (int k = 0; k < RHS::NP; ++k) gp[k] = 0.0;
+
+        // finish row m = (row of the state registers): q = adjoint weight of the residual that starts at row m
+        auto emit = [&](int m, double q, int voff) {
+            double direct, s;
+            if constexpr (DISC == DISC_TRAPEZOID) { direct = qp - q; s = -hdt * (qp + q); }
+            else if constexpr (DISC == DISC_EULER) { direct = qp - q; s = -dt * q; }
+            else { direct = qp; s = -q; }
+            double e[NE], diag;
+            RHS::scatter(col, s, x0p, xnp, p, 0.0, nullptr, e, diag);
+            RHS::pgrad(col, s, x0p, xnp, p, 0.0, nullptr, gp);
+#pragma unroll
+            for (int u = 0; u < NE; ++u) prod[u * PW + PL + lane] = e[u];
+            wave_sync_lds();
+            double r[NG];
+#pragma unroll
+            for (int u = 0; u < NG; ++u) r[u] = VA_LDS_CVP(prod + RHS::g_e(u) * PW + PL + lane)[RHS::g_off(u)];
+            wave_sync_lds();                                  // (the next row overwrites the arrays)
+            const double diff = x0p - yp;
+            me = fma(diff, diff, me);
+            double gv = (direct + diag) + RHS::gather(r);
+            gv = fma(c2, diff, gv);
+            if constexpr (LSRUN) {
+                gtd = fma(gv, dp, gtd);
+                gn2 = fma(gv, gv, gn2);
+                gmax = __builtin_fmax(gmax, __builtin_fabs(gv));
+            }
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            const int glo = __double2loint(gv), ghi = __double2hiint(gv);
+            const int nlo = __builtin_amdgcn_update_dpp(0, glo, 0xF5, 0xF, 0xF, false);      // quad_perm [1,1,3,3]
+            const int nhi = __builtin_amdgcn_update_dpp(0, ghi, 0xF5, 0xF, 0xF, false);
+            const v4u v = {(unsigned)glo, (unsigned)ghi, (unsigned)nlo, (unsigned)nhi};
+            if (dv.gaux) __builtin_amdgcn_raw_buffer_store_b128(v, grs, voff, m * D * 8, 16);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, grs, voff, m * D * 8, 0);
+            qp = q;
+        };
+        // one staged row in registers: own column, the stencil's neighbours, observation, own entry of d
+        struct Row { double x0, xn[NB], yv, dval; };
+        auto load_row = [&](int pos, int r01) {
+            Row t;
+            lds_cvp xr = VA_LDS_CVP(xring + pos * SLOTX + r01 * 2 * PR + xlane);
+            t.x0 = xr[0];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) t.xn[k] = xr[RHS::nb_off(k)];
+            t.yv = VA_LDS_CVP(yring + pos * SLOTY + r01 * 2 * YP + ylane)[0];
+            t.dval = 0.0;
+            if (LSRUN && use_d) t.dval = VA_LDS_CVP(dring + pos * SLOTX + r01 * 2 * PR + xlane)[0];
+            return t;
+        };
+        // row j enters: f_j, the residual of the interval (j-1, j), and row j-1 is finished; FIRST: only
+        // load the state registers
+        auto step = [&](const Row &t, int j, bool first, int voff) {
+            const double f = RHS::f(col, t.x0, t.xn, p, 0.0, nullptr);
+            if (!first) {
+                double r;
+                if constexpr (DISC == DISC_TRAPEZOID) r = (t.x0 - x0p) - hdt * (fp + f);
+                else if constexpr (DISC == DISC_EULER) r = (t.x0 - x0p) - dt * fp;
+                else r = t.x0 - fp;
+                fe = fma(r, r, fe);
+                emit(j - 1, cw * r, voff);
+            }
+            x0p = t.x0; fp = f; yp = t.yv; dp = t.dval;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) xnp[k] = t.xn[k];
+        };
+        // retire slot k, request slot k + P, form the trial point in place
+        bool drained = false;
+        auto begin_slot = [&](int k, int pos, int ppos) {
+            if (k + P > nslots) {
+                if (!drained) { VA_WAIT_VM(0); drained = true; }
+            } else if (LSRUN && use_d) {
+                if (k < P) VA_WAIT_VM((P - 1) * 3); else VA_WAIT_VM(1 + (P - 1) * 5 > 63 ? 63 : 1 + (P - 1) * 5);
+            } else {
+                if (k < P) VA_WAIT_VM((P - 1) * 2); else VA_WAIT_VM(1 + (P - 1) * 4 > 63 ? 63 : 1 + (P - 1) * 4);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (k + P < nslots) issue(k + P, ppos);
+            if (LSRUN && use_d) {
+                if (dma_on) {
+                    double a0, a1, d0, d1;
+                    ld2(xring + pos * SLOTX + 2 * lane, a0, a1); ld2(dring + pos * SLOTX + 2 * lane, d0, d1);
+                    st2(xring + pos * SLOTX + 2 * lane, trial(a0, stp, d0), trial(a1, stp, d1));
+                }
+                wave_sync_lds();
+            }
+        };
+
+        // slot 0: the row before the segment only loads the state; a segment that starts at row 0 has no
+        // residual behind it (q_{-1} = 0) and its first row is finished for real, any other segment's
+        // "row n0 - 1" is finished into nowhere and the sums it left are cleared
+        begin_slot(0, 0, P % NSLOT);
+        {
+            const Row t0 = load_row(0, 0), t1 = load_row(0, 1);
+            step(t0, rs, true, 0);
+            step(t1, rs + 1, false, n0 > 0 ? 0x7ffffff0 : gvoff);
+        }
+        if (n0 > 0) {
+            fe = 0.0; me = 0.0; gtd = 0.0; gn2 = 0.0; gmax = 0.0;
+#pragma unroll
+            for (int k = 0; k < RHS::NP; ++k) gp[k] = 0.0;
+        }
+        const int nfull = SR >> 1;                            // slots with two rows of the stream
+        int pos = 1 % NSLOT, ppos = (1 + P) % NSLOT;
+        for (int k = 1; k < nfull; ++k) {
+            begin_slot(k, pos, ppos);
+            const Row t0 = load_row(pos, 0), t1 = load_row(pos, 1);      // both rows' reads in flight before the first product exchange
+            step(t0, rs + 2 * k, false, gvoff);
+            step(t1, rs + 2 * k + 1, false, gvoff);
+            pos = pos + 1 == NSLOT ? 0 : pos + 1;
+            ppos = ppos + 1 == NSLOT ? 0 : ppos + 1;
+        }
+        if (SR & 1) {
+            begin_slot(nfull, pos, ppos);
+            const Row t0 = load_row(pos, 0);
+            step(t0, rs + 2 * nfull, false, gvoff);
+        }
+        if (re == N && n1 == N) emit(N - 1, 0.0, gvoff);      // the path's last row: no residual starts there
+        if (!drained) VA_WAIT_VM(0);
+
+        // ---- the lane's sums (lanes outside the strip's own columns computed ghosts: not theirs to count)
+        acc.v[EP_FE] = own ? dm.rf0 * fe : 0.0;
+        acc.v[EP_ME] = own ? wobs * me : 0.0;
+        acc.v[EP_GTD] = own ? gtd : 0.0;
+        acc.v[EP_GN2] = own ? gn2 : 0.0;
+        acc.v[EP_GMAX] = own ? gmax : 0.0;
+#pragma unroll
+        for (int k = 0; k < RHS::NP; ++k) acc.v[EP_GP + k] = own ? gp[k] : 0.0;
+    }
+
+    // ---- ONE row of partial sums per workgroup (as k_eval4): matrix-pipe wave sums, LDS strip, wave 0 adds
+    // the waves in wave order and stores the row write-through; the seed's last workgroup runs the tail
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if ((k == EP_GTD || k == EP_GN2 || k == EP_GMAX) && !LSRUN) continue;
+        const double r = (k == EP_GMAX) ? wave_max(acc.v[k]) : wave_sum_mfma(acc.v[k]);
+        if (lane == 0) strip_red[k] = r;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave != 0) return;
+    if (lane < NV) {
+        double v = 0.0;
+        if (!((lane == EP_GTD || lane == EP_GN2 || lane == EP_GMAX) && !LSRUN)) {
+            v = smem[lane];
+            for (int w2 = 1; w2 < WPG; ++w2) {
+                const double o = smem[w2 * WAVE + lane];
+                v = (lane == EP_GMAX) ? fmax(v, o) : v + o;
+            }
+        }
+        st_sc1(dv.evp + ((size_t)b * dm.ntiles + tile) * EP_N + lane, v);
+    }
+    if (dv.epi == EPI_NONE) return;
+    if (arrive_last(dv.cnt_eval + (size_t)b * CNT_STRIDE, (unsigned)dm.ntiles, lane))
+        eval_epilogue<true>(dv, b, lane, reinterpret_cast<SeedHot *>(smem + T4_STRIP), dv.epi);
+}
+
+inline size_t eval5_lds_bytes(const Dev &dv, int nslot, bool ls, int ne)
+{
+    return sizeof(double) * (size_t)dv.g5.WPG * tile5_wave_doubles(dv.g5, nslot, ls, ne);
+}
+
+}  // namespace va

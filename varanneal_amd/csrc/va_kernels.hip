@@ -23,6 +23,7 @@
 #include "va_eval_flat.h"
 #include "va_eval3.h"
 #include "va_eval4.h"
+#include "va_tile5.h"
 
 namespace va {
 
@@ -30,6 +31,7 @@ size_t eval_lds_bytes(const Dev &dv)
 {
     const Dims &dm = dv.dm;
     if (dm.emode == 4) return sizeof(double) * (size_t)dv.g4.NW * dv.g4.WAVE;
+    if (dm.emode == 5) return eval5_lds(dv);
     if (dm.emode == 1) return eval_flat_lds_bytes(dm);
     const int HL = dm.disc == DISC_SH ? 2 : 1;
     const size_t elems = (size_t)tile3_stage_elems(dm.maxr, dm.D, dm.ghost, dm.RY, HL + 1) + tile3_s_elems(dm.maxr, dm.D, dm.ghost, dm.RY);
@@ -113,7 +115,10 @@ static void eval4_d(const Dev &dv, EvalOp &op)
 static void eval_dispatch(const Dev &dv, int rhs, EvalOp &op)
 {
     (void)rhs;                 // VA_RHS_LORENZ96 is the only built-in RHS
-    if (dv.dm.emode == 4) {
+    if (dv.dm.emode == 5) {
+        if (op.prepare) op.err = prepare_eval5(dv);
+        else launch_eval5(dv, op.s);
+    } else if (dv.dm.emode == 4) {
         switch (dv.dm.maxr) {
         case 4: eval4_d<RhsL96s, 4>(dv, op); break;
         case 5: eval4_d<RhsL96s, 5>(dv, op); break;
