@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VA_ABI_VERSION 10
+#define VA_ABI_VERSION 11
 
 enum { VA_OK = 0, VA_EINVAL = -1, VA_ENOMEM = -2, VA_EHIP = -3, VA_EUNSUPPORTED = -4,
        VA_ESTATE = -5 };
@@ -82,7 +82,8 @@ typedef struct va_problem_desc {
     int32_t max_beta;         /* longest ladder va_anneal will be asked for (>=1)    */
     int32_t keep_paths;       /* 1: keep every beta step's path on device (minpaths) */
     int32_t tile_rows;        /* 0 = auto; time rows per workgroup                   */
-    int32_t eval_kernel;      /* 0 = auto; 1 = flat-mapped, 2 = column-mapped, 3 = column-run tile kernel */
+    int32_t eval_kernel;      /* 0 = auto; 1 = flat-mapped, 3 = workgroup column runs, 4 = wave-private column runs,
+                               * 5 = streaming column strips (a kernel that does not apply falls back)          */
     const double *t_model;    /* NULL or [N_model]: times passed to a non-autonomous RHS (va_ode.py:553,558) */
     const double *stim;       /* NULL or [N_model*n_stim]: external stimulus rows, f(t,x,(p,stim)) (va_ode.py:345-375) */
     int32_t n_stim;
@@ -127,6 +128,11 @@ int va_rhs_load_module(const char *path, int32_t *rhs_id);
  *           kernel 4: 1 if scalar weights else 0; kernel 3: threads per workgroup).
  * A module built for exactly that instantiation runs it; any other problem runs the module's flat kernel. */
 int va_eval_plan(const va_problem_desc *desc, int32_t ne, int32_t ghost, int32_t *out);
+/* The same for a column form whose reaches are known: reach[4] = {xl, xr, gl, gr} = how many columns to the left /
+ * right f reads (xl, xr) and the adjoint gather receives from (gl, gr).  Wide even states (D > 64) with a one-step
+ * discretisation, scalar weights, data at every model time and an even number of observed columns then run the
+ * streaming kernel k_eval5 (csrc/va_eval5.h): out = (5, disc, 0, 0).  Follows desc->Lidx (needs L and Lidx). */
+int va_eval_plan_reach(const va_problem_desc *desc, int32_t ne, int32_t ghost, const int32_t *reach, int32_t *out);
 
 int va_problem_create(const va_problem_desc *desc, va_handle *out);
 void va_problem_destroy(va_handle h);
@@ -136,7 +142,8 @@ int va_problem_info(va_handle h, int64_t *n_var, int64_t *ld_internal, int32_t *
                     int32_t *ntiles);
 
 /* Which evaluation kernel the handle runs (the values of va_problem_desc.eval_kernel: 1 flat,
- * 3 workgroup column runs, 4 wave-private column runs) and the rows per lane run (0 for the flat kernel). */
+ * 3 workgroup column runs, 4 wave-private column runs, 5 streaming column strips) and the rows per lane run
+ * (0 for the flat kernel, 2 = rows per ring slot for the streaming kernel). */
 int va_problem_eval_kernel(va_handle h, int32_t *eval_kernel, int32_t *run_rows);
 
 /* S1 evaluator -- replaces ADmin.A_gradA_taped (_autodiffmin.py:57-58), batched:

@@ -53,6 +53,6 @@ def test_world_size_must_match_gpus():
 
 
 def test_env_switches_are_recorded():
-    r = run(["--dry-run"], env={"VA_SOMETHING": "1", "VARANNEAL_AMD_JIT_WIDE": "0", "UNRELATED": "x"})
+    r = run(["--dry-run"], env={"VA_SOMETHING": "1", "VARANNEAL_AMD_LIB_X": "0", "UNRELATED": "x"})
     rec = last_json(r.stdout)
-    assert rec["config"]["env"] == {"VARANNEAL_AMD_JIT_WIDE": "0", "VA_SOMETHING": "1"}
+    assert rec["config"]["env"] == {"VARANNEAL_AMD_LIB_X": "0", "VA_SOMETHING": "1"}

@@ -300,3 +300,38 @@ def test_ghost_module_exports_its_variant():
     v = (C.c_int * 6)()
     L.va_user_variant_info(v)
     assert list(v) == [3, 1, 8, 256, 0, 2]
+
+
+def test_gather_coefficients_keep_their_digits():
+    """proportional products share a slot with a constant factor: the factor is printed from its value (2.1 and 11
+    used to lose their leading digits to a text replacement of "1 * ")"""
+    def f(t, x, p):
+        return np.roll(x, 1, 1) + 2.1 * np.roll(x, -1, 1) - p[0] * x
+
+    def g(t, x, p):
+        return np.roll(x, 1, 1) + 11 * np.roll(x, -1, 1) - p[0] * x * x
+
+    def h(t, x, p):
+        return np.roll(x, 1, 1) - np.roll(x, -1, 1) - p[0] * x
+    for fun, want in ((f, "r[0] + (2.1000000000000001) * r[1]"), (g, "r[0] + (11) * r[1]"), (h, "r[0] + -r[1]")):
+        m = codegen.module_for(fun, 20, 1, col_variant=lambda ne, gh: (4, 1, 6, 1), compile=False)
+        line = [ln for ln in m["text"].splitlines() if "double gather(" in ln][0]
+        assert want in line, line
+
+
+def test_wide_stencil_gets_the_streaming_variant():
+    """a three-argument callback is handed the column form's reaches; with them (and the observed columns) the plan
+    for BASELINE config 4's shape is the streaming kernel, and the header carries the column form"""
+    Lidx = list(range(0, 200, 5))
+    assert _capi.eval_plan(64, 200, 5000, "trapezoid", 2, 2, reach=(2, 1, 1, 2), Lidx=Lidx) == (5, 1, 0, 0)
+    assert _capi.eval_plan(64, 200, 5001, "SimpsonHermite", 2, 2, reach=(2, 1, 1, 2), Lidx=Lidx)[0] == 3
+    assert _capi.eval_plan(64, 200, 5000, "trapezoid", 2, 2, reach=(2, 1, 1, 2), Lidx=Lidx[:-1])[0] == 3      # odd L
+    assert _capi.eval_plan(64, 200, 5000, "trapezoid", 2, 2, reach=(2, 1, 1, 2), Lidx=Lidx, rf_array=True)[0] == 3
+    seen = {}
+
+    def cb(ne, gh, reach):
+        seen["reach"] = reach
+        return _capi.eval_plan(64, 200, 5000, "trapezoid", ne, gh, reach=reach, Lidx=Lidx)
+    m = codegen.module_for(_l96_plain, 200, 1, col_variant=cb, compile=False)
+    assert seen["reach"] == (2, 1, 1, 2) and m["col_variant"] == (5, 1, 0, 0)
+    assert "struct RhsUserCol" in m["text"] and "struct RhsUserG" not in m["text"]

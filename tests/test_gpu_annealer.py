@@ -94,27 +94,33 @@ def test_c_abi_gather_of_result_tables():
     assert np.array_equal(st, r["status"])
 
 
-def test_wide_builtin_model_runs_a_module_with_the_width_compiled_in(monkeypatch):
-    """set_model(l96, D = 100): the Annealer generates a module from the registry's own callable (state width
-    compiled into the workgroup kernel); VARANNEAL_AMD_JIT_WIDE=0 keeps the library's run-time-D kernel.  Same
-    kernel phases, same arithmetic up to the order of three additions: one rung agrees to 1e-9."""
+def test_wide_models_run_the_streaming_kernel_through_the_drop_in():
+    """set_model(l96, D = 100): the library's own streaming kernel (k_eval5, run-time width; no module is generated
+    for a built-in model).  A user's stencil that is NOT in the registry -- Lorenz-96 with a damping parameter -- is
+    traced, gets its column form compiled for k_eval5, and with the damping fixed at 1 one rung agrees with the
+    built-in's to 1e-9 (same arithmetic up to one multiplication by 1 and the order of a few additions)."""
     from varanneal_amd import twin, va_ode
     D, N, B = 100, 160, 4
-    Lidx = list(range(0, D, 4))
+    Lidx = list(range(0, D, 5))
     t, Y, _, _ = twin.make_twin(D, N, Lidx=Lidx)
     X0 = np.empty((B, N, D)); P0 = np.empty((B, 1))
     for s in range(B):
         X0[s], P0[s] = twin.initial_guess(N, D, s, Y, Lidx)
+
+    def damped_l96(t, x, p):
+        return np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - p[1] * x + p[0]
     res = {}
-    for jit in ("1", "0"):
-        monkeypatch.setenv("VARANNEAL_AMD_JIT_WIDE", jit)
+    for key, f, P in (("builtin", twin.l96, P0), ("traced", damped_l96, np.hstack([P0, np.ones((B, 1))]))):
         a = va_ode.Annealer()
-        a.set_model(twin.l96, D)
+        a.set_model(f, D)
         a.set_data(Y, t=t)
-        a.anneal(X0.copy(), P0.copy(), 1.5, [0], 4.0, 4e-6, Lidx, [0], disc="trapezoid",
+        a.anneal(X0.copy(), P.copy(), 1.5, [0], 4.0, 4e-6, Lidx, [0], disc="trapezoid",
                  opt_args={'gtol': 1e-8, 'ftol': 1e-8, 'maxiter': 20, 'maxfun': 1000}, verbose=False)
-        assert a._pb.info()["eval_kernel"] == 3
-        assert (getattr(a, "_rhs_module", None) is not None) == (jit == "1")
-        res[jit] = (a.A_array.copy(), a.nit_array.copy())
+        assert a._pb.info()["eval_kernel"] == 5
+        mod = getattr(a, "_rhs_module", None)
+        assert (mod is not None) == (key == "traced")
+        if mod is not None:
+            assert mod["col_variant"][0] == 5
+        res[key] = (a.A_array.copy(), a.nit_array.copy())
         a.close()
-    assert np.array_equal(res["1"][1], res["0"][1]) and np.allclose(res["1"][0], res["0"][0], rtol=1e-9)
+    assert np.array_equal(res["builtin"][1], res["traced"][1]) and np.allclose(res["builtin"][0], res["traced"][0], rtol=1e-9)

@@ -343,7 +343,7 @@ def test_c4_all_512_seeds_on_one_gpu(capi):
     XP[:, -1] = 6.0 + 4.0 * rng.rand(B)
     P = XP[:, -1:].copy()
     pb = capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", lbfgs_m=3)
-    assert pb.info()["n_var"] == 1000001 and pb.info()["eval_kernel"] == 3
+    assert pb.info()["n_var"] == 1000001 and pb.info()["eval_kernel"] == 5          # (the streaming kernel, several rounds of workgroups)
     A1, me1, fe1, _ = pb.action_grad(XP, 1.0, want_grad=False)
     A2, me2, fe2, g2 = pb.action_grad(XP, 1000.0)
     assert np.array_equal(me1, me2) and np.allclose(fe2, 1000.0 * fe1, rtol=1e-13)

@@ -76,6 +76,12 @@ def build_stamps(verbose=True):
     return _compile_link(os.path.join(HERE, "libvaranneal_amd_stamps.so"), ["-DVA_STAMPS"], verbose)
 
 
+def build_variant(tag, defines, verbose=True):
+    """Diagnostic library libvaranneal_amd_<tag>.so with extra -D switches (ablations for profiles/); never the
+    product.  Select it with VARANNEAL_AMD_LIB=<path> (tools/ab.sh)."""
+    return _compile_link(os.path.join(HERE, "libvaranneal_amd_%s.so" % tag), list(defines), verbose)
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
@@ -83,7 +89,10 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    if "--stamps" in sys.argv:
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], sys.argv[i + 2:])
+    elif "--stamps" in sys.argv:
         build_stamps()
     else:
         build(force="--force" in sys.argv)

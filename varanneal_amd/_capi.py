@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VARANNEAL_AMD_LIB", os.path.join(_HERE, "libvaranneal_amd.so"))   # (env: diagnostic builds)
 
 VA_OK = 0
-ABI_VERSION = 10         # VA_ABI_VERSION of include/varanneal_amd.h
+ABI_VERSION = 11         # VA_ABI_VERSION of include/varanneal_amd.h
 ERRNAMES = {-1: "VA_EINVAL", -2: "VA_ENOMEM", -3: "VA_EHIP", -4: "VA_EUNSUPPORTED", -5: "VA_ESTATE"}
 DISC = {"euler": 0, "trapezoid": 1, "SimpsonHermite": 2, "forwardmap": 3}
 RHS = {"lorenz96": 0}
@@ -186,6 +186,7 @@ def lib():
     L.va_rhs_load_module.argtypes = [C.c_char_p, c_ip]
     L.va_act_load_module.argtypes = [C.c_char_p, c_ip]
     L.va_eval_plan.argtypes = [C.POINTER(ProblemDesc), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+    L.va_eval_plan_reach.argtypes = [C.POINTER(ProblemDesc), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.va_problem_destroy.argtypes = [h]
     L.va_problem_destroy.restype = None
     L.va_problem_info.argtypes = [h, c_lp, c_lp, c_ip, c_ip]
@@ -207,7 +208,7 @@ def lib():
     L.va_read_eval_outputs.argtypes = [h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.va_debug_read_partials.argtypes = [h, c_dp, C.c_int64]
     L.va_problem_eval_kernel.argtypes = [h, c_ip, c_ip]
-    for fn in ("va_device_count", "va_rhs_load_module", "va_act_load_module", "va_eval_plan", "va_problem_eval_kernel", "va_problem_create", "va_nnet_problem_create",
+    for fn in ("va_device_count", "va_rhs_load_module", "va_act_load_module", "va_eval_plan", "va_eval_plan_reach", "va_problem_eval_kernel", "va_problem_create", "va_nnet_problem_create",
                "va_problem_info", "va_action_grad",
                "va_minimize_lbfgs", "va_anneal", "va_get_minpath", "va_eval_timed",
                "va_get_counters", "va_debug_read_partials", "va_read_eval_outputs", "va_lbfgs_timed",
@@ -217,7 +218,7 @@ def lib():
     return L
 
 
-EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_act_load_module", "va_eval_plan", "va_problem_eval_kernel", "va_problem_create",
+EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_act_load_module", "va_eval_plan", "va_eval_plan_reach", "va_problem_eval_kernel", "va_problem_create",
            "va_problem_destroy", "va_problem_info", "va_action_grad", "va_minimize_lbfgs",
            "va_anneal", "va_get_minpath", "va_eval_timed", "va_get_counters", "va_nnet_problem_create", "va_debug_read_partials",
            "va_read_eval_outputs", "va_lbfgs_timed", "va_comm_unique_id", "va_comm_create", "va_comm_destroy",
@@ -230,11 +231,12 @@ def check(rc):
 
 
 def eval_plan(batch, D, N_model, disc, ne, ghost=0, rm_array=False, rm_full=False, rf_array=False, rf_full=False,
-              merr_nskip=1, tile_rows=0, eval_kernel=0, bounded=False, p_time_dependent=False):
-    """(eval kernel 3 | 4, disc, K, w) of the column-run kernel instantiation a problem of this shape would run
+              merr_nskip=1, tile_rows=0, eval_kernel=0, bounded=False, p_time_dependent=False, reach=None, Lidx=None):
+    """(eval kernel 3 | 4 | 5, disc, K, w) of the column-run kernel instantiation a problem of this shape would run
     for a model with a column form of `ne` products per element and / or a ghosted form of `ghost` ghost
     columns (0 = the model has no such form), or None (flat kernel).  w: kernel 4 -- 1 for scalar weights;
-    kernel 3 -- threads per workgroup.  No GPU call (va_eval_plan)."""
+    kernel 3 -- threads per workgroup.  reach = (xl, xr, gl, gr) of the column form and Lidx (the observed columns)
+    let wide states pick the streaming kernel 5.  No GPU call (va_eval_plan / va_eval_plan_reach)."""
     d = ProblemDesc()
     d.struct_size = C.sizeof(ProblemDesc)
     d.batch, d.D, d.N_model, d.merr_nskip = batch, D, N_model, merr_nskip
@@ -248,7 +250,14 @@ def eval_plan(batch, D, N_model, disc, ne, ghost=0, rm_array=False, rm_full=Fals
     if bounded:
         d.lower = C.cast(dummy, c_dp); d.upper = C.cast(dummy, c_dp)
     out = (C.c_int32 * 4)()
-    check(lib().va_eval_plan(C.byref(d), int(ne), int(ghost), out))
+    if reach is not None and Lidx is not None and len(Lidx) > 0:
+        li = np.ascontiguousarray(Lidx, dtype=np.int32)
+        d.L = len(li)
+        d.Lidx = li.ctypes.data_as(c_ip)
+        r = (C.c_int32 * 4)(*[int(v) for v in reach])
+        check(lib().va_eval_plan_reach(C.byref(d), int(ne), int(ghost), r, out))
+    else:
+        check(lib().va_eval_plan(C.byref(d), int(ne), int(ghost), out))
     return (out[0], out[1], out[2], out[3]) if out[0] else None
 
 

@@ -342,8 +342,15 @@ def column_form(exprs, syms, D, NP, nstim, max_dense=8, uniform=None):
     out += emit_switch(scat, " ".join("e[%d] = 0.0;" % k for k in range(NE)) + " diag = 0.0;")
     out.append("    }")
     # gather
-    terms = " + ".join("%s * r[%d]" % (_printer().doprint(sp.Float(coef_of[k]) if coef_of[k].is_Float else coef_of[k]), k) for k in range(NB))
-    terms = terms.replace("1 * ", "").replace("-1 * ", "-")
+    def term(k):
+        # from the VALUE of the coefficient (text surgery on "1 * " would also hit 2.1, 11, ...)
+        c = coef_of[k]
+        if c == 1:
+            return "r[%d]" % k
+        if c == -1:
+            return "-r[%d]" % k
+        return "(%s) * r[%d]" % (_printer().doprint(sp.Float(c) if c.is_Float else c), k)
+    terms = " + ".join(term(k) for k in range(NB))
     out.append("    static VA_HD double gather(const double *r) { return %s; }" % terms)
     # pgrad
     out.append("    static VA_HD void pgrad(int col, double s, double x0, const double *xn, const double *p, double t, const double *st, double *acc)")
@@ -361,7 +368,9 @@ def column_form(exprs, syms, D, NP, nstim, max_dense=8, uniform=None):
     out += emit_switch(pg, "")
     out.append("    }")
     out.append("};")
-    return dict(text="\n".join(out), uniform=uniform, offsets=offs, NE=NE, NB=NB)
+    xl, xr = max([0] + [-o for o in offs]), max([0] + offs)
+    return dict(text="\n".join(out), uniform=uniform, offsets=offs, NE=NE, NB=NB, reach=(xl, xr, xr, xl),
+                autonomous=not uses_t and nstim == 0)
 
 
 def ghost_form(exprs, syms, D, NP, nstim, uniform=None):
@@ -462,7 +471,7 @@ BUILD_TAG = "sched=iterative-maxocc"      # part of every module's cache key: a 
 def _core_fingerprint():
     h = hashlib.sha1(BUILD_TAG.encode())
     for fn in ("va_core.h", "va_device.h", "va_eval_flat.h", "va_eval3.h", "va_eval4.h", "va_epilogue.h", "va_tile2.h", "va_tile3.h",
-               "va_tile4.h", "va_user_rhs.hip"):
+               "va_tile4.h", "va_tile5.h", "va_eval5.h", "va_user_rhs.hip"):
         with open(os.path.join(CSRC, fn), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
@@ -510,7 +519,7 @@ def build_module(header_text, verbose=False, col_variant=None, compile=True):
 
 def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False, p_rows=False, col_variant=None, compile=True):
     """trace + check + generate + build.  Returns dict(so=, header=, exprs=, col=).
-    col_variant: None, or a callable (NE, GHOST) -> (eval kernel 3 | 4, disc, K, w) or None (as
+    col_variant: None, or a callable (NE, GHOST[, reach]) -> (eval kernel 3 | 4 | 5, disc, K, w) or None (as
     _capi.eval_plan returns it) naming the instantiation of a column-run kernel to compile for a model that has
     a column form (NE products per element; 0 = none) and / or a ghosted form (GHOST columns; 0 = none)."""
     if NP > MAX_NP:
@@ -521,10 +530,22 @@ def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False, p_rows=False, col_
     variant = None
     if col_variant is not None and not p_rows:
         uniform = _translation_invariant(exprs, list(syms["x"]), D)
-        col = column_form(exprs, syms, D, NP, nstim, uniform=uniform) if D <= 64 else None   # (k_eval4: D <= 64)
+        # column form: k_eval4 (D <= 64: stencils and small dense systems) or, for stencils, the streaming k_eval5
+        col = column_form(exprs, syms, D, NP, nstim, uniform=uniform) if (D <= 64 or uniform) else None
         ghost = ghost_form(exprs, syms, D, NP, nstim, uniform=uniform)
-        variant = col_variant(col["NE"] if col else 0, ghost["GHOST"] if ghost else 0) if (col or ghost) else None
-        if variant is None or variant[0] != 4:
+        variant = None
+        if col or ghost:
+            ne, gh = (col["NE"] if col else 0), (ghost["GHOST"] if ghost else 0)
+            import inspect
+            try:
+                three = len(inspect.signature(col_variant).parameters) >= 3
+            except (TypeError, ValueError):
+                three = False
+            # (a callback of three arguments also gets the column form's reaches, or None when the form is not one
+            # the streaming kernel can run: non-uniform, explicit time, stimulus)
+            reach = col["reach"] if (col and col["uniform"] and col["autonomous"]) else None
+            variant = col_variant(ne, gh, reach) if three else col_variant(ne, gh)
+        if variant is None or variant[0] not in (4, 5):
             col = None
         if variant is None or variant[0] != 3:
             ghost = None

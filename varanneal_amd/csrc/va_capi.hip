@@ -49,8 +49,8 @@ int fail(int code, const char *fmt, ...)
 // generated right-hand-side modules (va_rhs_load_module); ids are VA_RHS_USER_BASE + index
 struct UserRhs {
     // the ONE column-run instantiation the module carries besides its flat kernel, if any (va_user_rhs.hip):
-    // (eval kernel 0 / 3 / 4, DISC, K, W_SCALAR [4] or threads [3], NE [4], GHOST [3])
-    int var[6] = {0, 0, 0, 0, 0, 0};
+    // (eval kernel 0 / 3 / 4 / 5, DISC, K, W_SCALAR [4] or threads [3], NE [4, 5], GHOST [3])
+    int var[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // (+ the column form's reaches xl, xr, gl, gr [5])
     void (*launch_var)(const Dev *, void *) = nullptr;
     int (*prepare_var)(const Dev *) = nullptr;
     std::string path;
@@ -155,6 +155,7 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
     if (user_rhs) dm.emode = 1;                           // no column form (or a case only the flat kernel carries)
     if (dm.emode == 5) {
         Geo5 g = tile5_cols(D, reach5[0], reach5[1], reach5[2], reach5[3]);
+        g.ne = ne;
         // segments: as many workgroups as the chip holds at once (four 4-wave groups per CU: 128 registers, 40 KiB
         // of LDS each), every one with the same number of rows; at least 32 rows per segment
         const long per_row = (long)d->batch * g.NSG;
@@ -171,7 +172,7 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
         ystrip->assign(2 * g.NS, 0);
         g.YPMAX = 1;
         for (int s5 = 0; s5 < g.NS; ++s5) {
-            const int c0 = s5 * g.CW, c1 = std::min(D, c0 + g.CW);
+            const int c0 = tile5_c0(D, g.NS, s5), c1 = tile5_c0(D, g.NS, s5 + 1);
             const int l0 = (int)(std::lower_bound(ls.begin(), ls.end(), c0) - ls.begin());
             const int l1 = (int)(std::lower_bound(ls.begin(), ls.end(), c1) - ls.begin());
             int start = l0 & ~1;
@@ -180,11 +181,12 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
             (*ystrip)[2 * s5] = start; (*ystrip)[2 * s5 + 1] = yp;
             if (yp > g.YPMAX) g.YPMAX = yp;
         }
-        // ring depth: the deepest that still lets four workgroups share a CU's 160 KiB
-        auto fits = [&](int nslot, bool lsr) { return (size_t)g.WPG * tile5_wave_doubles(g, nslot, lsr, ne) * sizeof(double) <= 40 * 1024; };
-        g.nslot = fits(8, false) ? 8 : (fits(6, false) ? 6 : 4);
-        g.nslot_ls = fits(6, true) ? 6 : (fits(4, true) ? 4 : 3);
-        if (const char *e = getenv("VA_E5_NSLOT")) { const int v = atoi(e); if (v == 4 || v == 6 || v == 8) g.nslot = v; }
+        // ring depth: four slots (three requested ahead) while four workgroups still share a CU's 160 KiB, else three.
+        // Measured at C4 (profiles/r03_e5_experiments.txt): 3 and 4 slots equal; 6 slots drop a workgroup per CU (+33 %)
+        auto fits = [&](int nslot, bool lsr) { return (size_t)g.WPG * tile5_wave_doubles(g, nslot, lsr) * sizeof(double) <= 40 * 1024; };
+        g.nslot = fits(4, false) ? 4 : 3;
+        g.nslot_ls = fits(4, true) ? 4 : 3;
+        g.xdpp = (reach5[2] <= 2 && reach5[3] <= 2) ? 1 : 0;
         if (g.YPMAX <= 32 && !(d->L & 1)) {          // (odd L: data rows alternate between 16-byte phases -- not staged by 16-byte pieces)
             *g5 = g;
             dm.RY = 0; dm.NT = 64 * g.WPG; dm.maxr = 2; dm.T = g.SEGL;
@@ -500,7 +502,7 @@ int va_device_count(int32_t *count)
     return VA_OK;
 }
 
-int va_eval_plan(const va_problem_desc *d, int32_t ne, int32_t ghost, int32_t *out)
+int va_eval_plan_reach(const va_problem_desc *d, int32_t ne, int32_t ghost, const int32_t *reach, int32_t *out)
 {
     if (!d || !out) return fail(VA_EINVAL, "null argument");
     if (d->struct_size != (int32_t)sizeof(va_problem_desc)) return fail(VA_EINVAL, "struct_size %d != %zu", d->struct_size, sizeof(va_problem_desc));
@@ -508,11 +510,21 @@ int va_eval_plan(const va_problem_desc *d, int32_t ne, int32_t ghost, int32_t *o
     if ((ne <= 0 && ghost <= 0) || d->D < 1 || d->N_model < 2 || d->batch < 1) return VA_OK;
     Dims dm{};
     Geo4 g4{};
-    pick_eval_geometry(d, dm, g4, ne, ghost);
-    if (dm.emode != 3 && dm.emode != 4) return VA_OK;
-    out[0] = dm.emode; out[1] = d->disc; out[2] = dm.maxr;
-    out[3] = dm.emode == 4 ? ((d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1) ? 1 : 0) : dm.NT;
+    Geo5 g5{};
+    std::vector<int> ys;
+    int r5[4] = {0, 0, 0, 0};
+    if (reach) for (int k = 0; k < 4; ++k) r5[k] = reach[k];
+    if (d->L > 0 && !d->Lidx) return fail(VA_EINVAL, "Lidx is NULL");
+    pick_eval_geometry(d, dm, g4, ne, ghost, reach ? r5 : nullptr, &g5, &ys);
+    if (dm.emode != 3 && dm.emode != 4 && dm.emode != 5) return VA_OK;
+    out[0] = dm.emode; out[1] = d->disc; out[2] = dm.emode == 5 ? 0 : dm.maxr;
+    out[3] = dm.emode == 4 ? ((d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1) ? 1 : 0) : (dm.emode == 5 ? 0 : dm.NT);
     return VA_OK;
+}
+
+int va_eval_plan(const va_problem_desc *d, int32_t ne, int32_t ghost, int32_t *out)
+{
+    return va_eval_plan_reach(d, ne, ghost, nullptr, out);
 }
 
 int va_rhs_load_module(const char *path, int32_t *rhs_id)
@@ -538,7 +550,7 @@ int va_rhs_load_module(const char *path, int32_t *rhs_id)
     }
     if (v[0] < 0 || v[0] > RHS_MAX_NP) { dlclose(u.dl); return fail(VA_EUNSUPPORTED, "%s: NP=%d > %d", path, v[0], RHS_MAX_NP); }
     u.NP = v[0]; u.D = v[1]; u.NSTIM = v[2];
-    if (info_fn vinfo = (info_fn)dlsym(u.dl, "va_user_variant_info")) {
+    if (info_fn vinfo = (info_fn)dlsym(u.dl, "va_user_variant_info")) {        // (writes 10 ints)
         vinfo(u.var);
         u.launch_var = (void (*)(const Dev *, void *))dlsym(u.dl, "va_user_launch_variant");
         u.prepare_var = (int (*)(const Dev *))dlsym(u.dl, "va_user_prepare_variant");
@@ -660,10 +672,10 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
         // the module holds ONE instantiation of a column-run kernel (va_eval_plan named it when the module
         // was generated); a problem that calls for any other geometry runs the module's flat kernel
         const int *v = user->var;
-        pick_eval_geometry(d, dm, dv.g4, v[0] == 4 ? v[4] : 0, v[0] == 3 ? v[5] : 0);
+        pick_eval_geometry(d, dm, dv.g4, (v[0] == 4 || v[0] == 5) ? v[4] : 0, v[0] == 3 ? v[5] : 0, v[0] == 5 ? v + 6 : nullptr, &dv.g5, &ystrip_h);
         const bool ws = d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1;
-        const bool fits = dm.emode == v[0] && v[1] == d->disc && v[2] == dm.maxr &&
-                          (dm.emode == 4 ? (v[3] != 0) == ws : v[3] == dm.NT);
+        const bool fits = dm.emode == v[0] && v[1] == d->disc &&
+                          (dm.emode == 5 ? true : (v[2] == dm.maxr && (dm.emode == 4 ? (v[3] != 0) == ws : v[3] == dm.NT)));
         if (dm.emode != 1 && fits) { h->user_launch = user->launch_var; h->user_prepare = user->prepare_var; }
         else if (dm.emode != 1) pick_eval_geometry(d, dm, dv.g4, 0, 0);
     }

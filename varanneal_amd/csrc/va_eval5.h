@@ -25,7 +25,33 @@ namespace va {
 
 #define VA_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-template <class RHS, int DISC, int DC, int NSLOT, bool LSRUN>
+// value of lane + O (|O| <= 2) through DPP whole-wave shifts (wave_shl:1 / wave_shr:1): lanes whose source lies
+// outside the wave get 0 -- they are ghost lanes
+template <int O>
+__device__ __forceinline__ double lane_from(double x)
+{
+    static_assert(O >= -2 && O <= 2, "reach of the DPP exchange");
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    constexpr int CTRL = O > 0 ? 0x130 : 0x138;               // wave_shl:1 : wave_shr:1
+#pragma unroll
+    for (int k = 0; k < (O > 0 ? O : -O); ++k) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    }
+    return __hiloint2double(hi, lo);
+}
+template <class RHS> constexpr bool t5_dpp_ok() { return t5_gl<RHS>() <= 2 && t5_gr<RHS>() <= 2; }
+template <class RHS, int U> struct T5Gather {
+    static __device__ __forceinline__ void run(const double *e, double *r)
+    {
+        r[U] = lane_from<RHS::g_off(U)>(e[RHS::g_e(U)]);
+        T5Gather<RHS, U - 1>::run(e, r);
+    }
+};
+template <class RHS> struct T5Gather<RHS, -1> { static __device__ __forceinline__ void run(const double *, double *) {} };
+
+// XDPP: the scatter products change lanes through DPP shifts instead of the wave's LDS arrays
+template <class RHS, int DISC, int DC, int NSLOT, bool LSRUN, bool XDPP>
 __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
 {
     static_assert(DISC != DISC_SH, "one-step discretisations only");
@@ -43,7 +69,7 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
     constexpr Geo5 gcc = tile5_cols_rhs<RHS>(DC > 0 ? DC : 128);
     const Geo5 gc = DC > 0 ? gcc : dv.g5;
     const int D = DC > 0 ? DC : dv.g5.D;
-    const int PR = gc.PR, CW = gc.CW, GL = gc.GL, XL = gc.XL, PW = gc.PW, PL = gc.PL;
+    const int PR = gc.PR, GL = gc.GL, XL = gc.XL, PW = gc.PW, PL = gc.PL;
     const int NSG = gc.NSG, WPG = gc.WPG;
     const int SEGL = dv.g5.SEGL, YPMAX = dv.g5.YPMAX;
     const int SLOTX = 4 * PR, SLOTY = 4 * YPMAX;              // doubles per ring slot
@@ -59,19 +85,20 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int strip = grp * WPG + wave;
     const bool wave_on = strip < gc.NS;                       // (the last workgroup of a row may have idle waves)
-    const int WAVE = tile5_wave_doubles(dv.g5, NSLOT, LSRUN, NE);
+    const int WAVE = tile5_wave_doubles(dv.g5, NSLOT, LSRUN);
     double *xring = smem + wave * WAVE;
     double *dring = xring + NSLOT * SLOTX;
     double *yring = dring + (LSRUN ? NSLOT * SLOTX : 0);
     double *prod = yring + NSLOT * SLOTY;
+    double *outb = prod + NE * PW;                            // [2 rows][64 lanes]: the gradient rows of a slot on their way out
     double *strip_red = xring;                                // after the walk
 
     ThreadAcc acc;
     acc.clear();
     if (wave_on) {
         const int N = dm.N, L = dm.L;
-        const int c0 = strip * CW;
-        const int cws = (D - c0) < CW ? (D - c0) : CW;
+        const int c0 = tile5_c0(D, gc.NS, strip);
+        const int cws = tile5_c0(D, gc.NS, strip + 1) - c0;
         const int n0 = sg * SEGL, n1 = (n0 + SEGL) < N ? (n0 + SEGL) : N;
         const int rs = n0 > 0 ? n0 - 1 : 0, re = n1 < N ? n1 + 1 : N;
         const int SR = re - rs;                               // rows of the stream (>= 2)
@@ -83,7 +110,7 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
         // staging: lane -> (row of the slot, piece of the image row); the image is the cyclic column window
         // [c0 - XL, c0 - XL + 2 PR)
         const int rr = lane >= PR ? 1 : 0, pc = lane - rr * PR;
-        const bool dma_on = lane < 2 * PR;
+        const bool dma_on = lane < 2 * PR && 2 * pc < XL + cws + ((t5_gr<RHS>() + t5_xr<RHS>() + 1) & ~1);     // (a narrower strip stages fewer pieces)
         const unsigned xoff = (unsigned)(rr * D + t5_wrap(c0 - XL + 2 * pc, D)) * 8u;
         const int l_start = as_const(dv.ystrip)[2 * strip], YP = as_const(dv.ystrip)[2 * strip + 1];
         const int yrr = lane >= YP ? 1 : 0, ypc = lane - yrr * YP;
@@ -97,7 +124,12 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
         const double wobs = obs ? dm.rm : 0.0;
         const int xlane = XL - GL + lane;                     // own column inside a staged row
         const int ylane = obs ? lm - l_start : 0;
-        const int gvoff = (own && (lane & 1) == 0) ? (c0 + lane - GL) * 8 : 0x7ffffff0;
+        // gradient rows leave two at a time, 16 bytes per lane, lanes packed: lane -> (row of the pair, column pair)
+        const int hp = cws >> 1;                              // column pairs of the strip
+        const int srow = lane >= hp ? 1 : 0, spc = lane - srow * hp;
+        const int gvoff2 = lane < 2 * hp ? (srow * D + c0 + 2 * spc) * 8 : 0x7ffffff0;     // both rows of a pair
+        const int gvoff1 = lane < hp ? (c0 + 2 * lane) * 8 : 0x7ffffff0;                    // a single row
+        const double *outrd = outb + srow * 64 + GL + 2 * spc;
         const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(dv.gt + (size_t)b * dm.ld), 0, (int)(sizeof(double) * N * D), 0x00020000);
 
@@ -142,7 +174,7 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
         for (int k = 0; k < RHS::NP; ++k) gp[k] = 0.0;
 
         // finish row m = (row of the state registers): q = adjoint weight of the residual that starts at row m
-        auto emit = [&](int m, double q, int voff) {
+        auto emit = [&](double q, int orow) {
             double direct, s;
             if constexpr (DISC == DISC_TRAPEZOID) { direct = qp - q; s = -hdt * (qp + q); }
             else if constexpr (DISC == DISC_EULER) { direct = qp - q; s = -dt * q; }
@@ -150,13 +182,16 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
             double e[NE], diag;
             RHS::scatter(col, s, x0p, xnp, p, 0.0, nullptr, e, diag);
             RHS::pgrad(col, s, x0p, xnp, p, 0.0, nullptr, gp);
-#pragma unroll
-            for (int u = 0; u < NE; ++u) prod[u * PW + PL + lane] = e[u];
-            wave_sync_lds();
             double r[NG];
+            if constexpr (XDPP) T5Gather<RHS, NG - 1>::run(e, r);
+            else {
 #pragma unroll
-            for (int u = 0; u < NG; ++u) r[u] = VA_LDS_CVP(prod + RHS::g_e(u) * PW + PL + lane)[RHS::g_off(u)];
-            wave_sync_lds();                                  // (the next row overwrites the arrays)
+                for (int u = 0; u < NE; ++u) prod[u * PW + PL + lane] = e[u];
+                wave_sync_lds();
+#pragma unroll
+                for (int u = 0; u < NG; ++u) r[u] = VA_LDS_CVP(prod + RHS::g_e(u) * PW + PL + lane)[RHS::g_off(u)];
+                wave_sync_lds();                              // (the next row overwrites the arrays)
+            }
             const double diff = x0p - yp;
             me = fma(diff, diff, me);
             double gv = (direct + diag) + RHS::gather(r);
@@ -166,14 +201,22 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
                 gn2 = fma(gv, gv, gn2);
                 gmax = __builtin_fmax(gmax, __builtin_fabs(gv));
             }
-            typedef unsigned v4u __attribute__((ext_vector_type(4)));
-            const int glo = __double2loint(gv), ghi = __double2hiint(gv);
-            const int nlo = __builtin_amdgcn_update_dpp(0, glo, 0xF5, 0xF, 0xF, false);      // quad_perm [1,1,3,3]
-            const int nhi = __builtin_amdgcn_update_dpp(0, ghi, 0xF5, 0xF, 0xF, false);
-            const v4u v = {(unsigned)glo, (unsigned)ghi, (unsigned)nlo, (unsigned)nhi};
-            if (dv.gaux) __builtin_amdgcn_raw_buffer_store_b128(v, grs, voff, m * D * 8, 16);
-            else __builtin_amdgcn_raw_buffer_store_b128(v, grs, voff, m * D * 8, 0);
+            outb[orow * 64 + lane] = gv;
             qp = q;
+        };
+        // rows m0, m0 + 1 (or m0 alone) of the gradient: LDS -> 16-byte stores
+        auto flush = [&](int m0, int voff) {
+#if defined(VA_E5_ABLATE) && VA_E5_ABLATE == 1
+            return;
+#endif
+            wave_sync_lds();
+            double a0, a1;
+            ld2(outrd, a0, a1);
+            wave_sync_lds();
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            const v4u v = {(unsigned)__double2loint(a0), (unsigned)__double2hiint(a0), (unsigned)__double2loint(a1), (unsigned)__double2hiint(a1)};
+            if (dv.gaux) __builtin_amdgcn_raw_buffer_store_b128(v, grs, voff, m0 * D * 8, 16);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, grs, voff, m0 * D * 8, 0);
         };
         // one staged row in registers: own column, the stencil's neighbours, observation, own entry of d
         struct Row { double x0, xn[NB], yv, dval; };
@@ -190,7 +233,17 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
         };
         // row j enters: f_j, the residual of the interval (j-1, j), and row j-1 is finished; FIRST: only
         // load the state registers
-        auto step = [&](const Row &t, int j, bool first, int voff) {
+        auto step = [&](const Row &t, bool first, int orow) {
+#if defined(VA_E5_ABLATE) && VA_E5_ABLATE == 1
+            // measurement build: the staging ring alone (no arithmetic, no stores)
+            fe += t.x0; return;
+#elif defined(VA_E5_ABLATE) && VA_E5_ABLATE == 2
+            // measurement build: staging ring + the gradient stores (a copy)
+            {
+                if (!first) outb[orow * 64 + lane] = t.x0;
+                return;
+            }
+#endif
             const double f = RHS::f(col, t.x0, t.xn, p, 0.0, nullptr);
             if (!first) {
                 double r;
@@ -198,7 +251,7 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
                 else if constexpr (DISC == DISC_EULER) r = (t.x0 - x0p) - dt * fp;
                 else r = t.x0 - fp;
                 fe = fma(r, r, fe);
-                emit(j - 1, cw * r, voff);
+                emit(cw * r, orow);
             }
             x0p = t.x0; fp = f; yp = t.yv; dp = t.dval;
 #pragma unroll
@@ -210,9 +263,9 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
             if (k + P > nslots) {
                 if (!drained) { VA_WAIT_VM(0); drained = true; }
             } else if (LSRUN && use_d) {
-                if (k < P) VA_WAIT_VM((P - 1) * 3); else VA_WAIT_VM(1 + (P - 1) * 5 > 63 ? 63 : 1 + (P - 1) * 5);
+                if (k < P) VA_WAIT_VM((P - 1) * 3); else VA_WAIT_VM((P - 1) * 4);        // per slot in flight: x, d, Y rows + one gradient store
             } else {
-                if (k < P) VA_WAIT_VM((P - 1) * 2); else VA_WAIT_VM(1 + (P - 1) * 4 > 63 ? 63 : 1 + (P - 1) * 4);
+                if (k < P) VA_WAIT_VM((P - 1) * 2); else VA_WAIT_VM((P - 1) * 3);
             }
             __builtin_amdgcn_wave_barrier();
             if (k + P < nslots) issue(k + P, ppos);
@@ -232,8 +285,9 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
         begin_slot(0, 0, P % NSLOT);
         {
             const Row t0 = load_row(0, 0), t1 = load_row(0, 1);
-            step(t0, rs, true, 0);
-            step(t1, rs + 1, false, n0 > 0 ? 0x7ffffff0 : gvoff);
+            step(t0, true, 0);
+            step(t1, false, 0);
+            flush(rs, n0 > 0 ? 0x7ffffff0 : gvoff1);
         }
         if (n0 > 0) {
             fe = 0.0; me = 0.0; gtd = 0.0; gn2 = 0.0; gmax = 0.0;
@@ -245,17 +299,19 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
         for (int k = 1; k < nfull; ++k) {
             begin_slot(k, pos, ppos);
             const Row t0 = load_row(pos, 0), t1 = load_row(pos, 1);      // both rows' reads in flight before the first product exchange
-            step(t0, rs + 2 * k, false, gvoff);
-            step(t1, rs + 2 * k + 1, false, gvoff);
+            step(t0, false, 0);
+            step(t1, false, 1);
+            flush(rs + 2 * k - 1, gvoff2);
             pos = pos + 1 == NSLOT ? 0 : pos + 1;
             ppos = ppos + 1 == NSLOT ? 0 : ppos + 1;
         }
         if (SR & 1) {
             begin_slot(nfull, pos, ppos);
             const Row t0 = load_row(pos, 0);
-            step(t0, rs + 2 * nfull, false, gvoff);
+            step(t0, false, 0);
+            flush(rs + 2 * nfull - 1, gvoff1);
         }
-        if (re == N && n1 == N) emit(N - 1, 0.0, gvoff);      // the path's last row: no residual starts there
+        if (n1 == N) { emit(0.0, 0); flush(N - 1, gvoff1); }    // the path's last row: no residual starts there
         if (!drained) VA_WAIT_VM(0);
 
         // ---- the lane's sums (lanes outside the strip's own columns computed ghosts: not theirs to count)
@@ -296,9 +352,46 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
         eval_epilogue<true>(dv, b, lane, reinterpret_cast<SeedHot *>(smem + T4_STRIP), dv.epi);
 }
 
-inline size_t eval5_lds_bytes(const Dev &dv, int nslot, bool ls, int ne)
+inline size_t eval5_lds_bytes(const Dev &dv)
 {
-    return sizeof(double) * (size_t)dv.g5.WPG * tile5_wave_doubles(dv.g5, nslot, ls, ne);
+    return sizeof(double) * (size_t)dv.g5.WPG * tile5_wave_doubles(dv.g5, dv.lsrun ? dv.g5.nslot_ls : dv.g5.nslot, dv.lsrun != 0);
+}
+
+// launch (or, once per handle and device, opt in to > 64 KiB of LDS) the instantiation the handle's geometry and
+// this launch's kind call for: ring depth and "line-search points possible" are template parameters
+template <class RHS, int DISC, int DC, bool XDPP>
+inline hipError_t eval5_slots(const Dev &dv, bool prepare, hipStream_t s)
+{
+    const int threads = 64 * dv.g5.WPG;
+    if (prepare) {
+        hipError_t err = hipSuccess;
+        Dev t = dv;
+        for (int ls = 0; ls < 2; ++ls) {          // both launch kinds of the handle
+            t.lsrun = ls;
+            if (eval5_lds_bytes(t) <= 64 * 1024) continue;
+            const int ns = ls ? t.g5.nslot_ls : t.g5.nslot;
+            hipError_t e = hipSuccess;
+#define VA_E5_ATTR(NSL, LS) e = hipFuncSetAttribute((const void *)k_eval5<RHS, DISC, DC, NSL, LS, XDPP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+            if (ls) { if (ns == 3) VA_E5_ATTR(3, true); else VA_E5_ATTR(4, true); }
+            else { if (ns == 3) VA_E5_ATTR(3, false); else VA_E5_ATTR(4, false); }
+#undef VA_E5_ATTR
+            if (e != hipSuccess) err = e;
+        }
+        return err;
+    }
+    const size_t lds = eval5_lds_bytes(dv);
+    const int ns = dv.lsrun ? dv.g5.nslot_ls : dv.g5.nslot;
+    const int grid = ((dv.dm.B * dv.dm.ntiles + 7) / 8) * 8;
+#define VA_E5_GO(NSL, LS) hipLaunchKernelGGL((k_eval5<RHS, DISC, DC, NSL, LS, XDPP>), dim3(grid), dim3(threads), lds, s, dv)
+    if (dv.lsrun) { if (ns == 3) VA_E5_GO(3, true); else VA_E5_GO(4, true); }
+    else { if (ns == 3) VA_E5_GO(3, false); else VA_E5_GO(4, false); }
+#undef VA_E5_GO
+    return hipSuccess;
+}
+template <class RHS, int DISC, int DC>
+inline hipError_t eval5_run(const Dev &dv, bool prepare, hipStream_t s)
+{
+    return dv.g5.xdpp ? eval5_slots<RHS, DISC, DC, t5_dpp_ok<RHS>()>(dv, prepare, s) : eval5_slots<RHS, DISC, DC, false>(dv, prepare, s);
 }
 
 }  // namespace va

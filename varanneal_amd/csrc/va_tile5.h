@@ -26,7 +26,7 @@ constexpr int T5_WPG_MAX = 4;     // strips (waves) per workgroup
 constexpr int T5_MAX_STRIPS = 64;
 
 struct Geo5 {
-    int D, NS, CW;        // strips per row, owned columns per strip (even; the last strip may own fewer)
+    int D, NS, CW;        // strips per row (tile5_c0), owned columns of the widest strip
     int NSG, WPG;         // workgroups per row of strips, waves per workgroup
     int GL;               // lane of a strip's first owned column (even: owned column pairs are lane pairs)
     int XL;               // image columns left of the first owned one (even)
@@ -37,6 +37,8 @@ struct Geo5 {
     int SEGL, NSEG;       // time rows per segment, segments per seed
     int YPMAX;            // 16-byte pieces per observation row of the widest strip
     int nslot, nslot_ls;  // ring slots: plain evaluation / launches that may hold line-search points
+    int ne;               // products per element of the model's column form (LDS arrays of the non-DPP exchange)
+    int xdpp;             // scatter products change lanes through DPP shifts (gather reach <= 2) instead of LDS
 };
 
 template <class RHS> VA_HD constexpr int t5_xl()
@@ -64,14 +66,31 @@ template <class RHS> VA_HD constexpr int t5_gr()
     return m;
 }
 
+// first column of strip s5 (s5 = NS: D).  Strips start on multiples of 8 columns = 64 bytes, so that no 64-byte
+// sector of a row of x or of the gradient is shared between two waves; widths differ by at most 8 columns
+// (the last strip also takes D mod 8).
+VA_HD constexpr int tile5_c0(int D, int NS, int s5)
+{
+    return s5 >= NS ? D : 8 * ((s5 * (D / 8)) / NS);
+}
+VA_HD constexpr int tile5_maxw(int D, int NS)
+{
+    int m = 0;
+    for (int s5 = 0; s5 < NS; ++s5) {
+        const int w = tile5_c0(D, NS, s5 + 1) - tile5_c0(D, NS, s5);
+        m = w > m ? w : m;
+    }
+    return m;
+}
+
 // column geometry from the state width and the reaches of the model's column form
 VA_HD constexpr Geo5 tile5_cols(int D, int xl, int xr, int gl, int gr)
 {
     Geo5 g{};
     g.D = D;
     g.NS = (D + T5_CW_MAX - 1) / T5_CW_MAX;
-    g.CW = (((D + g.NS - 1) / g.NS) + 1) & ~1;
-    g.NS = (D + g.CW - 1) / g.CW;
+    while (g.NS < T5_MAX_STRIPS && tile5_maxw(D, g.NS) > T5_CW_MAX) ++g.NS;
+    g.CW = tile5_maxw(D, g.NS);                 // the widest strip
     g.WPG = g.NS < T5_WPG_MAX ? g.NS : T5_WPG_MAX;
     g.NSG = (g.NS + g.WPG - 1) / g.WPG;
     g.GL = (gl + 1) & ~1;
@@ -99,10 +118,11 @@ VA_HD constexpr int t5_wrap(int c, int D) { return c < 0 ? c + D : (c >= D ? c -
 
 // doubles of LDS one wave needs: x ring (+ d ring), observation ring, product arrays.  The reduction strip
 // and the tail's copy of the seed state re-use the rings after the walk.
-VA_HD constexpr int tile5_wave_doubles(const Geo5 &g, int nslot, bool ls, int ne)
+VA_HD constexpr int tile5_wave_doubles(const Geo5 &g, int nslot, bool ls)
 {
+    const int ne = g.ne;
     const int slotx = 4 * g.PR, sloty = 4 * g.YPMAX;
-    const int rings = nslot * (slotx * (ls ? 2 : 1) + sloty) + ne * g.PW;
+    const int rings = nslot * (slotx * (ls ? 2 : 1) + sloty) + ne * g.PW + 128;     // (+ the gradient rows of a slot on their way out)
     const int minimum = T4_STRIP + 64;        // reduction strip + SeedHot copy (512 B)
     return ((rings > minimum ? rings : minimum) + 15) & ~15;
 }

@@ -10,6 +10,7 @@
 #include "va_eval_flat.h"
 #include "va_eval3.h"
 #include "va_eval4.h"
+#include "va_eval5.h"
 
 #ifndef VA_USER_RHS_HEADER
 #error "compile with -DVA_USER_RHS_HEADER='\"path/to/generated_header.h\"'"
@@ -40,26 +41,43 @@ int va_user_prepare_eval(const va::Dev *dv)
 // was generated (va_eval_plan; -DVA_USER_EK=3|4 -DVA_USER_DISC -DVA_USER_K -DVA_USER_W):
 //   EK = 4: the model's column form (struct RhsUserCol: a translation-invariant stencil, or a small dense
 //           system) on the wave-private kernel k_eval4; W = 1 for scalar weights
+//   EK = 5: a stencil's column form on the streaming kernel k_eval5 (wide even states, autonomous, one-step
+//           discretisations, scalar weights)
 //   EK = 3: a stencil's ghosted form (struct RhsUserG) on the workgroup kernel k_eval3; W = threads per workgroup
-// (eval kernel or 0, DISC, K, W, products per element [4], ghost columns [3])
-#if defined(VA_USER_EK) && VA_USER_EK == 4 && defined(VA_USER_COL)
+// (eval kernel or 0, DISC, K, W, products per element [4, 5], ghost columns [3], reaches xl, xr, gl, gr [5])
+#if defined(VA_USER_EK) && VA_USER_EK == 5 && defined(VA_USER_COL)
+#define VA_USER_VARIANT 5
+#elif defined(VA_USER_EK) && VA_USER_EK == 4 && defined(VA_USER_COL)
 #define VA_USER_VARIANT 4
 #elif defined(VA_USER_EK) && VA_USER_EK == 3 && defined(VA_USER_GHOST)
 #define VA_USER_VARIANT 3
 #endif
 void va_user_variant_info(int *out)
 {
-    out[0] = out[1] = out[2] = out[3] = out[4] = out[5] = 0;
+    for (int k = 0; k < 10; ++k) out[k] = 0;
 #ifdef VA_USER_VARIANT
     out[0] = VA_USER_VARIANT; out[1] = VA_USER_DISC; out[2] = VA_USER_K; out[3] = VA_USER_W;
-#if VA_USER_VARIANT == 4
+#if VA_USER_VARIANT == 5
+    out[4] = va::RhsUserCol::NE;
+    out[6] = va::t5_xl<va::RhsUserCol>(); out[7] = va::t5_xr<va::RhsUserCol>();
+    out[8] = va::t5_gl<va::RhsUserCol>(); out[9] = va::t5_gr<va::RhsUserCol>();
+#elif VA_USER_VARIANT == 4
     out[4] = va::RhsUserCol::NE;
 #else
     out[5] = va::RhsUserG::GHOST;
 #endif
 #endif
 }
-#if defined(VA_USER_VARIANT) && VA_USER_VARIANT == 4
+#if defined(VA_USER_VARIANT) && VA_USER_VARIANT == 5
+void va_user_launch_variant(const va::Dev *dv, void *stream)
+{
+    (void)va::eval5_run<va::RhsUserCol, VA_USER_DISC, va::RhsUserCol::D>(*dv, false, (hipStream_t)stream);
+}
+int va_user_prepare_variant(const va::Dev *dv)
+{
+    return (int)va::eval5_run<va::RhsUserCol, VA_USER_DISC, va::RhsUserCol::D>(*dv, true, nullptr);
+}
+#elif defined(VA_USER_VARIANT) && VA_USER_VARIANT == 4
 void va_user_launch_variant(const va::Dev *dv, void *stream)
 {
     va::launch_eval4_one<va::RhsUserCol, VA_USER_DISC, VA_USER_K, va::RhsUserCol::D, VA_USER_W != 0>(*dv, (hipStream_t)stream);

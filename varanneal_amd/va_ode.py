@@ -340,19 +340,6 @@ class Annealer(HIPmin):
         self._Pfull = np.array(Pf, dtype=np.float64)
         self.adolcID = adolcID                        # accepted, unused: there is no tape
 
-        jit_builtin = False
-        if (rhs_id is not None and self.D > 64 and self.D != 200 and not self._tdp
-                and os.environ.get("VARANNEAL_AMD_JIT_WIDE", "1") != "0"):
-            # A wide built-in model: the library compiles the state width into its workgroup kernel only for
-            # D = 200 (BASELINE config 4); a module generated from the registry's own callable has D compiled in
-            # for any width (measured at D = 500: 295 against 389 us per evaluation of 64 seeds).  Used when the
-            # problem would run that kernel anyway; any failure on the way keeps the built-in.
-            plan = _capi.eval_plan(self.B, self.D, self.N_model, disc, 0, 2,
-                                   rm_array=isinstance(self.RM, np.ndarray), rm_full=np.ndim(self.RM) == 3,
-                                   rf_array=isinstance(self.RF0, np.ndarray), rf_full=np.ndim(self.RF0) == 3,
-                                   merr_nskip=self.merr_nskip, bounded=self._device_bounds)
-            if plan is not None and plan[0] == 3:
-                jit_builtin, builtin_id, rhs_id = True, rhs_id, None
         if rhs_id is None:
             # trace the callable, differentiate it, emit HIP, compile a module.  A model with a column form
             # (codegen.column_form: stencils, small dense systems) or a ghosted form (codegen.ghost_form: wide
@@ -361,24 +348,17 @@ class Annealer(HIPmin):
             from . import codegen
             nstim = 0 if stim is None else (1 if stim.ndim == 1 else stim.shape[1])
 
-            def variant(ne, ghost):
+            def variant(ne, ghost, reach=None):
                 return _capi.eval_plan(self.B, self.D, self.N_model, disc, ne, ghost,
                                         rm_array=isinstance(self.RM, np.ndarray), rm_full=np.ndim(self.RM) == 3,
                                         rf_array=isinstance(self.RF0, np.ndarray), rf_full=np.ndim(self.RF0) == 3,
                                         merr_nskip=self.merr_nskip,
-                                        bounded=self._device_bounds, p_time_dependent=self._tdp)
-            try:
-                f = _rhs.REGISTRY[self._rhs_name][0] if jit_builtin else self.f
-                mod = codegen.module_for(f, self.D, self.NP, nstim, 1 if stim is None else stim.ndim,
-                                         p_rows=self._tdp, col_variant=variant)
-                if jit_builtin and (mod["col_variant"] is None or mod["col_variant"][0] != 3):
-                    raise RuntimeError("no ghosted form")
-                rhs_id = _capi.load_rhs_module(mod["so"])
-                self._rhs_module = mod
-            except Exception:
-                if not jit_builtin:
-                    raise
-                rhs_id = builtin_id                   # (no SymPy / no hipcc / ...: the library's own kernel)
+                                        bounded=self._device_bounds, p_time_dependent=self._tdp,
+                                        reach=reach, Lidx=self.Lidx)
+            mod = codegen.module_for(self.f, self.D, self.NP, nstim, 1 if stim is None else stim.ndim,
+                                     p_rows=self._tdp, col_variant=variant)
+            rhs_id = _capi.load_rhs_module(mod["so"])
+            self._rhs_module = mod
 
         # device image
         if self._pb is not None:
