@@ -185,7 +185,8 @@ def extra_c4(device, steps=60):
         pb.eval_timed(RF_SCALE, 10)
         ks = pb.eval_timed(RF_SCALE, steps) * 1e-3 / steps
     balg = bytes_alg(B, N, D, 1, N, len(Lidx))
-    return {"workload": w["name"], "kernel": kernel_name(D, info) + " + k_finalize_eval",
+    return {"workload": w["name"], "kernel": kernel_name(D, info) + ("" if B * info["ntiles"] <= 2048 else " + k_finalize_eval"),
+            "traffic": pmc_traffic(w["name"]),
             "us_per_eval_launch": ks * 1e6, "evals_per_s": B / ks, "bytes_alg_per_launch": balg,
             "achieved_GBs": balg / ks / 1e9, "frac": balg / ks / 1e9 / HBM_PEAK_GBS}
 
