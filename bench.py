@@ -443,6 +443,8 @@ def main():
                     help="run the workload's Lorenz-96 as a user would supply it: a Python callable traced and "
                          "compiled by varanneal_amd.codegen (not the built-in right-hand side)")
     ap.add_argument("--eval-kernel", type=int, default=0, help="0 auto, 1 flat-mapped, 3 workgroup column runs, 4 wave-private column runs, 5 streaming column strips")
+    ap.add_argument("--tune", default="", help="comma-separated va_problem_tune knobs for the measured handle, e.g. fold=0,graph=0 "
+                                               "(recorded in config.tune; none changes a result)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal without a GPU: every rank joins the process group (--backend gloo), "
                          "rank 0 prints the contract line's bookkeeping fields (n_gpus, config.rccl_ranks) and nothing is timed")
@@ -503,6 +505,8 @@ def main():
         rhs = _capi.load_rhs_module(mod["so"])
     pb = _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", rhs=rhs,
                        device=local_rank, tile_rows=args.tile_rows, eval_kernel=args.eval_kernel)
+    tune = {k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(",") if kv)}
+    pb.tune(**tune)
     info = pb.info()
     if args.mode == "ladder":
         ladder_mode(args, pb, XP, P, D, N, B, Y, Lidx, local_rank)
@@ -530,7 +534,7 @@ def main():
             "config": {"workload": w["name"], "seeds_per_gpu": B, "D": D, "N": N, "L": len(Lidx),
                        "disc": "trapezoid", "tile_rows": info["tile_rows"], "ntiles": info["ntiles"],
                        "parallelism": "seeds sharded, %d per GPU" % B, "final_gather_ms": gather_ms,
-                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "env": env_set},
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "env": env_set, "tune": tune},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "step": "complete S1 evaluation: A, me, fe formed in the same launch (va_epilogue.h)",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(w["name"]),

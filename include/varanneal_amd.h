@@ -141,6 +141,16 @@ void va_problem_destroy(va_handle h);
 int va_problem_info(va_handle h, int64_t *n_var, int64_t *ld_internal, int32_t *tile_rows,
                     int32_t *ntiles);
 
+/* Performance knobs of a handle.  None changes a result: the same sums are formed in the same order whichever
+ * launch forms them (tests/test_gpu_parity.py::test_tuning_knobs_leave_every_bit_alone).  There are no environment
+ * variables behind the library's choices; bench.py reports the knobs it was asked to set. */
+#define VA_TUNE_FOLD 1       /* 1: the seed's last-arriving workgroup forms A / runs the line-search step inside the
+                              * evaluation kernel (default while the grid is <= 8 workgroups per CU); 0: tail kernels */
+#define VA_TUNE_GRAD_SC1 2   /* 1: gradient stores write through (default with FOLD)                                   */
+#define VA_TUNE_PRIO 3       /* 1: later-dispatched workgroups of a CU issue at higher priority (default)            */
+#define VA_TUNE_GRAPH 4      /* 1: ladder cycles and timed evaluations are replayed from a hipGraph (default)        */
+int va_problem_tune(va_handle h, int32_t what, int32_t value);
+
 /* Which evaluation kernel the handle runs (the values of va_problem_desc.eval_kernel: 1 flat,
  * 3 workgroup column runs, 4 wave-private column runs, 5 streaming column strips) and the rows per lane run
  * (0 for the flat kernel, 2 = rows per ring slot for the streaming kernel). */

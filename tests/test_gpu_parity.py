@@ -469,3 +469,35 @@ def test_long_path_and_many_seeds(capi):
         Ao, meo, feo, go = opb.action_grad(XP[b], 1000.0)
         assert abs(A[b] - Ao) <= RTOL_A * abs(Ao) and np.abs(g[b] - go).max() <= RTOL_G * np.abs(go).max()
     pb.close()
+
+
+@pytest.mark.parametrize("D,N,B", [(20, 1000, 64), (200, 600, 8), (20, 161, 3)])
+def test_tuning_knobs_leave_every_bit_alone(capi, D, N, B):
+    """va_problem_tune: the tail folded into the evaluation kernel (the seed's last-arriving workgroup reads the
+    rows the others published) against the tail as kernels of their own, write-through against write-back gradient
+    stores, plain launches against graph replay -- A, me, fe, the gradient and a short ladder are bit-identical.
+    (The library reads no environment variable.)"""
+    from varanneal_amd import twin
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    if len(Lidx) % 2 and D > 64:
+        Lidx = Lidx[:-1]; Y = Y[:, :-1]
+    XP = np.empty((B, N * D + 1)); P = np.empty((B, 1))
+    for b in range(B):
+        X0, P0 = twin.initial_guess(N, D, b, Y, Lidx)
+        XP[b, :-1] = X0.ravel(); XP[b, -1] = P0[0]; P[b] = P0
+    rf = 1.5 ** np.arange(3)
+    o = dict(OPTS, maxiter=12)
+    ref = None
+    for knobs in ({}, {"fold": 0}, {"fold": 0, "grad_sc1": 1}, {"grad_sc1": 0}, {"prio": 0, "graph": 0}):
+        with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", max_beta=3) as pb:
+            pb.tune(**knobs)
+            ev = pb.action_grad(XP, 7.0)
+            pb.eval_timed(7.0, 9)
+            ev2 = pb.read_eval_outputs()
+            lad = pb.anneal(XP, rf, o)
+        got = list(ev) + list(ev2) + [lad["A"], lad["pest"], lad["nit"], lad["nfev"]]
+        if ref is None:
+            ref = got
+        else:
+            for a, b2 in zip(ref, got):
+                assert np.array_equal(a, b2), knobs

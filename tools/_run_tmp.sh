@@ -1,3 +1,5 @@
-mkdir -p gpurun_out/r3l
-timeout -k 10 600 python -m pytest tests/test_gpu_annealer.py tests/test_gpu_parity.py tests/test_gpu_codegen.py -m gpu -q > gpurun_out/r3l/gpu.log 2>&1; tail -4 gpurun_out/r3l/gpu.log
-python bench.py > gpurun_out/r3l/bench_c3.json 2> gpurun_out/r3l/bench_c3.err; cut -c1-1500 gpurun_out/r3l/bench_c3.json
+mkdir -p gpurun_out/r3u
+timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/r3u/gpu.log 2>&1; tail -3 gpurun_out/r3u/gpu.log
+grep -q failed gpurun_out/r3u/gpu.log && exit 1
+timeout -k 10 200 ./tools/e4abl.sh > gpurun_out/r3u/abl.txt 2>&1; cat gpurun_out/r3u/abl.txt
+timeout -k 10 200 ./tools/e4abl.sh --tune graph=0 > gpurun_out/r3u/abl_eager.txt 2>&1; tail -6 gpurun_out/r3u/abl_eager.txt

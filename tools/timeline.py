@@ -32,11 +32,19 @@ for rep in range(3):
     for k in (0, 2, 3, 4, 5, 6):
         a = us[:, :, k]
         print("   %-8s all waves: min %5.2f  median %5.2f  p90 %5.2f  max %5.2f us" % (names[k], a.min(), np.median(a), np.percentile(a, 90), a.max()))
-    a = w0[:, 7]
-    print("   %-8s wave 0   : min %5.2f  median %5.2f  p90 %5.2f  max %5.2f us" % (names[7], a.min(), np.median(a), np.percentile(a, 90), a.max()))
-    tail = w0[:, 1]
-    tail = tail[tail > w0[:, 7]]
-    print("   tail done (last workgroup of each seed, %d): min %5.2f median %5.2f max %5.2f us" % (len(tail), tail.min(), np.median(tail), tail.max()))
+    # the tail wave (wave 0 of each seed's last tile) re-uses slots: 7 tail starts, 2 rows validated, 5 outputs issued, 1 all its stores acknowledged
+    nt = info["ntiles"]
+    tw = np.array([us[w, 0, :] for w in range(nwg) if False])
+    import itertools
+    per = (nwg + 7) >> 3
+    tails = []
+    for bid in range(nwg):
+        w = (bid & 7) * per + (bid >> 3)
+        if w < B * nt and w % nt == nt - 1:
+            tails.append(us[bid, 0, :])
+    tails = np.array(tails)
+    for k, nm in ((3, "rows done"), (7, "tail starts"), (2, "rows valid"), (5, "outputs out"), (4, "gather done"), (1, "stores acked")):
+        print("   tail wave %-12s: min %5.2f median %5.2f max %5.2f us" % (nm, tails[:, k].min(), np.median(tails[:, k]), tails[:, k].max()))
     d = np.diff(us[:, :, [0, 2, 3, 4, 5, 6]], axis=2)
     print("   phase medians: wait-for-image %.2f  rows %.2f  gather %.2f  sums %.2f  barrier %.2f" % tuple(np.median(d[:, :, i]) for i in range(5)))
     grp = (np.arange(nwg) >> 8) % 3

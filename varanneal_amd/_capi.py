@@ -208,7 +208,8 @@ def lib():
     L.va_read_eval_outputs.argtypes = [h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.va_debug_read_partials.argtypes = [h, c_dp, C.c_int64]
     L.va_problem_eval_kernel.argtypes = [h, c_ip, c_ip]
-    for fn in ("va_device_count", "va_rhs_load_module", "va_act_load_module", "va_eval_plan", "va_eval_plan_reach", "va_problem_eval_kernel", "va_problem_create", "va_nnet_problem_create",
+    L.va_problem_tune.argtypes = [h, C.c_int32, C.c_int32]
+    for fn in ("va_device_count", "va_rhs_load_module", "va_act_load_module", "va_eval_plan", "va_eval_plan_reach", "va_problem_eval_kernel", "va_problem_tune", "va_problem_tune", "va_problem_create", "va_nnet_problem_create",
                "va_problem_info", "va_action_grad",
                "va_minimize_lbfgs", "va_anneal", "va_get_minpath", "va_eval_timed",
                "va_get_counters", "va_debug_read_partials", "va_read_eval_outputs", "va_lbfgs_timed",
@@ -218,7 +219,7 @@ def lib():
     return L
 
 
-EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_act_load_module", "va_eval_plan", "va_eval_plan_reach", "va_problem_eval_kernel", "va_problem_create",
+EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_act_load_module", "va_eval_plan", "va_eval_plan_reach", "va_problem_eval_kernel", "va_problem_tune", "va_problem_create",
            "va_problem_destroy", "va_problem_info", "va_action_grad", "va_minimize_lbfgs",
            "va_anneal", "va_get_minpath", "va_eval_timed", "va_get_counters", "va_nnet_problem_create", "va_debug_read_partials",
            "va_read_eval_outputs", "va_lbfgs_timed", "va_comm_unique_id", "va_comm_create", "va_comm_destroy",
@@ -350,6 +351,13 @@ class Problem(object):
         check(self._L.va_problem_eval_kernel(self._h, C.byref(ek), C.byref(rr)))
         return dict(n_var=nv.value, ld=ld.value, tile_rows=T.value, ntiles=nt.value, eval_kernel=ek.value,
                     run_rows=rr.value)
+
+    TUNE = {"fold": 1, "grad_sc1": 2, "prio": 3, "graph": 4}      # VA_TUNE_* of include/varanneal_amd.h
+
+    def tune(self, **knobs):
+        """performance knobs that change no result: fold= (tail inside the evaluation kernel), grad_sc1=, prio=, graph="""
+        for k, v in knobs.items():
+            check(self._L.va_problem_tune(self._h, self.TUNE[k], int(v)))
 
     def _xp(self, XP):
         XP = _f64(XP)

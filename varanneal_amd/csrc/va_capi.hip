@@ -78,6 +78,9 @@ struct va_problem_s {
     NnetActLaunch user_act = nullptr;  // generated activation module's launcher (nn.act >= NNET_USER)
     bool is_nnet = false;              // feed-forward-network action (va_nnet.hip) instead of an ODE path
     bool fold = false;                 // the evaluation kernel runs the tail itself (last arriver of each seed)
+    bool tune_graph = true;            // ladder cycles / timed evaluations replayed from a hipGraph (va_problem_tune)
+    hipGraphExec_t timed_gexec = nullptr;   // va_eval_timed's chunk of launches
+    int timed_chunk = 0;
     NnetDev nn;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -434,9 +437,8 @@ int run_ladder(va_handle h, const double *rf_scale, int nbeta)
     // ~4 us each against ~25 us of device time): once the polling interval has grown to 64 cycles,
     // that batch of 192 launches is captured ONCE into a hipGraph and replayed.  The kernels take the device image
     // by value, so the graph is private to this call (ladder length, options).
-    static const bool no_graph = [] { const char *e = getenv("VA_NO_GRAPH"); return e && atoi(e) != 0; }();
     hipGraphExec_t gexec = nullptr;
-    bool use_graph = !no_graph;
+    bool use_graph = h->tune_graph;
     auto enqueue = [&](int n) {
         for (int k = 0; k < n; ++k) {
             run_eval(h, EPI_LS);
@@ -684,10 +686,8 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
         return fail(VA_EUNSUPPORTED, "batch x tiles too large for the wave-private kernel: pass eval_kernel=3");
     }
     dv.ntiles_magic = (unsigned)(((1ull << 32) + dm.ntiles - 1) / dm.ntiles);
-    {   // fold the tail into the evaluation kernel while the whole grid is resident at once (<= 8 workgroups per CU)
-        const char *e = getenv("VA_FOLD");
-        h->fold = e ? atoi(e) != 0 : (long)dm.B * dm.ntiles <= 8L * 256;
-    }
+    // fold the tail into the evaluation kernel while the whole grid is resident at once (<= 8 workgroups per CU)
+    h->fold = (long)dm.B * dm.ntiles <= 8L * 256;
     dm.nprow = dm.ntiles;                                                    // one partial row per workgroup
     dm.chunk = VEC_CHUNK; dm.nchunks = (dm.ld + VEC_CHUNK - 1) / VEC_CHUNK;
     dm.dt = d->dt_model;
@@ -698,8 +698,8 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dv.evcols = EP_GP + d->NP <= 8 ? 8 : (EP_GP + d->NP <= 16 ? 16 : 32);
     // write-through gradient stores pay where the grid is one resident round and the end-of-kernel write-back
     // of 10 MB is on the critical path (C3: -1.3 us); on large grids they cost 10 % (4096 seeds: 446 vs 404 us)
-    { const char *e = getenv("VA_GRAD_SC1"); dv.gaux = e ? atoi(e) : (h->fold ? 1 : 0); }
-    { const char *e = getenv("VA_PRIO"); dv.prio = e ? atoi(e) : 1; }
+    dv.gaux = h->fold ? 1 : 0;
+    dv.prio = 1;
     dv.o.m = m; dv.o.maxiter = 15000; dv.o.maxls = 20; dv.o.maxfun = 15000; dv.o.ftol = 2.2204460492503131e-09; dv.o.gtol = 1e-5;
 
     {
@@ -913,8 +913,6 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
         int widest = d->M;
         for (int n = 0; n < NL; ++n) widest = s[n] > widest ? s[n] : widest;
         nn.small = (widest <= NN_SMALL && NL <= NN_ROWS_DIRECT) ? (widest <= 16 ? 16 : 32) : 0;
-        const char *e = getenv("VA_NNET_SMALL");                      // tests: force the tiled path
-        if (e && atoi(e) == 0) nn.small = 0;
     }
     if (nn.small) nn.nraw = NL;
     const bool fold_rows = nn.nraw > NN_ROWS_DIRECT;      // k_ls sums the rows with one wave: keep them few
@@ -970,6 +968,7 @@ void va_problem_destroy(va_handle h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->timed_gexec) (void)hipGraphExecDestroy(h->timed_gexec);
     for (void *p : h->allocs) (void)hipFree(p);
     if (h->h_nactive) (void)hipHostFree(h->h_nactive);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1081,16 +1080,51 @@ int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms
     HIPCHK(hipSetDevice(h->device));
     Dev &dv = h->dv;
     launch_init_states(dv, PH_START, rf_scale, h->stream);
+    // Each launch forms A, me, fe and the full gradient.  The launches are replayed from a hipGraph in chunks:
+    // a host thread issues ~3.7 us apart, which would be the number measured for any kernel shorter than that
+    // (the same kernel boundary either way: MI355X_MICROARCH.md, "boundary: eager = hipGraph").
+    const int chunk = iters < 500 ? iters : 500;
+    if (h->timed_gexec && (h->timed_chunk != chunk || !h->tune_graph)) { (void)hipGraphExecDestroy(h->timed_gexec); h->timed_gexec = nullptr; }
+    if (h->tune_graph && iters >= 8 && !h->timed_gexec) {
+        // (kept on the handle: the warm-up call builds it, the timed call replays it)
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            for (int i = 0; i < chunk; ++i) run_eval(h, EPI_FINALIZE);
+            if (hipStreamEndCapture(h->stream, &g) != hipSuccess || !g ||
+                hipGraphInstantiate(&h->timed_gexec, g, nullptr, nullptr, 0) != hipSuccess) h->timed_gexec = nullptr;
+            if (g) (void)hipGraphDestroy(g);
+        }
+        if (!h->timed_gexec) (void)hipGetLastError();
+        else { h->timed_chunk = chunk; (void)hipGraphUpload(h->timed_gexec, h->stream); }
+    }
+    hipGraphExec_t gexec = (h->tune_graph && iters >= 8) ? h->timed_gexec : nullptr;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    // each launch forms A, me, fe and the full gradient (VA_TIMED_EPI=0: profiling ablation without the tail)
-    static const int timed_epi = [] { const char *e = getenv("VA_TIMED_EPI"); return e ? atoi(e) : (int)EPI_FINALIZE; }();
-    for (int i = 0; i < iters; ++i) run_eval(h, timed_epi);
+    int done = 0;
+    if (gexec)
+        for (; done + chunk <= iters; done += chunk) HIPCHK(hipGraphLaunch(gexec, h->stream));
+    for (; done < iters; ++done) run_eval(h, EPI_FINALIZE);
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventSynchronize(h->ev1));
     HIPCHK(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
     HIPCHK(hipGetLastError());
     h->n_eval_launch += iters; h->n_seed_evals += (int64_t)iters * dv.dm.B;
     h->n_seed_evals_direct += (int64_t)iters * dv.dm.B;
+    return VA_OK;
+}
+
+int va_problem_tune(va_handle h, int32_t what, int32_t value)
+{
+    if (!h) return fail(VA_EINVAL, "null handle");
+    if (h->timed_gexec) { (void)hipGraphExecDestroy(h->timed_gexec); h->timed_gexec = nullptr; }      // (captured with the old settings)
+    switch (what) {
+    case VA_TUNE_FOLD:
+        if (h->is_nnet) return fail(VA_EUNSUPPORTED, "the network action chooses its tail by the net's size");
+        h->fold = value != 0; break;
+    case VA_TUNE_GRAD_SC1: h->dv.gaux = value != 0 ? 1 : 0; break;
+    case VA_TUNE_PRIO: h->dv.prio = value != 0 ? 1 : 0; break;
+    case VA_TUNE_GRAPH: h->tune_graph = value != 0; break;
+    default: return fail(VA_EINVAL, "unknown tuning knob %d", what);
+    }
     return VA_OK;
 }
 

@@ -50,6 +50,9 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : (K <= 7 ? 3 : 2)) void k_eval4(c
 #define STAMP(i) do { } while (0)
 #endif
     STAMP(0);
+#if defined(VA_E4_ABLATE) && VA_E4_ABLATE == 1
+    return;                                   // measurement build (profiles/r03_ablation_c3.txt): the launch alone
+#endif
     // with D fixed at compile time the whole geometry (and every LDS offset) is constant
     const Geo4 g = DC > 0 ? tile4_geo<HL + HR>(DC > 0 ? DC : 4, K, NE, SUB) : dv.g4;
     constexpr int NI = DC > 0 ? (tile4_geo<HL + HR>(DC > 0 ? DC : 4, K, NE, SUB).XP + 63) / 64 : T4_NI_MAX;
@@ -113,8 +116,12 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : (K <= 7 ? 3 : 2)) void k_eval4(c
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+#if defined(VA_E4_ABLATE) && VA_E4_ABLATE == 7
+                rg[s].yv[k] = 1.0 + k + voff * 1e-9;         // measurement build: no observation loads (wrong sums, same work)
+#else
                 const v2u v = __builtin_amdgcn_raw_buffer_load_b64(yr, voff, (s * RK + k) * dm.L * 8, 0);
                 rg[s].yv[k] = __hiloint2double((int)v.y, (int)v.x);
+#endif
             }
         }
     } else if (active) {
@@ -130,6 +137,25 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : (K <= 7 ? 3 : 2)) void k_eval4(c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the wave's images have landed
     __builtin_amdgcn_wave_barrier();
     STAMP(2);
+#if defined(VA_E4_ABLATE) && (VA_E4_ABLATE == 2 || VA_E4_ABLATE == 3)
+    {   // measurement builds: staging alone (2), staging + the gradient stores of a copy (3)
+#if VA_E4_ABLATE == 3
+        const __amdgpu_buffer_rsrc_t gr0 = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(dv.gt + (size_t)b * dm.ld), 0, (int)(sizeof(double) * dm.N * D), 0x00020000);
+        const bool writer0 = active && (tx & 1) == 0;
+        const int voff0 = ((n0w + a * K) * D + tx) * 8;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            double x0, x1;
+            ld2(xsw + a * g.PITCH + (tx & ~1) + (k + HL < K ? (k + HL) * D : g.PITCH + (k + HL - K) * D), x0, x1);
+            const v4u v = {(unsigned)__double2loint(x0), (unsigned)__double2hiint(x0), (unsigned)__double2loint(x1), (unsigned)__double2hiint(x1)};
+            if (writer0) { if (dv.gaux) __builtin_amdgcn_raw_buffer_store_b128(v, gr0, voff0, k * D * 8, 16); else __builtin_amdgcn_raw_buffer_store_b128(v, gr0, voff0, k * D * 8, 0); }
+        }
+#endif
+        return;
+    }
+#endif
     // Workgroups that share a CU start together and their data arrives in dispatch order; the later
     // ones then compete for the vector pipe with workgroups already in their gather / reduction
     // phases and finish up to 1.7 us after the first.  The kernel is as long as its last workgroup:
@@ -217,6 +243,12 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : (K <= 7 ? 3 : 2)) void k_eval4(c
         if (!lsq && s == SUB - 1) publish();
 #pragma unroll
         for (int k = 0; k < K; ++k) gvv[s][k] = 0.0;
+#if defined(VA_E4_ABLATE) && VA_E4_ABLATE == 4
+        // measurement build: no gather phase -- the direct term goes out as the gradient
+#pragma unroll
+        for (int k = 0; k < K; ++k) gvv[s][k] = rg[s].direct[k];
+        if (false)
+#endif
         if (active) {
             if (edge) {
                 if (lsq) tile4_grad<RHS, DISC, K, true, DC, W_SCALAR, true>(dm, g, t, rg[s], acc, gvv[s]);
@@ -232,30 +264,43 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : (K <= 7 ? 3 : 2)) void k_eval4(c
     // a line-search evaluation also needs g.d, g.g and max|g|: its row waits for the gradient
     if (lsq) publish();
     {
-        // gradient stores, 16 bytes per lane: the even lane of a column pair takes its neighbour's value
-        // (DPP inside the quad) and writes both.  Write-through (sc1): the lines leave L2 as they are
-        // written instead of being flushed, all 10 MB of them, at the end of the kernel.
+        // Gradient stores.  The wave's RW*K rows are ONE contiguous run of the path in memory: the values go
+        // through the wave's (now dead) product arrays in row-major order and leave as consecutive 16-byte pieces,
+        // every lane storing -- full 64-byte sectors instead of ten lanes x 16 B per row and instruction
+        // (profiles/r03_ablation_c3.txt: the stores were 2.65 us of the 8.7).  Write-through (sc1) on small grids:
+        // the lines leave L2 as they are written instead of being flushed, all 10 MB of them, at the end of the kernel.
         const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(dv.gt + (size_t)b * dm.ld), 0, (int)(sizeof(double) * dm.N * D), 0x00020000);
-        const bool writer = active && (tx & 1) == 0;
+        const int npieces = RK * D / 2;                       // 16-byte pieces of one sub-tile's rows
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
-            const int voff = ((n0w + s * RK + a * K) * D + tx) * 8;
+            wave_sync_lds();                                  // (the gather phase has read the products)
+            if (active) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
+                for (int k = 0; k < K; ++k) r2w[(a * K + k) * D + tx] = gvv[s][k];
+            }
+            wave_sync_lds();
+            const int base = (n0w + s * RK) * D * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                     // (RW * D <= 64 columns, K <= 8 rows: at most 256 pieces)
+                if (i * 64 >= npieces) break;
                 typedef unsigned v4u __attribute__((ext_vector_type(4)));
-                const int glo = __double2loint(gvv[s][k]), ghi = __double2hiint(gvv[s][k]);
-                const int nlo = __builtin_amdgcn_update_dpp(0, glo, 0xF5, 0xF, 0xF, false);      // quad_perm [1,1,3,3]
-                const int nhi = __builtin_amdgcn_update_dpp(0, ghi, 0xF5, 0xF, 0xF, false);
-                const v4u v = {(unsigned)glo, (unsigned)ghi, (unsigned)nlo, (unsigned)nhi};
+                const int q = i * 64 + lane;
+                double g0, g1;
+                ld2(r2w + 2 * (q < npieces ? q : 0), g0, g1);
+                const v4u v = {(unsigned)__double2loint(g0), (unsigned)__double2hiint(g0), (unsigned)__double2loint(g1), (unsigned)__double2hiint(g1)};
                 // rows >= N fall outside the buffer (N*D*8 bytes): the hardware drops those stores
-                if (writer) {
-                    if (dv.gaux) __builtin_amdgcn_raw_buffer_store_b128(v, gr, voff, k * D * 8, 16);
-                    else __builtin_amdgcn_raw_buffer_store_b128(v, gr, voff, k * D * 8, 0);
-                }
+                const int voff = q < npieces ? q * 16 : 0x7ffffff0;
+                if (dv.gaux) __builtin_amdgcn_raw_buffer_store_b128(v, gr, voff, base, 16);
+                else __builtin_amdgcn_raw_buffer_store_b128(v, gr, voff, base, 0);
             }
         }
     }
+#if defined(VA_E4_ABLATE) && (VA_E4_ABLATE == 4 || VA_E4_ABLATE == 5)
+    // measurement builds: no last-arriver tail (its arrival count is reset here instead)
+    if (wave == 0 && lane == 0 && dv.epi != EPI_NONE) __hip_atomic_store(dv.cnt_eval + (size_t)b * CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+#endif
     // The last workgroup of the seed runs the tail (and resets the counter for the next launch).
     // (Measured at C3: running it before wave 0's own gradient stores, so that its loads do not retire
     // behind seven write-through stores, is slower -- 10.2 vs 9.6 us: those stores then end the kernel.)
