@@ -191,6 +191,33 @@ def extra_c4(device, steps=60):
             "achieved_GBs": balg / ks / 1e9, "frac": balg / ks / 1e9 / HBM_PEAK_GBS}
 
 
+def extra_variant(device, steps=1000, **kw):
+    """One (f)3 variant of the C3 shape (reference: va_ode.py:147-148, 203-209, 404-437, 555-558):
+    complete evaluations of 64 seeds, HIP events.  kw: disc=, N=, rf_vec= (RF0 of shape (D,) resized over time),
+    rm_vec= (RM of shape (N_data, L)), nskip= (dt_model = dt_data / nskip)."""
+    from varanneal_amd import _capi, twin
+    D, B = 20, 64
+    disc, N, nskip = kw.get("disc", "trapezoid"), kw.get("N", 1000), kw.get("nskip", 1)
+    Y, Lidx, XP, P = make_inputs(D, N, B, 0)
+    RM, RF0 = 4.0, 4e-6
+    if kw.get("rf_vec"):
+        RF0 = np.resize(4e-6 * (1.0 + 0.1 * np.arange(D)), (N - 1, D))
+    if nskip > 1:
+        Y = Y[::nskip]
+    if kw.get("rm_vec"):
+        RM = np.resize(4.0 * (1.0 + 0.1 * np.arange(len(Lidx))), Y.shape)
+    with _capi.Problem(B, D, N, Y, Lidx, twin.DT, RM, RF0, P, [0], disc=disc, merr_nskip=nskip, device=device, tile_rows=kw.get("tile_rows", 0)) as pb:
+        info = pb.info()
+        pb.action_grad(XP, RF_SCALE)
+        pb.eval_timed(RF_SCALE, max(steps // 10, 2))
+        ks = pb.eval_timed(RF_SCALE, steps) * 1e-3 / steps
+    balg = bytes_alg(B, N, D, 1, Y.shape[0], len(Lidx)) + (8 * (N - 1) * D if kw.get("rf_vec") else 0) + (8 * Y.size if kw.get("rm_vec") else 0)
+    return {"workload": "lorenz96_D%d_N%d_B%d_%s%s%s%s" % (D, N, B, disc, "_rfvec" if kw.get("rf_vec") else "", "_rmvec" if kw.get("rm_vec") else "",
+                                                          "_nskip%d" % nskip if nskip > 1 else ""),
+            "eval_kernel": info["eval_kernel"], "run_rows": info["run_rows"], "us_per_eval_launch": ks * 1e6, "evals_per_s": B / ks,
+            "bytes_alg_per_launch": balg, "frac": balg / ks / 1e9 / HBM_PEAK_GBS}
+
+
 def extra_nnet(device, key, steps):
     """The network action (BASELINE config 5, va_nnet) as a sub-record: `c5` = the reference's twin example
     (20 layers x 10 neurons, M = 2: one small kernel per evaluation), `c5x` = layers that fill the matrix cores
@@ -234,6 +261,7 @@ def extra_ladder(device, D, N, B, Y, Lidx, XP, P, nbeta=30):
         cyc = pb.counters()["cycles"] - c0["cycles"]
         it = 200
         ms_u, ms_d = pb.lbfgs_timed(it)
+        ms_e = pb.eval_ls_timed(RF_SCALE, 1000)
     nfev = int(r["nfev"].sum())
     # per element and launch: k_update reads d, g, gt, x + 2(m-1) old history vectors and writes g, S_new,
     # Y_new (x only on acceptance: counted); k_direction reads g + 2m history vectors and writes d
@@ -243,6 +271,7 @@ def extra_ladder(device, D, N, B, Y, Lidx, XP, P, nbeta=30):
     return {"workload": "lorenz96_D%d_N%d_B%d_trapezoid_ladder%d" % (D, N, B, nbeta),
             "seconds": dt, "seed_evals": nfev, "seed_evals_per_s": nfev / dt, "cycles": cyc,
             "us_per_cycle": dt * 1e6 / max(1, cyc), "launches_per_cycle": 3,
+            "eval_us_in_cycle": ms_e,          # (1000 launches: ms total = us each) a line-search evaluation: x + stp*d, g.d, the line-search step
             "A_final_median": float(np.median(r["A"][:, -1])), "k_final_median": float(np.median(r["pest"][:, -1, 0])),
             "k_update": {"us": us_u, "bytes": b_upd, "GBs": b_upd / us_u / 1e3, "frac_of_8TBs": b_upd / us_u / 1e3 / HBM_PEAK_GBS},
             "k_direction": {"us": us_d, "bytes": b_dir, "GBs": b_dir / us_d / 1e3, "frac_of_8TBs": b_dir / us_d / 1e3 / HBM_PEAK_GBS},
@@ -549,6 +578,7 @@ def main():
             pb.close()
             out["extra"] = {"ladder": extra_ladder(local_rank, D, N, B, Y, Lidx, XP, P),
                             "c4": extra_c4(local_rank),
+                            "c3_sh": extra_variant(local_rank, disc="SimpsonHermite", N=1001),      # (what Lorenz96_anneal.py:85 runs)
                             "c5": extra_nnet(local_rank, "c5", 2000), "c5x": extra_nnet(local_rank, "c5x", 40)}
         print(json.dumps(out), flush=True)
     pb.close()

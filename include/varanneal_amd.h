@@ -199,6 +199,10 @@ int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms
  * elapsed ms of each.  Overwrites the resident paths and the L-BFGS state: evaluate / anneal again
  * from host data afterwards. */
 int va_lbfgs_timed(va_handle h, int32_t iters, float *ms_update, float *ms_direction);
+/* Measurement only: `iters` evaluation launches as a ladder cycle makes them (every seed at a line-search trial
+ * point x + stp*d, the tail runs one line-search step), each after re-arming the seeds; *ms_eval = the launches'
+ * time with the re-arming kernel's own time (measured in a second pass) subtracted.  Leaves the seeds idle. */
+int va_eval_ls_timed(va_handle h, double rf_scale, int32_t iters, float *ms_eval);
 
 /* The outputs the last S1 evaluation (va_action_grad or va_eval_timed) left on the device:
  * A/me/fe [B], grad [B*ldg] (any may be NULL), HOST arrays. */

@@ -205,6 +205,7 @@ def lib():
     L.va_comm_destroy.restype = None
     L.va_gather_results.argtypes = [h, h, C.c_int32, c_dp, c_ip]
     L.va_lbfgs_timed.argtypes = [h, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.va_eval_ls_timed.argtypes = [h, C.c_double, C.c_int32, C.POINTER(C.c_float)]
     L.va_read_eval_outputs.argtypes = [h, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.va_debug_read_partials.argtypes = [h, c_dp, C.c_int64]
     L.va_problem_eval_kernel.argtypes = [h, c_ip, c_ip]
@@ -212,7 +213,7 @@ def lib():
     for fn in ("va_device_count", "va_rhs_load_module", "va_act_load_module", "va_eval_plan", "va_eval_plan_reach", "va_problem_eval_kernel", "va_problem_tune", "va_problem_tune", "va_problem_create", "va_nnet_problem_create",
                "va_problem_info", "va_action_grad",
                "va_minimize_lbfgs", "va_anneal", "va_get_minpath", "va_eval_timed",
-               "va_get_counters", "va_debug_read_partials", "va_read_eval_outputs", "va_lbfgs_timed",
+               "va_get_counters", "va_debug_read_partials", "va_read_eval_outputs", "va_lbfgs_timed", "va_eval_ls_timed",
                "va_comm_unique_id", "va_comm_create", "va_gather_results"):
         getattr(L, fn).restype = C.c_int
     _lib = L
@@ -222,7 +223,7 @@ def lib():
 EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_act_load_module", "va_eval_plan", "va_eval_plan_reach", "va_problem_eval_kernel", "va_problem_tune", "va_problem_create",
            "va_problem_destroy", "va_problem_info", "va_action_grad", "va_minimize_lbfgs",
            "va_anneal", "va_get_minpath", "va_eval_timed", "va_get_counters", "va_nnet_problem_create", "va_debug_read_partials",
-           "va_read_eval_outputs", "va_lbfgs_timed", "va_comm_unique_id", "va_comm_create", "va_comm_destroy",
+           "va_read_eval_outputs", "va_lbfgs_timed", "va_eval_ls_timed", "va_comm_unique_id", "va_comm_create", "va_comm_destroy",
            "va_gather_results"]
 
 
@@ -428,6 +429,13 @@ class Problem(object):
         a, b = C.c_float(), C.c_float()
         check(self._L.va_lbfgs_timed(self._h, int(iters), C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def eval_ls_timed(self, rf_scale, iters):
+        """ms of `iters` evaluation launches as a ladder cycle makes them (line-search trial points, line-search step
+        in the tail); destroys the resident line-search state."""
+        a = C.c_float()
+        check(self._L.va_eval_ls_timed(self._h, float(rf_scale), int(iters), C.byref(a)))
+        return a.value
 
     def read_eval_outputs(self, want_grad=True):
         """(A, me, fe, grad) as the last S1 evaluation (action_grad / eval_timed) left them on the device."""

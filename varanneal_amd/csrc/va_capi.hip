@@ -233,14 +233,16 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
             K = K < 4 ? 4 : (K > 8 ? 8 : K);
             if (sh && (K & 1)) ++K;
         }
-        // A grid of only a few wave-tiles per SIMD (1024 SIMDs) runs as ONE wave per SIMD working
-        // through SUB sub-tiles in turn (k_eval4): C3 = 3072 wave-tiles -> SUB = 3, 256 workgroups.
-        int SUB = 1;
-        const bool ws = d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1;
-        if (false && D == 20 && ws && (K == 6 || K == 7) && d->tile_rows <= 0) {      // (slower than co-resident waves: see eval4_rhs)
-            const long wtiles = (long)d->batch * ((N + RW * K - 1) / (RW * K));
-            if (wtiles > 1024 && wtiles <= 3 * 1024) SUB = (int)((wtiles + 1023) / 1024);
+        // weight arrays / data every nskip-th row: runs of 6 and 7 rows do not fit three waves per SIMD's 168 registers
+        // with their weight registers (18-59 spilled; measured at the C3 shape, profiles/r03_f3_variants.txt: 21 us
+        // against 13 us for K = 5): those problems run K <= 5, or 8 at two waves per SIMD
+        {
+            const bool ws4 = d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1;
+            if (!ws4 && (K == 6 || K == 7)) K = sh ? 4 : 5;
         }
+        // (one wave per SIMD walking SUB sub-tiles in turn was measured slower than co-resident waves -- DESIGN.md section 7;
+        // only SUB = 1 is instantiated, and the host never asks for anything else)
+        const int SUB = 1;
         g4 = sh ? tile4_geo<3>(D, K, ne, SUB) : tile4_geo<2>(D, K, ne, SUB);
         if ((g4.XP + 63) / 64 <= T4_NI_MAX && tile4_magic_ok(g4)) {
             dm.RY = 4 * RW; dm.NT = 256; dm.maxr = K; dm.T = g4.T;
@@ -276,6 +278,7 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
         }
         if (D > 64 && d->tile_rows <= 0 && (long)d->batch * ((N + dm.RY * 8 - 1) / (dm.RY * 8)) >= 256)
             K = 8;                                         // few lanes per column: long runs keep the halo share down
+        if (dm.NT == 1024 && K > 6) K = 6;                 // (1024-thread groups live on 128 registers: runs of 8 rows spill 20-88 of them)
         for (;;) {                                        // shrink until the staging arrays fit in LDS
             const size_t elems = (size_t)tile3_stage_elems(K, D, dm.ghost, dm.RY, HLR) + tile3_s_elems(K, D, dm.ghost, dm.RY);
             if (sizeof(double) * elems <= (D <= 64 ? 60 : (D <= 512 ? 78 : 150)) * 1024 || K <= 4) break;   // two groups per CU (one beyond D = 512)
@@ -1269,6 +1272,32 @@ int va_lbfgs_timed(va_handle h, int32_t iters, float *ms_update, float *ms_direc
     HIPCHK(hipEventSynchronize(h->ev1));
     HIPCHK(hipEventElapsedTime(ms_direction, h->ev0, h->ev1));
     dv.sticky = 0;
+    launch_init_states(dv, PH_IDLE, 1.0, h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    return VA_OK;
+}
+
+int va_eval_ls_timed(va_handle h, double rf_scale, int32_t iters, float *ms_eval)
+{
+    if (!h || !ms_eval || iters < 1) return fail(VA_EINVAL, "bad argument");
+    if (h->is_nnet) return fail(VA_EUNSUPPORTED, "ODE problems only");
+    HIPCHK(hipSetDevice(h->device));
+    Dev &dv = h->dv;
+    float both = 0.f, arm = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        launch_arm_ls(dv, rf_scale, h->stream);
+        if (pass == 0) run_eval(h, EPI_LS);                                  // warm-up
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        for (int i = 0; i < iters; ++i) {
+            launch_arm_ls(dv, rf_scale, h->stream);
+            if (pass == 0) run_eval(h, EPI_LS);
+        }
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        HIPCHK(hipEventSynchronize(h->ev1));
+        HIPCHK(hipEventElapsedTime(pass == 0 ? &both : &arm, h->ev0, h->ev1));
+    }
+    *ms_eval = both - arm;
     launch_init_states(dv, PH_IDLE, 1.0, h->stream);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());

@@ -66,6 +66,7 @@ void launch_update(const Dev &dv, hipStream_t s);
 void launch_direction(const Dev &dv, hipStream_t s);
 void launch_init_states(const Dev &dv, int phase, double rf_scale_or_neg, hipStream_t s);
 void launch_arm_full_history(const Dev &dv, hipStream_t s);
+void launch_arm_ls(const Dev &dv, double rf, hipStream_t s);
 void launch_clamp_x(const Dev &dv, hipStream_t s);
 void launch_finalize_eval(const Dev &dv, hipStream_t s);
 size_t eval_lds_bytes(const Dev &dv);

@@ -236,6 +236,26 @@ __global__ void k_arm_full_history(const Dev dv)
     for (int j = 0; j < m; ++j) s.order[j] = (j + 1) % m;
     s.upd = UPD_G | UPD_HIST; s.dir = 1; s.stp_upd = 1.0; s.dr = 1.0; s.theta = 1.0; s.store_idx = -1;
 }
+// measurement only (va_eval_ls_timed): every seed at a line-search trial point whose outcome is "another trial"
+// (the sufficient-decrease test cannot pass against finit = -1e300), so that an evaluation launch does what it does
+// inside a ladder cycle -- x + stp*d formed from the two staged images, g.d / g.g / max|g|, one More'-Thuente step in
+// the tail -- and can be repeated after re-arming
+__global__ void k_arm_ls(const Dev dv, double rf)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= dv.dm.B) return;
+    SeedState &s = dv.st[b];
+    s.phase = PH_LS; s.ifun = 1; s.iback = 0; s.stp = 1e-3; s.ls_task = LS_FG; s.rf_scale = rf;
+    s.iter = 1; s.nfev = 2; s.f = 1.0; s.fold = 1.0; s.gd = -1.0; s.gdold = -1.0; s.stpmx = 1e10;
+    LsState &l = s.ls;
+    l.brackt = 0; l.stage = 1; l.ginit = -1.0; l.gtest = -1e-3; l.gx = -1.0; l.gy = -1.0;
+    l.finit = -1e300; l.fx = -1e300; l.fy = -1e300; l.stx = 0.0; l.sty = 0.0; l.stmin = 0.0; l.stmax = 5e-3;
+    l.width = 1e10; l.width1 = 2e10;
+}
+void launch_arm_ls(const Dev &dv, double rf, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_arm_ls, dim3((dv.dm.B + 63) / 64), dim3(64), 0, s, dv, rf);
+}
 void launch_arm_full_history(const Dev &dv, hipStream_t s)
 {
     hipLaunchKernelGGL(k_arm_full_history, dim3((dv.dm.B + 63) / 64), dim3(64), 0, s, dv);

@@ -36,11 +36,14 @@ def seed_range(n_seeds, rank, world):
     return lo, hi
 
 
-def gather_tables(local, n_seeds, group=None):
+def gather_tables(local, n_seeds, group=None, device=None):
     """All-gather per-seed result tables with ONE collective.
 
     `local` maps name -> float/int array whose leading axis is this rank's seeds (in
     seed order).  Returns the same names with leading axis `n_seeds` on every rank.
+    `device`: the GPU ordinal this rank's problem ran on (RCCL backend): the collective's buffers are
+    allocated THERE, whatever torch's current device is -- two ranks staging on cuda:0 would make RCCL
+    fail with a duplicate-GPU error or hang.
     """
     import torch
     import torch.distributed as dist
@@ -66,7 +69,7 @@ def gather_tables(local, n_seeds, group=None):
     use_cuda = dist.get_backend(group) == "nccl"
     send = torch.from_numpy(buf)
     if use_cuda:
-        send = send.cuda()
+        send = send.to(torch.device("cuda", torch.cuda.current_device() if device is None else int(device)))
     recv = torch.empty((world * maxloc, row), dtype=send.dtype, device=send.device)
     dist.all_gather_into_tensor(recv, send, group=group)        # the single RCCL gather
     recv = recv.cpu().numpy().reshape(world, maxloc, row)

@@ -139,7 +139,7 @@ class Annealer(HIPmin):
                     local = {"A": np.zeros((0, nb)), "me": np.zeros((0, nb)), "fe": np.zeros((0, nb)),
                              "params": np.zeros((0, nb, npw)), "exitflags": np.zeros((0, nb), np.int8),
                              "nit": np.zeros((0, nb), np.int32), "nfev": np.zeros((0, nb), np.int64)}
-                self.gathered = parallel.gather_tables(local, n_seeds)
+                self.gathered = parallel.gather_tables(local, n_seeds, device=device)
             else:
                 self.gathered = local
             return
