@@ -540,3 +540,6 @@ int vao_action_grad_batch(const vao_problem *const *pb, int nseeds, const double
     }
     return rc;
 }
+
+/* L-BFGS-B with bounds (generalised Cauchy point + subspace minimisation): its own file, same translation unit */
+#include "va_lbfgsb.inc.c"

@@ -74,6 +74,11 @@ int vao_lbfgs_generic(int32_t n, double *x, vao_fg_t fg, void *ctx,
 int vao_lbfgs_bounded(int32_t n, double *x, vao_fg_t fg, void *ctx, const double *lo, const double *hi,
                       const vao_lbfgs_opts *o, double *Amin, int32_t *status,
                       int32_t *nit_out, int64_t *nfev_out);
+/* L-BFGS-B ITSELF for a problem with bounds: generalised Cauchy point + subspace minimisation, the published
+ * algorithm restated routine for routine (va_lbfgsb.inc.c) -- what scipy.optimize.minimize(method='L-BFGS-B',
+ * bounds=...) runs at the reference's call site _autodiffmin.py:85-86; pinned against it step for step. */
+int vao_lbfgsb(int32_t n, double *x, vao_fg_t fg, void *ctx, const double *lo, const double *hi,
+               const vao_lbfgs_opts *o, double *Amin, int32_t *status, int32_t *nit_out, int64_t *nfev_out);
 int vao_minimize_lbfgs(const vao_problem *pb, double *XP_inout, double rf_scale,
                        const vao_lbfgs_opts *o, double *Amin, int32_t *status,
                        int32_t *nit, int64_t *nfev);

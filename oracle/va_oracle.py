@@ -40,8 +40,8 @@ class _Opts(C.Structure):
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "va_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("va_oracle.c", "va_lbfgsb.inc.c", "va_oracle.h")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libva_oracle.so"])
     return _LIB
 
@@ -74,10 +74,12 @@ def lib():
 _FG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
-def lbfgs_generic(fg, x0, opt_args=None, bounds=None):
+def lbfgs_generic(fg, x0, opt_args=None, bounds=None, exact=False):
     """The oracle's L-BFGS (restated L-BFGS-B 3.0 unconstrained path + dcsrch, va_oracle.c) on any
     objective `fg(x) -> (f, grad)`: the arbiter for actions other than the ODE one.  `bounds`: list of
-    (lo, hi) per variable (None = none), handled as the device handles them (vao_lbfgs_bounded).
+    (lo, hi) per variable (None = none): exact=True runs L-BFGS-B itself (generalised Cauchy point + subspace
+    minimisation, vao_lbfgsb: SciPy's iterates), exact=False the active-set form the device's batched
+    minimiser used before it had the Cauchy point (vao_lbfgs_bounded).
     Returns (x, f, status, nit, nfev)."""
     x = np.array(x0, dtype=np.float64)
     n = x.size
@@ -100,6 +102,15 @@ def lbfgs_generic(fg, x0, opt_args=None, bounds=None):
         return 0
     o = Problem._opts(opt_args)
     A, st, nit, nfev = C.c_double(), C.c_int32(), C.c_int32(), C.c_int64()
+    if exact:
+        if lo is None:
+            lo, hi = np.full(n, -np.inf), np.full(n, np.inf)
+        L.vao_lbfgsb.argtypes = L.vao_lbfgs_bounded.argtypes
+        L.vao_lbfgsb.restype = C.c_int
+        rc = L.vao_lbfgsb(n, _dp(x), _FG(cb), None, _dp(lo), _dp(hi), C.byref(o), C.byref(A), C.byref(st), C.byref(nit), C.byref(nfev))
+        if rc:
+            raise ValueError("vao_lbfgsb rc=%d" % rc)
+        return x, A.value, st.value, nit.value, nfev.value
     rc = L.vao_lbfgs_bounded(n, _dp(x), _FG(cb), None, _dp(lo) if lo is not None else None,
                              _dp(hi) if hi is not None else None, C.byref(o), C.byref(A), C.byref(st), C.byref(nit),
                              C.byref(nfev))
@@ -196,10 +207,10 @@ class Problem(object):
                      float(o.get("gtol", 1e-5)), int(min(o.get("maxiter", 15000), 2**31 - 1)),
                      int(o.get("maxfun", 15000)), int(o.get("maxls", 20)))
 
-    def minimize_lbfgs(self, XP0, rf_scale, opt_args=None, bounds=None):
-        if bounds is not None:       # the device's active-set form (vao_lbfgs_bounded)
+    def minimize_lbfgs(self, XP0, rf_scale, opt_args=None, bounds=None, exact=False):
+        if bounds is not None:       # exact: L-BFGS-B itself (vao_lbfgsb); else the active-set form (vao_lbfgs_bounded)
             fg = lambda z: (lambda r: (r[0], r[3]))(self.action_grad(z, rf_scale))
-            return lbfgs_generic(fg, XP0, opt_args, bounds)
+            return lbfgs_generic(fg, XP0, opt_args, bounds, exact=exact)
         x = np.array(XP0, dtype=np.float64)
         o = self._opts(opt_args)
         A, st, nit, nfev = C.c_double(), C.c_int32(), C.c_int32(), C.c_int64()
