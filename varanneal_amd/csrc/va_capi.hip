@@ -354,6 +354,11 @@ int alloc_solver_state(va_handle h, int max_beta, int keep_paths)
     TRYA(h->alloc(&dv.status, B * max_beta)); TRYA(h->alloc(&dv.nit, B * max_beta));
     TRYA(h->alloc(&dv.nfev, B * max_beta));
     if (keep_paths) TRYA(h->alloc(&dv.minpaths, B * max_beta * (size_t)(dm.ND + dm.NP), false));
+    if (dm.bounded) {
+        TRYA(h->alloc(&dv.lb_z, B * ld)); TRYA(h->alloc(&dv.lb_r, B * ld)); TRYA(h->alloc(&dv.lb_xp, B * ld));
+        TRYA(h->alloc(&dv.lb_t, B * ld)); TRYA(h->alloc(&dv.lb_iwhere, B * ld));
+        TRYA(h->alloc(&dv.lb_mat, B * 3 * m * m)); TRYA(h->alloc(&dv.lb_dtd, B));
+    }
     TRYA(h->alloc(&dv.cnt_eval, B * CNT_STRIDE)); TRYA(h->alloc(&dv.cnt_upd, B * CNT_STRIDE)); TRYA(h->alloc(&dv.cnt_dir, B * CNT_STRIDE));
     TRYA(h->alloc(&dv.n_active, 1));
     TRYA(h->alloc(&dv.n_evals, 1));
@@ -446,7 +451,8 @@ int run_ladder(va_handle h, const double *rf_scale, int nbeta)
         for (int k = 0; k < n; ++k) {
             run_eval(h, EPI_LS);
             launch_update(dv, h->stream);
-            launch_direction(dv, h->stream);
+            if (dv.dm.bounded) launch_lbfgsb_dir(dv, h->stream);      // L-BFGS-B: Cauchy point + subspace minimisation
+            else launch_direction(dv, h->stream);
         }
     };
     struct GraphGuard { hipGraphExec_t &g; ~GraphGuard() { if (g) (void)hipGraphExecDestroy(g); } } guard{gexec};
@@ -717,7 +723,8 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
                         T, D, need, cap);
         }
         // more than 64 KiB of dynamic LDS is an opt-in per kernel AND per device: once per handle
-        const hipError_t e = h->user_prepare ? (hipError_t)h->user_prepare(&dv) : prepare_eval(dv, h->rhs);
+        hipError_t e = h->user_prepare ? (hipError_t)h->user_prepare(&dv) : prepare_eval(dv, h->rhs);
+        if (e == hipSuccess && dm.bounded) e = prepare_lbfgsb(dv);
         if (e != hipSuccess) {
             va_problem_destroy(h);
             return fail(VA_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(e));
@@ -752,6 +759,9 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
             if (!(d->lower[i] <= d->upper[i])) { va_problem_destroy(h); return fail(VA_EINVAL, "lower[%d] > upper[%d] (or NaN)", i, i); }
             lo_h[i] = d->lower[i]; hi_h[i] = d->upper[i];
         }
+        bool boxed = true;
+        for (int i = 0; i < nv; ++i) boxed = boxed && lo_h[i] > -HUGE_VAL && hi_h[i] < HUGE_VAL;
+        if (boxed) { dm.bounded |= 2; dv.dm.bounded |= 2; }
         TRY(h->alloc(&lo_d, (size_t)dm.ld)); TRY(h->alloc(&hi_d, (size_t)dm.ld));
     }
     if (d->t_model) TRY(h->alloc(&t_d, (size_t)dm.N));

@@ -63,7 +63,7 @@ struct Dims {
     // L-BFGS kernels (one flat run), and the flat tile kernel uses NPt / NPe.  Static: tdp = 0,
     // NPt = NP, NPe = NPest.
     int tdp, NPt, NPe;
-    int bounded;               // box bounds on the path vector (ProblemPtrs::lo / hi)
+    int bounded;               // bit 0: box bounds on the path vector (ProblemPtrs::lo / hi); bit 1: every variable has both bounds (L-BFGS-B's `boxed`)
     double dt, cme, cfe, rm, rf0;
 };
 
@@ -99,7 +99,7 @@ struct Opts {
 // can stage it in LDS with a single coalesced 8-byte load per lane (k_ls).
 struct SeedHot {
     int phase, beta_idx, iter, col, head, ifun, iback, ls_task;
-    int upd, slot, dir, store_idx, nold, pad0;
+    int upd, slot, dir, store_idx, nold, pad0;      // pad0: bounded problems -- bit 0 a pair waits to enter S'Y / S'S (k_lbfgsb_dir), bit 1 the oldest pair was evicted
     int order[MAX_M];       // history slots, oldest -> newest (after the pending update)
     long long nfev;
     double f, fold, me, fe, theta, stp, gd, gdold, rf_scale, gn2, dr;
@@ -608,7 +608,7 @@ VA_HD_FLAT void begin_linesearch(SeedHot &s)
     s.dir = 1;
 }
 
-VA_HD_FLAT void reset_memory(SeedHot &s) { s.col = 0; s.head = 0; s.theta = 1.0; s.nold = 0; }
+VA_HD_FLAT void reset_memory(SeedHot &s) { s.col = 0; s.head = 0; s.theta = 1.0; s.nold = 0; s.pad0 = 0; }
 
 // K2: consume one evaluation.  ev[] = eval partial sums INCLUDING the parameter tail
 // contributions; dirp[] = (g.d, d.d) of the direction in use.
@@ -667,7 +667,7 @@ VA_HD_FLAT void ls_step(SeedHot &s, const double *ev, const double *dirp, const 
     if (s.iter >= o.maxiter) { finish_step(s, 1, true, rf_ladder, nbeta, r, n_active_dec); return; }
     if (s.nfev > o.maxfun) { finish_step(s, 1, true, rf_ladder, nbeta, r, n_active_dec); return; }
     if (ev[EP_GMAX] <= o.gtol) { finish_step(s, 0, true, rf_ladder, nbeta, r, n_active_dec); return; }
-    if (!(bounded && stp_eval >= stpmax)) {      // (a step that ended on a bound was cut short: no verdict on progress)
+    {
         const double dd = fmax(fmax(fabs(fold), fabs(ft)), 1.0);
         if (fold - ft <= o.ftol * dd) { finish_step(s, 0, true, rf_ladder, nbeta, r, n_active_dec); return; }
     }
@@ -677,15 +677,19 @@ VA_HD_FLAT void ls_step(SeedHot &s, const double *ev, const double *dirp, const 
     s.nold = s.col;
     if (dr > epsmch * ddum) {
         int slot;
+        bool evicted = false;
         if (s.col < o.m) { slot = (s.head + s.col) % o.m; s.nold = s.col; s.col += 1; }
         else {
             // the oldest pair is evicted: order[] shifts left
+            evicted = true;
             slot = s.head; s.head = (s.head + 1) % o.m;
             for (int j = 0; j + 1 < s.col; ++j) s.order[j] = s.order[j + 1];
             s.nold = s.col - 1;
         }
         s.order[s.col - 1] = slot;
         s.slot = slot; s.dr = dr; s.upd |= UPD_HIST;
+        // (bounded problems, k_lbfgsb_dir: a pair to enter S'Y / S'S; bit 1: the oldest pair was evicted)
+        s.pad0 = 1 | (evicted ? 2 : 0);
     }
     begin_linesearch(s);
 }

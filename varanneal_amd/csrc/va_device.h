@@ -57,6 +57,10 @@ struct Dev {
     unsigned long long *n_evals;   // seed-evaluations consumed by k_ls since create
     // S1 outputs
     double *outA, *outme, *outfe;  // [B]
+    // bounded problems (va_lbfgsb.hip): Cauchy point / subspace minimiser z, reduced gradient r, the copy xp,
+    // breakpoints t, variable status iwhere ([B][ld] each); S'Y, S'S, T ([B][3 m m]); d'd of the direction in use ([B])
+    double *lb_z, *lb_r, *lb_xp, *lb_t, *lb_mat, *lb_dtd;
+    int *lb_iwhere;
 };
 
 // launch wrappers (va_kernels.hip); all asynchronous on `s`
@@ -73,6 +77,9 @@ size_t eval_lds_bytes(const Dev &dv);
 size_t update_lds_bytes(const Dims &dm);
 hipError_t prepare_eval(const Dev &dv, int rhs);   // once per handle: opt the kernel in to > 64 KiB of LDS on this device
 int eval_grid(const Dims &dm);
+// bounded problems: L-BFGS-B's direction step in k_direction's place (va_lbfgsb.hip)
+void launch_lbfgsb_dir(const Dev &dv, hipStream_t s);
+hipError_t prepare_lbfgsb(const Dev &dv);
 // streaming column strips (va_eval5.hip)
 void launch_eval5(const Dev &dv, hipStream_t s);
 hipError_t prepare_eval5(const Dev &dv);
