@@ -94,11 +94,11 @@ typedef struct va_problem_desc {
     void *stream;             /* hipStream_t to run on; NULL = library-owned stream  */
     const double *lower;      /* NULL, or [n_var] box bounds of the path vector [X | p_est] shared by all seeds     */
     const double *upper;      /* (va_ode.py:582-605 expands `bounds` to this order); -/+HUGE_VAL = no bound.        */
-                              /* With bounds va_minimize_lbfgs / va_anneal run the device minimiser's active-set    */
-                              /* form (csrc/va_core.h: components of the direction that would leave the box from a  */
-                              /* bound are dropped, the line search stops at the box, convergence is tested on the  */
-                              /* projected gradient) -- not L-BFGS-B's generalised Cauchy point; the reference's    */
-                              /* exact L-BFGS-B route remains SciPy around va_action_grad (one seed).               */
+                              /* With bounds va_minimize_lbfgs / va_anneal run L-BFGS-B itself on the device: the    */
+                              /* direction step is csrc/va_lbfgsb.hip (generalised Cauchy point + subspace            */
+                              /* minimisation, one workgroup per seed) in k_direction's place; same line search,     */
+                              /* stopping rules on the projected gradient.  Iterates follow SciPy's step for step    */
+                              /* (tests/test_gpu_codegen.py::test_bounded_device_minimiser_is_lbfgsb_step_for_step). */
 } va_problem_desc;
 
 /* SciPy option names (reference passes opt_args through, _autodiffmin.py:85-86) */

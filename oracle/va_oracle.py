@@ -74,12 +74,12 @@ def lib():
 _FG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
-def lbfgs_generic(fg, x0, opt_args=None, bounds=None, exact=False):
+def lbfgs_generic(fg, x0, opt_args=None, bounds=None, exact=True):
     """The oracle's L-BFGS (restated L-BFGS-B 3.0 unconstrained path + dcsrch, va_oracle.c) on any
     objective `fg(x) -> (f, grad)`: the arbiter for actions other than the ODE one.  `bounds`: list of
-    (lo, hi) per variable (None = none): exact=True runs L-BFGS-B itself (generalised Cauchy point + subspace
-    minimisation, vao_lbfgsb: SciPy's iterates), exact=False the active-set form the device's batched
-    minimiser used before it had the Cauchy point (vao_lbfgs_bounded).
+    (lo, hi) per variable (None = none): L-BFGS-B itself (generalised Cauchy point + subspace minimisation,
+    vao_lbfgsb: SciPy's iterates, what the device runs); exact=False: the active-set form of round 2
+    (vao_lbfgs_bounded), kept for comparison only.
     Returns (x, f, status, nit, nfev)."""
     x = np.array(x0, dtype=np.float64)
     n = x.size
@@ -207,7 +207,7 @@ class Problem(object):
                      float(o.get("gtol", 1e-5)), int(min(o.get("maxiter", 15000), 2**31 - 1)),
                      int(o.get("maxfun", 15000)), int(o.get("maxls", 20)))
 
-    def minimize_lbfgs(self, XP0, rf_scale, opt_args=None, bounds=None, exact=False):
+    def minimize_lbfgs(self, XP0, rf_scale, opt_args=None, bounds=None, exact=True):
         if bounds is not None:       # exact: L-BFGS-B itself (vao_lbfgsb); else the active-set form (vao_lbfgs_bounded)
             fg = lambda z: (lambda r: (r[0], r[3]))(self.action_grad(z, rf_scale))
             return lbfgs_generic(fg, XP0, opt_args, bounds, exact=exact)

@@ -137,8 +137,10 @@ def test_nakl_bounded_ladder_on_the_device_batched(gold):
     rel = np.abs(a.A_array[0] - c["A_array"]) / c["A_array"]
     print("bounded NaKL ladder on the device, seed 0 vs the reference's SciPy ladder: rel. deviation per rung",
           np.array2string(rel, precision=2), " iterations", a.nit_array[0], "reference", c["nit"])
-    assert list(a.nit_array[0][:3]) == list(c["nit"][:3])
-    assert np.all(rel <= 1e-3)
+    # measured: iterations [38 1 1 1 62 5 5 58] against the reference's [38 1 1 1 62 5 5 86]; deviations 1e-10 ... 9e-8 on
+    # the first seven rungs, 1.7e-4 on the last (ftol = 1e-8 is absolute at A ~ 1e-3: both stop on a flat floor)
+    assert list(a.nit_array[0][:7]) == list(c["nit"][:7])
+    assert np.all(rel[:7] <= 1e-6) and rel[7] <= 1e-3
     a.close()
 
 

@@ -66,32 +66,6 @@ def test_ladder_matches_reference_ladder(golden_ladders):
         assert np.allclose(r["A"], r["me"] + r["fe"], rtol=1e-12)
 
 
-def test_bounded_minimiser_against_scipy():
-    """The active-set form of the minimiser (what the device runs with `bounds`; vao_lbfgs_bounded) is
-    not L-BFGS-B's Cauchy-point machinery, so its iterates differ from SciPy's; it must stay inside the
-    box to the last bit, reproduce the unbounded run when no bound is ever touched, and reach an action
-    close to SciPy's L-BFGS-B from the same start."""
-    import scipy.optimize as opt
-    from varanneal_amd import twin
-    D, N = 20, 60
-    t, Y, _, Lidx = twin.make_twin(D, N)
-    X0, P0 = twin.initial_guess(N, D, 0, Y, Lidx)
-    XP = np.append(X0.ravel(), P0)
-    pb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P0, [0])
-    o = {'gtol': 1e-8, 'ftol': 1e-10, 'maxiter': 2000, 'maxfun': 100000}
-    free = pb.minimize_lbfgs(XP, 50.0, o)
-    wide = pb.minimize_lbfgs(XP, 50.0, o, bounds=[(-1e6, 1e6)] * (N * D) + [(None, None)])
-    assert free[1:] == wide[1:] and np.array_equal(free[0], wide[0])
-    fg = lambda x: (lambda r: (r[0], r[3]))(pb.action_grad(x, 50.0))
-    for bnds, tol in (([(-15, 15)] * (N * D) + [(6.5, 10.0)], 5e-2), ([(-4.0, 4.0)] * (N * D) + [(7.0, 7.5)], 1e-4),
-                      ([(-1.0, 6.0)] * (N * D) + [(None, 8.0)], 1e-4)):
-        x, A, st, nit, nfev = pb.minimize_lbfgs(XP, 50.0, o, bounds=bnds)
-        rs = opt.minimize(fg, XP, method='L-BFGS-B', jac=True, bounds=bnds, options=o)
-        lo = np.array([-np.inf if q[0] is None else q[0] for q in bnds]); hi = np.array([np.inf if q[1] is None else q[1] for q in bnds])
-        assert st == 0 and np.all(x >= lo) and np.all(x <= hi)
-        assert abs(A - rs.fun) <= tol * rs.fun, (A, rs.fun)
-
-
 # ---- L-BFGS-B itself (generalised Cauchy point + subspace minimisation): oracle/va_lbfgsb.inc.c ------------------
 def _rosen(x):
     f = np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2)
@@ -135,7 +109,7 @@ def test_lbfgsb_follows_scipy_step_for_step_on_bounded_problems():
 
 def test_lbfgsb_on_the_action_with_bounds():
     """the Lorenz-96 action with box bounds that bind (the boxes of test_bounded_minimiser_against_scipy): the
-    restated L-BFGS-B takes SciPy's iterations; the active-set form of round 2 does not, and is held to its minima"""
+    restated L-BFGS-B takes SciPy's iterations"""
     from varanneal_amd import twin
     D, N = 20, 60
     t, Y, _, Lidx = twin.make_twin(D, N)

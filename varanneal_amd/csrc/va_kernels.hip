@@ -541,21 +541,6 @@ __global__ __launch_bounds__(VEC_THREADS) void k_direction(const Dev dv)
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         if (idx[e] >= dm.ld) continue;
-        if (dm.bounded) {
-            // box bounds: a component that would leave the box from the bound it sits on is dropped;
-            // the others limit the step (va_core.h: ls_step stops the line search at stpmx)
-            const double2 xv = *reinterpret_cast<const double2 *>(dv.x + vo + idx[e]);
-            const double xs[2] = {xv.x, xv.y};
-            double ds[2] = {acc[e].x, acc[e].y};
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const double l = dv.pp.lo[idx[e] + u], h = dv.pp.hi[idx[e] + u];
-                if ((xs[u] <= l && ds[u] < 0.0) || (xs[u] >= h && ds[u] > 0.0)) ds[u] = 0.0;
-                if (ds[u] > 0.0) smx = fmin(smx, (h - xs[u]) / ds[u]);
-                else if (ds[u] < 0.0) smx = fmin(smx, (l - xs[u]) / ds[u]);
-            }
-            acc[e] = make_double2(ds[0], ds[1]);
-        }
         *reinterpret_cast<double2 *>(d + idx[e]) = acc[e];
         gd += gv[e].x * acc[e].x + gv[e].y * acc[e].y;
         dd += acc[e].x * acc[e].x + acc[e].y * acc[e].y;
@@ -593,11 +578,6 @@ __global__ __launch_bounds__(VEC_THREADS) void k_direction(const Dev dv)
     if (lane == 0) {
         SeedState &s = dv.st[b];
         s.gd_dir = tot[DP_GD];
-        if (dm.bounded) {
-            // the first trial step of the line search must already respect the box
-            s.stpmx = tot[DP_STPMX];
-            s.stp = fmin(s.iter == 0 ? fmin(1.0 / sqrt(tot[DP_DD]), 1e10) : 1.0, s.stpmx);
-        }
         if (!dv.sticky) s.dir = 0;
     }
 }

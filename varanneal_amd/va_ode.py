@@ -110,9 +110,9 @@ class Annealer(HIPmin):
           gather   False: skip the collective (`self.gathered` then holds this rank's seeds only)
           bounded_minimiser  with `bounds`: 'scipy' = SciPy's L-BFGS-B on the host around the device
                    evaluator, exactly the reference's call (_autodiffmin.py:85-86; one seed; the default
-                   for a single seed); 'device' = the device-resident minimiser in its active-set form
-                   (every seed at once, nothing leaves HBM; not L-BFGS-B's generalised Cauchy point, so
-                   iterates differ from SciPy's; the default for batched seeds)"""
+                   for a single seed); 'device' = L-BFGS-B itself on the device (generalised Cauchy point +
+                   subspace minimisation, csrc/va_lbfgsb.hip): every seed at once, nothing leaves HBM, SciPy's
+                   iterates step for step (the default for batched seeds)"""
         if n_seeds is not None:
             from . import parallel
             X0 = np.asarray(X0); P0 = np.asarray(P0, dtype=np.float64)
