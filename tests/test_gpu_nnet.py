@@ -122,6 +122,21 @@ def test_twin_ladder_on_device(gold):
     rel = np.abs(a.A_array - c["A_array"]) / c["A_array"]
     print("twin ladder vs reference goldens: rel. deviation per rung", np.array2string(rel, precision=2))
     assert np.all(rel[:8] <= 1e-2) and rel[-1] <= 1e-1
+    # What the twin experiment is for (nnet_twin_anneal.py:101-138): the weights that produced the data.  With M = 2
+    # examples 1900 weights are not identifiable -- the reference's own run ends 9.18 (rms) away from the true weights
+    # having started 0.08 away, the device's 23.9 away (measured) -- so recovered weights cannot arbitrate anything here;
+    # they are recorded.  What both runs must have in common is what the data do determine: the final network
+    # reproduces the twin's outputs as the reference's does (measurement error), with a model error that stays a small part of A.
+    _, _, Ptrue = twin.make_nnet_twin(np.array(c["structure"]), int(c["M"]))
+    Pidx = np.asarray(c["Pidx"])
+    err_ref = np.sqrt(np.mean((c["minpaths_last"][400:][Pidx] - Ptrue[Pidx]) ** 2))
+    err_dev = np.sqrt(np.mean((a.P[Pidx] - Ptrue[Pidx]) ** 2))
+    print("recovered weights, rms error against the twin's true weights: device %.4f, reference %.4f; final me %.3e / %.3e, fe %.3e / %.3e"
+          % (err_dev, err_ref, a.me_array[-1], c["me_array"][-1], a.fe_array[-1], c["fe_array"][-1]))
+    assert np.isfinite(err_dev)
+    # (measured: me 0.40011 / 0.40023, fe 1.08e-3 / 7.3e-6 -- the data term is the reference's to 3e-4; the model term,
+    # 0.3 % of A up here, is where the two neighbouring minima differ)
+    assert abs(a.me_array[-1] - c["me_array"][-1]) <= 1e-2 * c["me_array"][-1] and a.fe_array[-1] <= 1e-2 * a.A_array[-1]
     assert np.all(a.exitflags == 0)
     assert np.allclose(a.A_array, a.me_array + a.fe_array, rtol=1e-12)
     A, g = a.A_gradA_taped(np.append(a.minpaths[-1][:400], a.P[c["Pidx"]]))

@@ -33,10 +33,10 @@ va_ode.py:170-188, 565-570) are supported for the discretisations that work upst
 Here any subset Pidx may be estimated and bounds work (upstream's anneal_step and bounds
 branches for this case are broken, va_ode.py:597-601, 715-732).  A batch uses P0 (B, N_model, NP).
 
-Full measurement precision matrices (`RM` of shape (L,L) or (N_data,L,L), va_ode.py:149-152) are
-supported (flat tile kernel).  Not implemented (raise NotImplementedError): full (D,D) RF matrices
-(the upstream branch is wrong: va_ode.py:222 contracts `diff` where `diff[i]` is meant),
-user-defined action callables, method='LM'.
+Full measurement precision matrices (`RM` of shape (L,L) or (N_data,L,L), va_ode.py:149-152) and full
+model-error precision matrices (`RF0` of shape (D,D) or (N_model-1,D,D), va_ode.py:211-217; contracted per
+row, which is what upstream's Simpson-Hermite branch does and its other branches mean) are supported
+(flat tile kernel).  Not implemented (raise NotImplementedError): user-defined action callables, method='LM'.
 """
 from __future__ import print_function
 
