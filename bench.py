@@ -529,8 +529,8 @@ def main():
 
         def l96_user(t, x, p):
             return np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - x + p[0]
-        mod = codegen.module_for(l96_user, D, 1, col_variant=lambda ne, gh: _capi.eval_plan(
-            B, D, N, "trapezoid", ne, gh, tile_rows=args.tile_rows, eval_kernel=args.eval_kernel))
+        mod = codegen.module_for(l96_user, D, 1, col_variant=lambda ne, gh, reach: _capi.eval_plan(
+            B, D, N, "trapezoid", ne, gh, tile_rows=args.tile_rows, eval_kernel=args.eval_kernel, reach=reach, Lidx=Lidx))
         rhs = _capi.load_rhs_module(mod["so"])
     pb = _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", rhs=rhs,
                        device=local_rank, tile_rows=args.tile_rows, eval_kernel=args.eval_kernel)

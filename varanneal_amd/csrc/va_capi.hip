@@ -1096,7 +1096,7 @@ int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms
     // Each launch forms A, me, fe and the full gradient.  The launches are replayed from a hipGraph in chunks:
     // a host thread issues ~3.7 us apart, which would be the number measured for any kernel shorter than that
     // (the same kernel boundary either way: MI355X_MICROARCH.md, "boundary: eager = hipGraph").
-    const int chunk = iters < 500 ? iters : 500;
+    const int chunk = iters < 250 ? iters : 250;          // (one graph serves the warm-up call and the timed call)
     if (h->timed_gexec && (h->timed_chunk != chunk || !h->tune_graph)) { (void)hipGraphExecDestroy(h->timed_gexec); h->timed_gexec = nullptr; }
     if (h->tune_graph && iters >= 8 && !h->timed_gexec) {
         // (kept on the handle: the warm-up call builds it, the timed call replays it)
