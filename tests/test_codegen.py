@@ -335,3 +335,35 @@ def test_wide_stencil_gets_the_streaming_variant():
     m = codegen.module_for(_l96_plain, 200, 1, col_variant=cb, compile=False)
     assert seen["reach"] == (2, 1, 1, 2) and m["col_variant"] == (5, 1, 0, 0)
     assert "struct RhsUserCol" in m["text"] and "struct RhsUserG" not in m["text"]
+
+
+def _ring_of_units(t, x, p):
+    """NOT a stencil: a ring of five identical 4-state units (D = 20).  Unit u has a fast variable v = x[4u] driven by
+    its own three slow variables and diffusively coupled to the neighbouring units' v; the slow variables relax towards
+    polynomial functions of v.  Three parameters shared by all units."""
+    D = x.shape[-1]
+    U = D // 4
+    out = []
+    for u in range(U):
+        v, a, b, c = x[..., 4 * u], x[..., 4 * u + 1], x[..., 4 * u + 2], x[..., 4 * u + 3]
+        vl, vr = x[..., 4 * ((u - 1) % U)], x[..., 4 * ((u + 1) % U)]
+        out.append(p[0] * (vl + vr - 2.0 * v) - v * v * v + a * v - b + c * c)
+        out.append(p[1] * (v - a))
+        out.append(p[2] * (v * v - b))
+        out.append(-c + 0.5 * v * a)
+    return np.stack(out, axis=-1)
+
+
+def test_ring_of_identical_units_gets_a_periodic_column_form():
+    """block-periodic models (period P > 1): P column classes, one body each (`switch (col % P)`), the neighbour offsets
+    their union -- instead of the flat kernel's switch over all D columns"""
+    m = codegen.module_for(_ring_of_units, 20, 3, col_variant=lambda ne, gh: (4, 1, 5, 1), compile=False)
+    c = m["col"]
+    assert c is not None and not c["uniform"] and c["period"] == 4
+    assert c["offsets"] == [-4, -3, -2, -1, 1, 2, 3, 4] and c["NB"] == 8
+    assert "switch (col % 4)" in m["text"] and "case 3:" in m["text"] and "case 4:" not in m["text"].split("struct RhsUserCol")[1].split("struct")[0]
+    # a model without any such structure (every unit different) has no column form at D = 20
+    def irregular(t, x, p):
+        return np.stack([x[..., (i + 1) % 20] * (1.0 + 0.1 * i) - x[..., i] ** 2 + p[0] for i in range(20)], axis=-1)
+    m2 = codegen.module_for(irregular, 20, 1, col_variant=lambda ne, gh: (4, 1, 5, 1), compile=False)
+    assert m2["col"] is None

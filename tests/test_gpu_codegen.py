@@ -381,3 +381,59 @@ def test_ghosted_stencil_with_five_parameters_on_device():
         gi = fun(z)[0].imag / 1e-30
         z[i] = XP[i]
         assert abs(out[0][3][0, i] - gi) <= 1e-10 * np.abs(out[0][3][0]).max(), (i, out[0][3][0, i], gi)
+
+
+# ---- block-periodic models (a ring of identical units): periodic column form on the column-run kernels ------------
+def _ring_of_units(t, x, p):
+    """five identical 4-state units on a ring (D = 20): NOT a stencil (see tests/test_codegen.py)"""
+    D = x.shape[-1]
+    U = D // 4
+    out = []
+    for u in range(U):
+        v, a, b, c = x[..., 4 * u], x[..., 4 * u + 1], x[..., 4 * u + 2], x[..., 4 * u + 3]
+        vl, vr = x[..., 4 * ((u - 1) % U)], x[..., 4 * ((u + 1) % U)]
+        out.append(p[0] * (vl + vr - 2.0 * v) - v * v * v + a * v - b + c * c)
+        out.append(p[1] * (v - a))
+        out.append(p[2] * (v * v - b))
+        out.append(-c + 0.5 * v * a)
+    return np.stack(out, axis=-1)
+
+
+def test_ring_of_units_runs_the_column_kernel_at_c3_shape():
+    """a D = 20 model that is neither a stencil nor small: its periodic column form (4 classes) runs k_eval4; values
+    and gradient against the oracle's generic NumPy action (complex-step derivative) to 1e-12 / 1e-10, and against the
+    same module's flat kernel; time per evaluation of 64 seeds recorded next to the built-in Lorenz-96's"""
+    from varanneal_amd import twin
+    D, N, B, NP = 20, 1000, 64, 3
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    rng = np.random.RandomState(8)
+    P = np.array([0.7, 0.9, 1.3])
+    XP = np.concatenate([0.8 * rng.randn(B, N * D), np.tile(P, (B, 1))], axis=1)
+    m = codegen.module_for(_ring_of_units, D, NP, col_variant=lambda ne, gh: _capi.eval_plan(B, D, N, "trapezoid", ne, gh))
+    assert m["col"] is not None and m["col"]["period"] == 4 and m["col_variant"][0] == 4
+    rid = _capi.load_rhs_module(m["so"])
+    us = {}
+    with _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 0.3, np.tile(P, (B, 1)), [0, 1, 2], disc="trapezoid", rhs=rid) as pr:
+        assert pr.info()["eval_kernel"] == 4
+        A, me, fe, g = pr.action_grad(XP, 2.0)
+        pr.eval_timed(2.0, 100)
+        us["ring, column form"] = min(pr.eval_timed(2.0, 1000) for _ in range(3))
+    with _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 0.3, np.tile(P, (B, 1)), [0, 1, 2], disc="trapezoid", rhs=rid, eval_kernel=1) as pf:
+        assert pf.info()["eval_kernel"] == 1
+        Af, mef, fef, gf = pf.action_grad(XP, 2.0)
+        pf.eval_timed(2.0, 20)
+        us["ring, flat form"] = min(pf.eval_timed(2.0, 200) for _ in range(3)) * 5
+    P1 = XP[:, -1:].copy() * 0 + 8.0
+    with _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 0.3, P1, [0], disc="trapezoid") as pl:
+        pl.action_grad(np.concatenate([XP[:, :N * D], P1], axis=1), 2.0)
+        pl.eval_timed(2.0, 100)
+        us["built-in Lorenz-96"] = min(pl.eval_timed(2.0, 1000) for _ in range(3))
+    print("column vs flat form: A rel", (np.abs(A - Af) / np.abs(Af)).max(), "grad rel", np.abs(g - gf).max() / np.abs(gf).max())
+    assert np.all(np.abs(A - Af) <= 1e-12 * np.abs(Af)) and np.abs(g - gf).max() <= 1e-11 * np.abs(gf).max()
+    fun = lambda z: va_oracle.numpy_action_generic(_ring_of_units, z, D, N, Y, Lidx, twin.DT, 4.0, 0.3 * 2.0, NP, [0, 1, 2], P, "trapezoid")
+    for b in (0, B - 1):
+        A0 = fun(XP[b])[0]
+        assert abs(A[b] - A0) <= 1e-12 * abs(A0)
+    g0 = va_oracle.complex_step_grad(fun, XP[3])
+    assert np.abs(g[3] - g0).max() <= 1e-10 * np.abs(g0).max()
+    print("D = 20, N = 1000, 64 seeds, us per complete evaluation:", {k: round(v, 2) for k, v in us.items()})

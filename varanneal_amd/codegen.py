@@ -225,6 +225,24 @@ def _translation_invariant(exprs, xs, D):
     return True
 
 
+def _period(exprs, xs, D, max_period=8):
+    """smallest P > 1 dividing D such that every f_{i+P} is f_i with the state indices shifted cyclically by P (a ring of
+    D / P identical units of P states each, e.g. coupled neurons), or None.  P = 1 is _translation_invariant's case."""
+    sp = _sympy()
+    for P in range(2, min(max_period, D // 2) + 1):
+        if D % P:
+            continue
+        ok = True
+        for i in range(D):
+            e = exprs[i].xreplace({xs[j]: xs[(j + P) % D] for j in range(D)})
+            if e != exprs[(i + P) % D] and sp.simplify(e - exprs[(i + P) % D]) != 0:
+                ok = False
+                break
+        if ok:
+            return P
+    return None
+
+
 def _local_printer(xmap):
     """C printer that writes state symbols as the column kernel sees them: the lane's own value `x0`
     and the neighbour values `xn[k]` (xmap: symbol -> C text)."""
@@ -253,12 +271,27 @@ def column_form(exprs, syms, D, NP, nstim, max_dense=8, uniform=None):
     uses_t = any(e.has(syms["t"]) for e in exprs)
 
     uniform = _translation_invariant(exprs, xs, D) if uniform is None else uniform
+    period = 1 if uniform else None
     if uniform:
         cols = [j for j in range(1, D) if sp.diff(exprs[0], xs[j]) != 0]
         offs = sorted(((j + D // 2) % D) - D // 2 for j in cols)          # signed cyclic offsets
         if len(set(o % D for o in offs)) != len(offs) or len(offs) > 8 or len(offs) == 0:
             uniform = False
-    if not uniform:
+            period = None
+    if not uniform and D > max_dense:
+        # a ring of identical units (period P): P column classes, each with its own body; the neighbour offsets are
+        # the union over the classes, so the exchange of the adjoint products stays the uniform one
+        P = _period(exprs, xs, D)
+        if P is not None:
+            offset_set = set()
+            for i in range(P):
+                for j in range(D):
+                    if j != i and sp.diff(exprs[i], xs[j]) != 0:
+                        offset_set.add(((j - i + D // 2) % D) - D // 2)
+            offs = sorted(offset_set)
+            if 0 < len(offs) <= 8 and len(set(o % D for o in offs)) == len(offs):
+                period = P
+    if not uniform and period is None:
         if D > max_dense or D < 2:
             return None
         offs = list(range(1, D))
@@ -272,7 +305,7 @@ def column_form(exprs, syms, D, NP, nstim, max_dense=8, uniform=None):
             xmap[xs[(i + o) % D]] = "xn[%d]" % k
         return _local_printer(xmap)
 
-    rows = [0] if uniform else list(range(D))
+    rows = [0] if uniform else (list(range(period)) if period else list(range(D)))
     # products: per neighbour k the derivative df_i/dx_{i+off_k}; in the uniform case proportional ones share a slot
     derivs = {i: [sp.diff(exprs[i], xs[(i + o) % D]) for o in offs] for i in rows}
     slot_of, coef_of = list(range(NB)), [sp.Integer(1)] * NB
@@ -314,7 +347,7 @@ def column_form(exprs, syms, D, NP, nstim, max_dense=8, uniform=None):
     def emit_switch(body_for_row, default):
         if uniform:
             return ["        " + body_for_row(0)]
-        lines = ["        switch (col) {"]
+        lines = ["        switch (col %% %d) {" % period] if period else ["        switch (col) {"]
         for i in rows:
             lines.append("        case %d: { %s break; }" % (i, body_for_row(i)))
         lines.append("        default: { %s break; }" % default)
@@ -369,7 +402,7 @@ def column_form(exprs, syms, D, NP, nstim, max_dense=8, uniform=None):
     out.append("    }")
     out.append("};")
     xl, xr = max([0] + [-o for o in offs]), max([0] + offs)
-    return dict(text="\n".join(out), uniform=uniform, offsets=offs, NE=NE, NB=NB, reach=(xl, xr, xr, xl),
+    return dict(text="\n".join(out), uniform=uniform, period=period, offsets=offs, NE=NE, NB=NB, reach=(xl, xr, xr, xl),
                 autonomous=not uses_t and nstim == 0)
 
 
@@ -531,7 +564,7 @@ def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False, p_rows=False, col_
     if col_variant is not None and not p_rows:
         uniform = _translation_invariant(exprs, list(syms["x"]), D)
         # column form: k_eval4 (D <= 64: stencils and small dense systems) or, for stencils, the streaming k_eval5
-        col = column_form(exprs, syms, D, NP, nstim, uniform=uniform) if (D <= 64 or uniform) else None
+        col = column_form(exprs, syms, D, NP, nstim, uniform=uniform)          # (None when the model has no such form)
         ghost = ghost_form(exprs, syms, D, NP, nstim, uniform=uniform)
         variant = None
         if col or ghost:
@@ -543,7 +576,7 @@ def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False, p_rows=False, col_
                 three = False
             # (a callback of three arguments also gets the column form's reaches, or None when the form is not one
             # the streaming kernel can run: non-uniform, explicit time, stimulus)
-            reach = col["reach"] if (col and col["uniform"] and col["autonomous"]) else None
+            reach = col["reach"] if (col and (col["uniform"] or col["period"]) and col["autonomous"]) else None
             variant = col_variant(ne, gh, reach) if three else col_variant(ne, gh)
         if variant is None or variant[0] not in (4, 5):
             col = None

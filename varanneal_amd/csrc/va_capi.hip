@@ -240,6 +240,15 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
             const bool ws4 = d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1;
             if (!ws4 && (K == 6 || K == 7)) K = sh ? 4 : 5;
         }
+        // column forms with many products per element (a ring of coupled units: 8): the product arrays grow with the run
+        // length; keep at least two workgroups per CU (measured, five 4-state units at the C3 shape: K = 4 23.4 us, K = 7 31.5)
+        if (d->tile_rows <= 0) {
+            while (K > 4) {
+                const Geo4 gt = sh ? tile4_geo<3>(D, K, ne, 1) : tile4_geo<2>(D, K, ne, 1);
+                if (sizeof(double) * (size_t)gt.NW * gt.WAVE <= 80 * 1024) break;
+                K -= (sh || K == 5) ? (K == 5 ? 1 : 2) : 1;
+            }
+        }
         // (one wave per SIMD walking SUB sub-tiles in turn was measured slower than co-resident waves -- DESIGN.md section 7;
         // only SUB = 1 is instantiated, and the host never asks for anything else)
         const int SUB = 1;

@@ -31,7 +31,7 @@ __device__ __forceinline__ void tile4_dma(const Geo4 &g, const double *src, doub
 // (co-resident waves run in lockstep: load, then compute, then store, all of them together), and
 // the wave reduces its partial sums once.
 template <class RHS, int DISC, int K, int DC, bool W_SCALAR, int SUB>
-__global__ __launch_bounds__(256, SUB > 1 ? 1 : (K <= 7 ? 3 : 2)) void k_eval4(const Dev dv)
+__global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ? 3 : 2)) void k_eval4(const Dev dv)      // (the neighbour values of the lane's K rows live in registers: K * NB of them)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const Dims &dm = dv.dm;
