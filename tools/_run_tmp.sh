@@ -1,3 +1,7 @@
-mkdir -p gpurun_out/r3z
-timeout -k 10 600 python -m pytest tests/test_gpu_codegen.py -m gpu -q -x -s -k "ring_of_units" 2>&1 | grep -E "us per complete|passed|failed" | cut -c1-300
-timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/r3z/gpu.log 2>&1; tail -3 gpurun_out/r3z/gpu.log
+one() { python bench.py --no-cpu --no-extra --steps 3000 --warmup 300 "$@" 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        j=json.loads(l); r=j['roofline']; c=j['config']; print('kernel_us=%6.3f frac=%.3f tune=%s' % (r['kernel_us'], r['frac'], c['tune']))
+"; }
+one; for p in 2 3 4 5 7 9 -2 -4 -6; do one --tune prio=$p; done; one
