@@ -285,13 +285,13 @@ def _wide_stencil(t, x, p):
 
 
 def test_traced_l96_at_c4_width_runs_the_builtin_kernels():
-    """D = 200 (BASELINE config 4's width): the traced Lorenz-96 gets the kernels the built-in runs -- the streaming
-    kernel k_eval5 through its column form, and (Simpson-Hermite, which k_eval5 does not carry) the workgroup kernel
-    k_eval3 through its ghosted form -- with values within 1e-13 of the built-in's"""
+    """D = 200 (BASELINE config 4's width): the traced Lorenz-96 gets the kernel the built-in runs -- the streaming
+    kernel k_eval5 through its column form, one-step rules and Simpson-Hermite -- with values within 1e-13 of the
+    built-in's"""
     from varanneal_amd import twin
     D, B = 200, 16
     Lidx = list(range(0, D, 5))
-    for disc, N, ek in (("trapezoid", 2000, 5), ("SimpsonHermite", 1001, 3)):
+    for disc, N, ek in (("trapezoid", 2000, 5), ("SimpsonHermite", 1001, 5)):
         t, Y, _, _ = twin.make_twin(D, N, Lidx=Lidx)
         rng = np.random.RandomState(0)
         XP = np.concatenate([8.0 * rng.rand(B, N * D) - 4.0, 8.17 + 0.1 * rng.randn(B, 1)], axis=1)

@@ -52,11 +52,13 @@ def check_vs_oracle(capi, D, N, B, disc, tile_rows, seed=1, L=None, rf=37.0):
     return info
 
 
-@pytest.mark.parametrize("disc", ["trapezoid", "euler", "forwardmap"])
+@pytest.mark.parametrize("disc", ["trapezoid", "euler", "forwardmap", "SimpsonHermite"])
 def test_c4_shape_small(capi, disc):
-    """D = 200 (the compiled-in width): one segment, several segments, segments of odd and even stream length"""
-    for N, B, tile_rows in ((40, 3, 0), (301, 2, 0), (300, 2, 50), (97, 4, 32), (64, 1, 33)):
-        check_vs_oracle(capi, 200, N, B, disc, tile_rows, seed=N)
+    """D = 200 (the compiled-in width): one segment, several segments, segments of odd and even stream length
+    (Simpson-Hermite: an odd number of rows, va_ode.py:231-233 upstream; a last segment of one row)"""
+    odd = disc == "SimpsonHermite"
+    for N, B, tile_rows in ((40, 3, 0), (301, 2, 0), (300, 2, 50), (97, 4, 32), (64, 1, 33), (129, 2, 32), (67, 1, 64)):
+        check_vs_oracle(capi, 200, N + (odd and N % 2 == 0), B, disc, tile_rows, seed=N)
 
 
 def test_other_widths(capi):
@@ -66,6 +68,7 @@ def test_other_widths(capi):
         L = 2 * (D // 5)
         info = check_vs_oracle(capi, D, N, B, "trapezoid", 0, seed=D, L=L)
         check_vs_oracle(capi, D, N, B, "trapezoid", 34, seed=D + 1, L=L)
+        check_vs_oracle(capi, D, N + 1 - N % 2, B, "SimpsonHermite", 34, seed=D + 2, L=L)
         print(D, info)
 
 
@@ -93,7 +96,7 @@ def test_sparse_and_dense_observations(capi):
 
 
 def test_fallback_when_the_streaming_kernel_does_not_apply(capi):
-    """odd L, Simpson-Hermite, per-row weights: the handle runs a tile kernel instead (and says so)"""
+    """odd L, per-row weights: the handle runs a tile kernel instead (and says so); Simpson-Hermite streams"""
     from varanneal_amd import twin
     D, N, B = 200, 41, 1
     Y, Lidx, XP, P = make(D, N, B, 3, L=7)
@@ -101,7 +104,7 @@ def test_fallback_when_the_streaming_kernel_does_not_apply(capi):
         assert pb.info()["eval_kernel"] == 3
     Y, Lidx, XP, P = make(D, N, B, 3)
     with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="SimpsonHermite", eval_kernel=5) as pb:
-        assert pb.info()["eval_kernel"] == 3
+        assert pb.info()["eval_kernel"] == 5
     with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, np.full((N - 1, D), 4e-6), P, [0], disc="trapezoid", eval_kernel=5) as pb:
         assert pb.info()["eval_kernel"] == 3
 
@@ -118,12 +121,13 @@ def test_timed_evaluation_is_a_complete_evaluation(capi):
             assert np.array_equal(A, A2) and np.array_equal(me, me2) and np.array_equal(fe, fe2) and np.array_equal(g, g2)
 
 
-def test_minimisation_follows_the_oracle(capi):
+@pytest.mark.parametrize("disc", ["trapezoid", "SimpsonHermite"])
+def test_minimisation_follows_the_oracle(capi, disc):
     """line-search evaluations (x + stp d formed in LDS from the two staged images): a short minimisation takes
     the oracle's (nit, nfev, status) and ends at its point; the tile kernel gives the same counts"""
     import va_oracle
     from varanneal_amd import twin
-    D, N, B = 200, 120, 3
+    D, N, B = 200, 121, 3
     t, Y, _, Lidx = twin.make_twin(D, N)
     XP = np.empty((B, N * D + 1)); P = np.empty((B, 1))
     for b in range(B):
@@ -132,11 +136,11 @@ def test_minimisation_follows_the_oracle(capi):
     o = dict(OPTS, maxiter=30)
     res = {}
     for ek in (5, 3):
-        with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", eval_kernel=ek, tile_rows=(40 if ek == 5 else 0)) as pb:
+        with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc=disc, eval_kernel=ek, tile_rows=(40 if ek == 5 else 0)) as pb:
             assert pb.info()["eval_kernel"] == ek
             res[ek] = pb.minimize_lbfgs(XP, 1.5 ** 6, o)
     for b in range(B):
-        opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[b], [0], disc="trapezoid")
+        opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[b], [0], disc=disc)
         x, A, st, nit, nfev = opb.minimize_lbfgs(XP[b], 1.5 ** 6, o)
         r = res[5]
         assert (r["nit"][b], r["nfev"][b], r["status"][b]) == (nit, nfev, st), b

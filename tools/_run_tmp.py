@@ -1,17 +1,17 @@
-import sys, os
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "oracle")); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
-import numpy as np
-from varanneal_amd import _capi, codegen, twin
-from test_gpu_codegen import _ring_of_units
-D, NP, N, B = 20, 3, 1000, 64
-P = np.array([0.7, 0.9, 1.3])
-t, Y, _, Lidx = twin.make_twin(D, N)
-rng = np.random.RandomState(8)
-XP = np.concatenate([0.8 * rng.randn(B, N * D), np.tile(P, (B, 1))], axis=1)
-for tr in (48, 60, 72, 84, 96):
-    m = codegen.module_for(_ring_of_units, D, NP, col_variant=lambda ne, gh: _capi.eval_plan(B, D, N, "trapezoid", ne, gh, tile_rows=tr))
-    rid = _capi.load_rhs_module(m["so"])
-    with _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 0.3, np.tile(P, (B, 1)), [0, 1, 2], disc="trapezoid", rhs=rid, tile_rows=tr) as pr:
-        pr.action_grad(XP, 2.0); pr.eval_timed(2.0, 100)
-        us = min(pr.eval_timed(2.0, 500) for _ in range(3)) * 2
-        print(tr, m["col_variant"], pr.info()["eval_kernel"], pr.info()["run_rows"], pr.info()["ntiles"], "%.2f us" % us, flush=True)
+import numpy as np, sys
+sys.path.insert(0, '.')
+from varanneal_amd import _capi, twin
+D, N, B = 200, 5001, 64
+Lidx = list(range(0, D, 5))
+t, Y, _, _ = twin.make_twin(D, N, Lidx=Lidx)
+rng = np.random.RandomState(0)
+XP = np.concatenate([8.0 * rng.rand(B, N * D) - 4.0, 8.17 + 0.1 * rng.randn(B, 1)], axis=1)
+P = XP[:, N * D:].copy()
+for disc in ("SimpsonHermite", "trapezoid"):
+    for ek in (5, 3):
+        pr = _capi.Problem(B, D, N, Y, Lidx, 0.025, 4.0, 4e-6, P, [0], disc=disc, eval_kernel=ek)
+        out = pr.action_grad(XP, 1.5 ** 20)
+        pr.eval_timed(1.5 ** 20, 20)
+        us = min(pr.eval_timed(1.5 ** 20, 50) for _ in range(3)) / 50 * 1e3
+        print(disc, ek, pr.info()["eval_kernel"], "us=%.1f" % us, "frac=%.3f" % (16.0 * B * N * D / (us * 1e-6) / 8e12), "A0=%.15g" % out[0][0], flush=True)
+        pr.close()

@@ -148,10 +148,10 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
     // auto: wave-private column runs for narrow states that fill a wave, workgroup column runs up
     // to 1024 columns, flat mapping beyond
     if (dm.emode == 2) dm.emode = 3;                      // (the row-strided kernel of round 1 is gone)
-    // streaming column strips: wide even states, a column form, a one-step discretisation, scalar weights with
+    // streaming column strips: wide even states, a column form, scalar weights with
     // data at every model time (what every BASELINE config has); anything else keeps the tile kernels
     const bool ws5 = d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1 && d->L >= 1;
-    const bool can5 = reach5 && g5 && ystrip && !user_rhs && ne > 0 && !sh && ws5 && D > 64 &&
+    const bool can5 = reach5 && g5 && ystrip && !user_rhs && ne > 0 && ws5 && D > 64 && (!sh || (N & 1)) &&
                       tile5_ok(D, reach5[0], reach5[1], reach5[2], reach5[3]);
     if (dm.emode == 5 && !can5) dm.emode = 0;
     if (dm.emode < 1 || dm.emode > 5) dm.emode = (tile4_ok(D) && ne > 0) ? 4 : (can5 ? 5 : ((D <= 1024 && ghost > 0) ? 3 : 1));
@@ -747,7 +747,8 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
 #define TRY(x) do { rc = (x); if (rc) { va_problem_destroy(h); return rc; } } while (0)
     TRY(h->alloc(&lmap_d, dm.D));
     // (two rows + a line of padding: the streaming kernel stages observation rows by whole 16-byte pieces, two rows at a time)
-    TRY(h->alloc(&Y_d, (size_t)dm.N_data * dm.L + 2 * (size_t)dm.L + 16));
+    TRY(h->alloc(&Y_d, (size_t)dm.N_data * dm.L + 4 * (size_t)dm.L + 16));   // (k_eval5 stages row pairs: one pair before the first row, one past the last)
+    Y_d += 2 * (size_t)(dm.L / 2) + (dm.L & 1) * 2;       // an even number of doubles >= L: the data keep their 16-byte alignment
     int *ystrip_d = nullptr;
     if (dm.emode == 5) TRY(h->alloc(&ystrip_d, ystrip_h.size()));
     const size_t np_seed = tdp ? (size_t)dm.N * dm.NPt : (size_t)dm.NPt;       // parameters stored per seed

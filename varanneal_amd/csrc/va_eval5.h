@@ -2,7 +2,8 @@
 // (BASELINE config 4: Lorenz-96 D = 200, N = 5000) and its launcher.  Geometry: va_tile5.h.
 //
 // Reference arithmetic (va_core.h header): fe_gaussian va_ode.py:160-234 with disc_trapezoid :358-380,
-// disc_euler :341-356 or disc_forwardmap :439-454, me_gaussian :138-158; gradient by the hand-coded adjoint of
+// disc_euler :341-356, disc_forwardmap :439-454 or disc_SimpsonHermite :404-437 (an interval of two rows per
+// step instead of a row, see the walk), me_gaussian :138-158; gradient by the hand-coded adjoint of
 // the stencil.  One wave = one strip of state columns of one seed over one segment of time rows:
 //
 //   ring      NSLOT slots of two staged rows each; slot k+NSLOT-1 is requested (global_load_lds_dwordx4:
@@ -54,7 +55,6 @@ template <class RHS> struct T5Gather<RHS, -1> { static __device__ __forceinline_
 template <class RHS, int DISC, int DC, int NSLOT, bool LSRUN, bool XDPP>
 __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
 {
-    static_assert(DISC != DISC_SH, "one-step discretisations only");
     static_assert(!RHS::USES_T && RHS::NSTIM == 0, "autonomous right-hand sides only");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const Dims &dm = dv.dm;
@@ -100,8 +100,11 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
         const int c0 = tile5_c0(D, gc.NS, strip);
         const int cws = tile5_c0(D, gc.NS, strip + 1) - c0;
         const int n0 = sg * SEGL, n1 = (n0 + SEGL) < N ? (n0 + SEGL) : N;
-        const int rs = n0 > 0 ? n0 - 1 : 0, re = n1 < N ? n1 + 1 : N;
-        const int SR = re - rs;                               // rows of the stream (>= 2)
+        // first and one-past-last row of the stream.  One-step rules: the row before the segment .. the row
+        // after it.  Simpson-Hermite walks interval by interval (rows m, m+1, m+2, m even): the stream starts one
+        // interval early, and one more row in front (never used) keeps the interval's rows (m+1, m+2) in ONE slot
+        const int rs = DISC == DISC_SH ? (n0 > 0 ? n0 - 3 : -1) : (n0 > 0 ? n0 - 1 : 0), re = n1 < N ? n1 + 1 : N;
+        const int SR = re - rs;                               // rows of the stream (>= 2; even for Simpson-Hermite)
         const int nslots = (SR + 1) >> 1;
         const double *xg = dv.x + (size_t)b * dm.ld;
         const double *dg = dv.d + (size_t)b * dm.ld;
@@ -150,9 +153,9 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
         const double c2 = 2.0 * dm.cme * wobs;
 
         // ---- staging
-        const char *xrow = reinterpret_cast<const char *>(xg + (size_t)rs * D);      // uniform: first row of slot 0
-        const char *drow = reinterpret_cast<const char *>(dg + (size_t)rs * D);
-        const char *yrow = reinterpret_cast<const char *>(dv.pp.Y + (size_t)rs * L);
+        const char *xrow = reinterpret_cast<const char *>(xg + (ptrdiff_t)rs * D);   // uniform: first row of slot 0
+        const char *drow = reinterpret_cast<const char *>(dg + (ptrdiff_t)rs * D);
+        const char *yrow = reinterpret_cast<const char *>(dv.pp.Y + (ptrdiff_t)rs * L);
         const size_t xstep = (size_t)2 * D * 8, ystep = (size_t)2 * L * 8;
         auto issue = [&](int k, int pos) {
             if (dma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(xrow + k * xstep + xoff), (lds_void_t *)(xring + pos * SLOTX), 16, 0, 0);
@@ -173,15 +176,11 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
 #pragma unroll
         for (int k = 0; k < RHS::NP; ++k) gp[k] = 0.0;
 
-        // finish row m = (row of the state registers): q = adjoint weight of the residual that starts at row m
-        auto emit = [&](double q, int orow) {
-            double direct, s;
-            if constexpr (DISC == DISC_TRAPEZOID) { direct = qp - q; s = -hdt * (qp + q); }
-            else if constexpr (DISC == DISC_EULER) { direct = qp - q; s = -dt * q; }
-            else { direct = qp; s = -q; }
+        // finish a row: its direct term and s (the adjoint weight that multiplies df/dx of that row)
+        auto emit_row = [&](double x0, const double *xn, double yv, double dval, double direct, double s, int orow) {
             double e[NE], diag;
-            RHS::scatter(col, s, x0p, xnp, p, 0.0, nullptr, e, diag);
-            RHS::pgrad(col, s, x0p, xnp, p, 0.0, nullptr, gp);
+            RHS::scatter(col, s, x0, xn, p, 0.0, nullptr, e, diag);
+            RHS::pgrad(col, s, x0, xn, p, 0.0, nullptr, gp);
             double r[NG];
             if constexpr (XDPP) T5Gather<RHS, NG - 1>::run(e, r);
             else {
@@ -192,16 +191,24 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
                 for (int u = 0; u < NG; ++u) r[u] = VA_LDS_CVP(prod + RHS::g_e(u) * PW + PL + lane)[RHS::g_off(u)];
                 wave_sync_lds();                              // (the next row overwrites the arrays)
             }
-            const double diff = x0p - yp;
+            const double diff = x0 - yv;
             me = fma(diff, diff, me);
             double gv = (direct + diag) + RHS::gather(r);
             gv = fma(c2, diff, gv);
             if constexpr (LSRUN) {
-                gtd = fma(gv, dp, gtd);
+                gtd = fma(gv, dval, gtd);
                 gn2 = fma(gv, gv, gn2);
                 gmax = __builtin_fmax(gmax, __builtin_fabs(gv));
             }
             outb[orow * 64 + lane] = gv;
+        };
+        // one-step rules: finish the row of the state registers; q = adjoint weight of the residual that starts there
+        auto emit = [&](double q, int orow) {
+            double direct, s;
+            if constexpr (DISC == DISC_TRAPEZOID) { direct = qp - q; s = -hdt * (qp + q); }
+            else if constexpr (DISC == DISC_EULER) { direct = qp - q; s = -dt * q; }
+            else { direct = qp; s = -q; }
+            emit_row(x0p, xnp, yp, dp, direct, s, orow);
             qp = q;
         };
         // rows m0, m0 + 1 (or m0 alone) of the gradient: LDS -> 16-byte stores
@@ -279,6 +286,55 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
             }
         };
 
+        if constexpr (DISC == DISC_SH) {
+            // Simpson-Hermite: the state registers hold an even row m with the adjoint weights (q1p, q2p) of the
+            // interval that ENDS there; rows (m+1, m+2) enter together, give the interval's two residuals
+            //   r1 = x_{m+2} - x_m - (dt/3)(f_m + 4 f_{m+1} + f_{m+2})          (counted at row m)
+            //   r2 = x_{m+1} - (x_m + x_{m+2})/2 - (dt/4)(f_m - f_{m+2})        (counted at row m+1)
+            // and rows m and m+1 are finished (va_tile4.h tile4_rows has the same sums tile by tile)
+            double q2p = 0.0;                                 // (qp is q1 of the interval behind)
+            const double dt3 = dt / 3.0, dt4 = dt / 4.0;
+            auto step_sh = [&](const Row &t0, const Row &t1) {
+                const double f0 = RHS::f(col, t0.x0, t0.xn, p, 0.0, nullptr);
+                const double f1 = RHS::f(col, t1.x0, t1.xn, p, 0.0, nullptr);
+                const double r1 = t1.x0 - x0p - (fp + 4.0 * f0 + f1) * dt3;
+                const double r2 = t0.x0 - (0.5 * (x0p + t1.x0) + (fp - f1) * dt4);
+                fe = fma(r1, r1, fe);
+                fe = fma(r2, r2, fe);
+                const double q1 = cw * r1, q2 = cw * r2;
+                emit_row(x0p, xnp, yp, dp, -q1 - 0.5 * q2 + qp - 0.5 * q2p, -dt3 * (q1 + qp) - dt4 * (q2 - q2p), 0);
+                emit_row(t0.x0, t0.xn, t0.yv, t0.dval, q2, -(4.0 * dt3) * q1, 1);
+                x0p = t1.x0; fp = f1; yp = t1.yv; dp = t1.dval; qp = q1; q2p = q2;
+#pragma unroll
+                for (int k = 0; k < NB; ++k) xnp[k] = t1.xn[k];
+            };
+            // slot 0: its second row is the even row the walk starts from (row 0, or two rows before the segment)
+            begin_slot(0, 0, P % NSLOT);
+            {
+                const Row t1 = load_row(0, 1);
+                step(t1, true, 0);
+                flush(0, 0x7ffffff0);                         // (a store that goes nowhere: the queue counts of begin_slot stay those of the one-step walk)
+            }
+            int pos = 1 % NSLOT, ppos = (1 + P) % NSLOT;
+            for (int k = 1; k < nslots; ++k) {
+                begin_slot(k, pos, ppos);
+                const Row t0 = load_row(pos, 0), t1 = load_row(pos, 1);
+                step_sh(t0, t1);
+                const bool lead = k == 1 && n0 > 0;           // the interval before the segment: finished into nowhere
+                flush(rs + 2 * k - 1, lead ? 0x7ffffff0 : gvoff2);
+                if (lead) {
+                    fe = 0.0; me = 0.0; gtd = 0.0; gn2 = 0.0; gmax = 0.0;
+#pragma unroll
+                    for (int u = 0; u < RHS::NP; ++u) gp[u] = 0.0;
+                }
+                pos = pos + 1 == NSLOT ? 0 : pos + 1;
+                ppos = ppos + 1 == NSLOT ? 0 : ppos + 1;
+            }
+            if (n1 == N) {                                    // the path's last row: no interval starts there
+                emit_row(x0p, xnp, yp, dp, qp - 0.5 * q2p, -dt3 * qp + dt4 * q2p, 0);
+                flush(N - 1, gvoff1);
+            }
+        } else {
         // slot 0: the row before the segment only loads the state; a segment that starts at row 0 has no
         // residual behind it (q_{-1} = 0) and its first row is finished for real, any other segment's
         // "row n0 - 1" is finished into nowhere and the sums it left are cleared
@@ -312,6 +368,7 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
             flush(rs + 2 * nfull - 1, gvoff1);
         }
         if (n1 == N) { emit(0.0, 0); flush(N - 1, gvoff1); }    // the path's last row: no residual starts there
+        }
         if (!drained) VA_WAIT_VM(0);
 
         // ---- the lane's sums (lanes outside the strip's own columns computed ghosts: not theirs to count)

@@ -15,6 +15,7 @@ static hipError_t eval5_disc(const Dev &dv, bool prepare, hipStream_t s)
     switch (dv.dm.disc) {
     case DISC_EULER: return eval5_run<RHS, DISC_EULER, DC>(dv, prepare, s);
     case DISC_TRAPEZOID: return eval5_run<RHS, DISC_TRAPEZOID, DC>(dv, prepare, s);
+    case DISC_SH: return eval5_run<RHS, DISC_SH, DC>(dv, prepare, s);
     default: return eval5_run<RHS, DISC_FWDMAP, DC>(dv, prepare, s);
     }
 }
