@@ -917,16 +917,49 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
         if (n < NL - 1) { t.sn1 = s[n + 1]; t.offn1 = off[n + 1]; t.woff = woff[n]; t.boff = boff[n]; }
         return t;
     };
-    for (int n = 0; n < NL - 1; ++n)
-        for (int m0 = 0; m0 < d->M; m0 += NN_TILE)
-            for (int i0 = 0; i0 < s[n + 1]; i0 += NN_TILE) t1.push_back(tile(n, m0, i0, 0));
-    for (int n = 0; n < NL; ++n)
-        for (int m0 = 0; m0 < d->M; m0 += NN_TILE)
-            for (int j0 = 0; j0 < s[n]; j0 += NN_TILE) t2.push_back(tile(n, m0, j0, 0));
-    for (int n = 0; n < NL - 1; ++n)
-        for (int c = 0; c < nn.nmch; ++c)
+    // Order of the jobs: workgroup i of a launch runs on XCD i % 8, each with an L2 of its own.  The jobs that read the
+    // same operand rows (the column tiles of one row block; the four tiles of one example chunk) are placed 8 apart --
+    // eight such families at a time, member by member -- so that they meet in ONE L2 and the rows come from HBM once
+    auto place = [&](std::vector<NnetTile> &out, std::vector<std::vector<NnetTile>> &fam) {
+        size_t f0 = 0;
+        while (f0 < fam.size()) {
+            const size_t nf = std::min<size_t>(8, fam.size() - f0);
+            size_t width = 0;
+            for (size_t f = 0; f < nf; ++f) width = std::max(width, fam[f0 + f].size());
+            bool uniform = nf == 8;
+            for (size_t f = 0; f < nf; ++f) uniform = uniform && fam[f0 + f].size() == width;
+            if (uniform)
+                for (size_t k = 0; k < width; ++k)
+                    for (size_t f = 0; f < nf; ++f) out.push_back(fam[f0 + f][k]);
+            else
+                for (size_t f = 0; f < nf; ++f) out.insert(out.end(), fam[f0 + f].begin(), fam[f0 + f].end());
+            f0 += nf;
+        }
+        fam.clear();
+    };
+    std::vector<std::vector<NnetTile>> fam;
+    for (int n = 0; n < NL - 1; ++n) {
+        for (int m0 = 0; m0 < d->M; m0 += NN_TILE) {
+            fam.emplace_back();
+            for (int i0 = 0; i0 < s[n + 1]; i0 += NN_TILE) fam.back().push_back(tile(n, m0, i0, 0));
+        }
+        place(t1, fam);
+    }
+    for (int n = 0; n < NL; ++n) {
+        for (int m0 = 0; m0 < d->M; m0 += NN_TILE) {
+            fam.emplace_back();
+            for (int j0 = 0; j0 < s[n]; j0 += NN_TILE) fam.back().push_back(tile(n, m0, j0, 0));
+        }
+        place(t2, fam);
+    }
+    for (int n = 0; n < NL - 1; ++n) {
+        for (int c = 0; c < nn.nmch; ++c) {
+            fam.emplace_back();
             for (int i0 = 0; i0 < s[n + 1]; i0 += NN_TILE)
-                for (int j0 = 0; j0 < s[n]; j0 += NN_TILE) t3.push_back(tile(n, i0, j0, c));
+                for (int j0 = 0; j0 < s[n]; j0 += NN_TILE) fam.back().push_back(tile(n, i0, j0, c));
+        }
+        place(t3, fam);
+    }
     nn.n1 = (int)t1.size(); nn.n2 = (int)t2.size(); nn.n3 = (int)t3.size();
     nn.n4 = (d->NP + NN_THREADS - 1) / NN_THREADS;
     nn.n0 = (nn.NDens + d->NP + NN_THREADS * NN_PACK - 1) / (NN_THREADS * NN_PACK);
