@@ -219,15 +219,15 @@ def test_column_module_exports_its_variant():
     import ctypes as C
     m = codegen.module_for(_l96_plain, 20, 1, col_variant=lambda ne, gh: (4, 1, 7, 1) if ne == 2 else None)
     L = C.CDLL(m["so"])
-    v = (C.c_int * 6)()
+    v = (C.c_int * 12)()
     L.va_user_variant_info(v)
-    assert list(v) == [4, 1, 7, 1, 2, 0] and hasattr(L, "va_user_launch_variant") and hasattr(L, "va_user_prepare_variant")
+    assert list(v)[:6] == [4, 1, 7, 1, 2, 0] and list(v)[10] == 0 and hasattr(L, "va_user_launch_variant") and hasattr(L, "va_user_prepare_variant")
 
 
 def test_module_without_variant_reports_none(nakl_module):
     import ctypes as C
     L0 = C.CDLL(nakl_module["so"])                              # no variant asked for: flat kernel only
-    v = (C.c_int * 6)()
+    v = (C.c_int * 12)()
     L0.va_user_variant_info(v)
     assert list(v)[0] == 0 and not hasattr(L0, "va_user_launch_variant")
 
@@ -297,9 +297,9 @@ def test_ghost_module_exports_its_variant():
     m = codegen.module_for(_l96_plain, 200, 1, col_variant=lambda ne, gh: _capi.eval_plan(64, 200, 5000, "trapezoid", ne, gh))
     assert m["col_variant"] == (3, 1, 8, 256) and m["col"] is None
     L = C.CDLL(m["so"])
-    v = (C.c_int * 6)()
+    v = (C.c_int * 12)()
     L.va_user_variant_info(v)
-    assert list(v) == [3, 1, 8, 256, 0, 2]
+    assert list(v)[:6] == [3, 1, 8, 256, 0, 2]
 
 
 def test_gather_coefficients_keep_their_digits():
@@ -367,3 +367,66 @@ def test_ring_of_identical_units_gets_a_periodic_column_form():
         return np.stack([x[..., (i + 1) % 20] * (1.0 + 0.1 * i) - x[..., i] ** 2 + p[0] for i in range(20)], axis=-1)
     m2 = codegen.module_for(irregular, 20, 1, col_variant=lambda ne, gh: (4, 1, 5, 1), compile=False)
     assert m2["col"] is None
+
+
+# ---- dense constant linear part (codegen.linear_split) and the switch-free flat form --------------------------------
+def _coupled20():
+    C = np.random.RandomState(0).randn(20, 20) / np.sqrt(20.0)
+
+    def coupled(t, x, p):
+        return x @ C.T - p[1] * x ** 3 + p[0]
+    return coupled, C
+
+
+def test_linear_split_takes_the_dense_constant_part():
+    f, C = _coupled20()
+    ex, sy = codegen.trace(f, 20, 2)
+    A0, rest = codegen.linear_split(ex, sy, 20)
+    assert np.array_equal(A0, C)
+    assert all(not r.has(sy["x"][(i + 1) % 20]) for i, r in enumerate(rest))     # what is left is local
+    # Lorenz-96: one constant linear entry per row (-x_i) -- not worth a matrix product; narrow states never are
+    ex, sy = codegen.trace(_l96_plain, 20, 1)
+    assert codegen.linear_split(ex, sy, 20) is None
+    ex, sy = codegen.trace(lambda t, x, p: x @ np.ones((8, 8)) * 0.5 + p[0], 8, 1)
+    assert codegen.linear_split(ex, sy, 8) is None
+    # a coefficient that depends on a parameter stays with the element-wise code
+    ex, sy = codegen.trace(lambda t, x, p: p[0] * (x @ C.T), 20, 1)
+    assert codegen.linear_split(ex, sy, 20) is None
+
+
+@pytest.mark.parametrize("disc", ["trapezoid", "SimpsonHermite", "euler", "forwardmap"])
+def test_linear_module_matches_complex_step(disc):
+    """the struct of a split model describes the rest only (translation-invariant here: no switch) and carries the
+    tables of A0; the emulator adds the linear part with plain loops where the device uses the matrix cores"""
+    f, C = _coupled20()
+    D, NP, N = 20, 2, 33
+    m = codegen.module_for(f, D, NP, compile=False)
+    assert m["lin"] is not None and "LINEAR = true" in m["text"] and "switch (i)" not in m["text"] and "va_lin_A0T" in m["text"]
+    rng = np.random.RandomState(0)
+    Y = rng.randn(N, 6); Lidx = [0, 3, 5, 9, 12, 17]
+    P = np.array([1.5, 0.3])
+    XP = np.append(rng.randn(N * D), P)
+    fun = lambda z: va_oracle.numpy_action_generic(f, z, D, N, Y, Lidx, 0.02, 2.0, 0.7, NP, [0, 1], P, disc)
+    g0 = va_oracle.complex_step_grad(fun, XP)
+    desc, keep = _capi.make_desc(1, D, N, Y, Lidx, 0.02, 2.0, 0.7, P[None, :], [0, 1], disc=disc, rhs=1000)
+    A, me, fe, g = emul.action_grad(desc, 8, XP[None, :], 1.0, user_header=m["header"])
+    assert abs(A[0] - fun(XP)[0]) <= 1e-12 * abs(A[0])
+    assert np.abs(g[0] - g0).max() <= 1e-10 * np.abs(g0).max()
+
+
+def test_translation_invariant_models_get_a_switch_free_flat_form():
+    """the flat kernel's struct of a stencil: one body with cyclic index arithmetic (a per-component switch diverges
+    64 ways in a wave); checked through the emulator against the built-in Lorenz-96 of the oracle"""
+    D, N = 20, 31
+    m = codegen.module_for(_l96_plain, D, 1, compile=False)
+    assert "switch (i)" not in m["text"] and "x[w(i - 2)]" in m["text"]
+    rng = np.random.RandomState(1)
+    Y = rng.randn(N, 4); Lidx = [0, 5, 11, 19]
+    XP = np.append(3.0 * rng.randn(N * D), 8.1)
+    pb = va_oracle.Problem(D, N, Y, Lidx, 0.025, 4.0, 0.3, np.array([8.1]), [0], disc="trapezoid")
+    A0, me0, fe0, g0 = pb.action_grad(XP, 1.0)
+    desc, keep = _capi.make_desc(1, D, N, Y, Lidx, 0.025, 4.0, 0.3, np.array([[8.1]]), [0], disc="trapezoid", rhs=1000)
+    A, me, fe, g = emul.action_grad(desc, 8, XP[None, :], 1.0, user_header=m["header"])
+    assert abs(A[0] - A0) <= 1e-12 * abs(A0) and np.abs(g[0] - g0).max() <= 1e-10 * np.abs(g0).max()
+    # a model that is not translation-invariant keeps the switch
+    assert "switch (i)" in codegen.module_for(nakl, 4, 18, nstim=1, stim_ndim=1, compile=False)["text"]

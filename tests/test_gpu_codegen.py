@@ -437,3 +437,70 @@ def test_ring_of_units_runs_the_column_kernel_at_c3_shape():
     g0 = va_oracle.complex_step_grad(fun, XP[3])
     assert np.abs(g[3] - g0).max() <= 1e-10 * np.abs(g0).max()
     print("D = 20, N = 1000, 64 seeds, us per complete evaluation:", {k: round(v, 2) for k, v in us.items()})
+
+
+# ---- dense constant linear part on the matrix cores (codegen.linear_split, va_eval_flat.h lin_gemm) -----------------
+def _coupled(D, seed=0):
+    """dense linear coupling (a fixed D x D matrix) + local cubic damping + a drive: neither a stencil nor small"""
+    C = np.random.RandomState(seed).randn(D, D) / np.sqrt(D)
+
+    def coupled(t, x, p):
+        return x @ C.T - p[1] * x ** 3 + p[0]
+    return coupled, C
+
+
+@pytest.mark.parametrize("D,N", [(20, 61), (48, 40), (50, 33), (200, 12)])
+def test_dense_linear_part_matches_complex_step(D, N):
+    """f = C x + rest(x, p): the generator splits C off, the flat kernel forms X C^T and S C with
+    v_mfma_f64_16x16x4_f64 (BASELINE north_star: MFMA for a dense D x D linear map) and the element-wise code keeps the
+    rest; A to 1e-12 and the gradient to 1e-10 of the oracle's generic NumPy action with complex-step derivatives,
+    all four discretisations, widths that are / are not multiples of 16"""
+    f, C = _coupled(D, D)
+    m = codegen.module_for(f, D, 2)
+    assert m["lin"] is not None and np.array_equal(m["lin"], C) and "LINEAR = true" in m["text"]
+    rid = _capi.load_rhs_module(m["so"])
+    rng = np.random.RandomState(N)
+    B = 3
+    Lidx = sorted(rng.choice(D, max(2, D // 4), replace=False).tolist())
+    Y = rng.randn(N, len(Lidx))
+    P = np.array([1.5, 0.3])
+    XP = np.concatenate([rng.randn(B, N * D), np.tile(P, (B, 1))], axis=1)
+    for disc in (("trapezoid", "SimpsonHermite", "euler", "forwardmap") if D < 200 else ("trapezoid",)):
+        Nd = N + (disc == "SimpsonHermite" and N % 2 == 0)
+        Yd = Y if Nd == N else np.vstack([Y, Y[-1:]])
+        XPd = XP if Nd == N else np.concatenate([rng.randn(B, Nd * D), np.tile(P, (B, 1))], axis=1)
+        with _capi.Problem(B, D, Nd, Yd, Lidx, 0.02, 2.0, 0.7, np.tile(P, (B, 1)), [0, 1], disc=disc, rhs=rid) as pr:
+            assert pr.info()["eval_kernel"] == 1
+            A, me, fe, g = pr.action_grad(XPd, 3.0)
+        fun = lambda z: va_oracle.numpy_action_generic(f, z, D, Nd, Yd, Lidx, 0.02, 2.0, 0.7 * 3.0, 2, [0, 1], P, disc)
+        for b in range(B):
+            A0, me0, fe0 = fun(XPd[b])
+            assert abs(A[b] - A0) <= 1e-12 * abs(A0) and abs(me[b] - me0) <= 1e-12 * abs(A0), (D, disc, b)
+        g0 = va_oracle.complex_step_grad(fun, XPd[1])
+        assert np.abs(g[1] - g0).max() <= 1e-10 * np.abs(g0).max(), (D, disc)
+
+
+def test_dense_linear_part_at_c3_shape_timed():
+    """D = 20, N = 1000, 64 seeds: the split module against the same model with the linear part left in the
+    element-wise code (a 20-term switch per column) -- same values, time per evaluation recorded"""
+    from varanneal_amd import twin
+    D, N, B = 20, 1000, 64
+    f, C = _coupled(D, 1)
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    rng = np.random.RandomState(2)
+    P = np.array([1.5, 0.3])
+    XP = np.concatenate([rng.randn(B, N * D), np.tile(P, (B, 1))], axis=1)
+    out, us = {}, {}
+    for key, lin in (("matrix cores", True), ("element-wise", False)):
+        m = codegen.module_for(f, D, 2, linear=lin)
+        assert (m["lin"] is not None) == lin
+        with _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 0.3, np.tile(P, (B, 1)), [0, 1], disc="trapezoid",
+                           rhs=_capi.load_rhs_module(m["so"])) as pr:
+            out[key] = pr.action_grad(XP, 2.0)
+            pr.eval_timed(2.0, 20)
+            us[key] = min(pr.eval_timed(2.0, 200) for _ in range(3)) * 5
+    (A, me, fe, g), (Ae, mee, fee, ge) = out["matrix cores"], out["element-wise"]
+    assert np.all(np.abs(A - Ae) <= 1e-12 * np.abs(Ae)) and np.abs(g - ge).max() <= 1e-11 * np.abs(ge).max()
+    A0 = va_oracle.numpy_action_generic(f, XP[5], D, N, Y, Lidx, twin.DT, 4.0, 0.3 * 2.0, 2, [0, 1], P, "trapezoid")[0]
+    assert abs(A[5] - A0) <= 1e-12 * abs(A0)
+    print("dense coupling D = 20, N = 1000, 64 seeds, us per complete evaluation:", {k: round(v, 2) for k, v in us.items()})

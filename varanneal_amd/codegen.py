@@ -149,17 +149,9 @@ def _emit_case(pr, expr, ret):
     return " ".join(lines)
 
 
-def generate_header(exprs, syms, D, NP, nstim, name="user", col=None, ghost=None):
+def _switch_flat(out, exprs, syms, D, NP, pr, sv):
+    """f, J^T s and (df/dp)^T s of the flat kernel's struct with one case per state component"""
     sp = _sympy()
-    pr = _printer()
-    sv = sp.symbols("sv0:%d" % D, real=True)
-    out = []
-    out.append("// generated by varanneal_amd.codegen from the model function %r -- do not edit" % name)
-    out.append("// D=%d NP=%d NSTIM=%d" % (D, NP, nstim))
-    out.append("#pragma once")
-    out.append("namespace va {")
-    out.append("struct RhsUser {")
-    out.append("    static constexpr int NP = %d, D = %d, NSTIM = %d;" % (NP, D, nstim))
     # f
     out.append("    static VA_HD double f(const double *x, int i, int, const double *p, double t, const double *st)")
     out.append("    {")
@@ -197,6 +189,88 @@ def generate_header(exprs, syms, D, NP, nstim, name="user", col=None, ghost=None
     out.append("        default: break;")
     out.append("        }")
     out.append("    }")
+
+
+def _uniform_flat(exprs, syms, D, NP, pr0):
+    """the same three functions for a TRANSLATION-INVARIANT model (every f_i is f_0 shifted cyclically) without a
+    switch: one body, neighbours by cyclic index arithmetic.  A per-component switch diverges 64 ways in a wave of
+    a wide state (D = 200: 22 ms per evaluation against 0.35 ms, tools/lin_wide.py).  None for any other model."""
+    sp = _sympy()
+    xs, ps = list(syms["x"]), list(syms["p"])
+    if not _translation_invariant(exprs, xs, D):
+        return None
+    rel = lambda j: ((j + D // 2) % D) - D // 2
+    f0 = exprs[0]
+    used = sorted(rel(j) for j in range(D) if f0.has(xs[j]))
+    base = pr0.__class__
+
+    def printer(var, shift):
+        class P(base):
+            def _print_Symbol(self, sym):
+                if sym in xs:
+                    k = rel(xs.index(sym)) - shift
+                    return "x[%s]" % var if k == 0 else "x[w(%s %s %d)]" % (var, "+" if k > 0 else "-", abs(k))
+                return base._print_Symbol(self, sym)
+        return P()
+    out = ["    // translation-invariant: one body for every component, neighbours at cyclic offsets %s" % used,
+           "    static VA_HD int w(int k) { return k < 0 ? k + D : (k >= D ? k - D : k); }",
+           "    static VA_HD double f(const double *x, int i, int, const double *p, double t, const double *st)",
+           "    {",
+           "        (void)x; (void)i; (void)p; (void)t; (void)st;",
+           "        " + _emit_case(printer("i", 0), f0, "return %s;"),
+           "    }",
+           "    static VA_HD double vjp(const double *x, const double *s, int j, int, const double *p, double t, const double *st)",
+           "    {",
+           "        (void)x; (void)s; (void)j; (void)p; (void)t; (void)st; double r = 0.0;"]
+    for o in used:
+        dk = sp.diff(f0, xs[o % D])
+        if dk == 0:
+            continue
+        # row i = j - o holds the residual whose f reads x_j at offset o; its x_k sits at column j + (k - o)
+        sname = "s[j]" if o == 0 else "s[w(j %s %d)]" % ("-" if o > 0 else "+", abs(o))
+        out.append("        { %s }" % _emit_case(printer("j", o), sp.Symbol("SADJ") * dk, "r += %s;").replace("SADJ", sname))
+    out += ["        return r;", "    }",
+            "    static VA_HD void pgrad(const double *x, const double *s, int i, int, const double *p, double t, const double *st, double *acc)",
+            "    {",
+            "        (void)x; (void)s; (void)i; (void)p; (void)t; (void)st; (void)acc;"]
+    for k in range(NP):
+        dk = sp.diff(f0, ps[k])
+        if dk != 0:
+            out.append("        { %s }" % _emit_case(printer("i", 0), sp.Symbol("SADJ") * dk, "acc[%d] += %%s;" % k).replace("SADJ", "s[i]"))
+    out.append("    }")
+    return out
+
+
+def generate_header(exprs, syms, D, NP, nstim, name="user", col=None, ghost=None, lin=None):
+    """lin = (A0, rest) from linear_split: the struct then describes `rest` and carries the tables of A0"""
+    sp = _sympy()
+    pr = _printer()
+    if lin is not None:
+        exprs = lin[1]
+    sv = sp.symbols("sv0:%d" % D, real=True)
+    out = []
+    out.append("// generated by varanneal_amd.codegen from the model function %r -- do not edit" % name)
+    out.append("// D=%d NP=%d NSTIM=%d" % (D, NP, nstim))
+    out.append("#pragma once")
+    out.append("namespace va {")
+    if lin is not None:
+        DP, tables = _lin_tables(lin[0], D)
+        out.append("// dense constant linear part A0 (%d non-zero entries of %d) and its transpose, padded to %d x %d"
+                   % (int(np.count_nonzero(lin[0])), D * D, DP, DP))
+        out.append(tables)
+    out.append("struct RhsUser {")
+    out.append("    static constexpr int NP = %d, D = %d, NSTIM = %d;" % (NP, D, nstim))
+    if lin is not None:
+        out.append("    // f = A0 x + rest: f / vjp / pgrad below are the REST; A0 runs on the matrix cores (va_eval_flat.h lin_gemm)")
+        out.append("    static constexpr bool LINEAR = true;")
+        out.append("    static constexpr int LIN_DP = %d;" % DP)
+        out.append("    static VA_HD const double *lin_A0() { return va_lin_A0; }")
+        out.append("    static VA_HD const double *lin_A0T() { return va_lin_A0T; }")
+    uni = _uniform_flat(exprs, syms, D, NP, pr) if D >= 8 else None
+    if uni is not None:
+        out += uni
+    else:
+        _switch_flat(out, exprs, syms, D, NP, pr, sv)
     out.append("};")
     if col is not None:
         out.append("// the same model in column form (codegen.column_form): %s"
@@ -210,6 +284,48 @@ def generate_header(exprs, syms, D, NP, nstim, name="user", col=None, ghost=None
         out.append(ghost["text"])
     out.append("}  // namespace va")
     return "\n".join(out) + "\n"
+
+
+def linear_split(exprs, syms, D, min_row_fill=8, max_D=512):
+    """f = A0 x + rest: the dense CONSTANT linear part of a model (coefficients free of x, p, t and the stimulus),
+    which the flat kernel evaluates -- and transposes for the adjoint -- on the matrix cores (csrc/va_eval_flat.h
+    lin_gemm; BASELINE north_star: "MFMA only if the user RHS is a dense D x D linear map"), and the rest, which
+    stays with the generated element-wise code.  Returns (A0 [D, D] float array, rest expressions), or None when the
+    linear part is too sparse to be worth a matrix product (fewer than `min_row_fill` entries per row on average) or
+    the state is too narrow (D < 16: one MFMA block) or too wide for the staged rows (D > max_D)."""
+    sp = _sympy()
+    if D < 16 or D > max_D:
+        return None
+    xidx = dict((x, j) for j, x in enumerate(syms["x"]))
+    A0 = np.zeros((D, D))
+    rest = []
+    for i, e in enumerate(exprs):
+        keep = []
+        for term in sp.Add.make_args(sp.expand(e)):
+            c, r = term.as_coeff_Mul()
+            if r in xidx and c.is_number:
+                A0[i, xidx[r]] += float(c)
+            else:
+                keep.append(term)
+        rest.append(sp.Add(*keep) if keep else sp.Integer(0))
+    if np.count_nonzero(A0) < min_row_fill * D:
+        return None
+    return A0, rest
+
+
+def _lin_tables(A0, D):
+    """the two zero-padded row-major tables the kernel reads (DP = D rounded up to 16)"""
+    DP = ((D + 15) // 16) * 16
+    pad = np.zeros((DP, DP))
+    pad[:D, :D] = A0
+
+    def table(name, M):
+        rows = [", ".join(repr(float(v)) if v != 0.0 else "0" for v in row) for row in M]
+        return "VA_LIN_TABLE double %s[%d] = {\n%s\n};" % (name, DP * DP, ",\n".join(rows))
+    text = "\n".join([
+        "#ifdef __HIPCC__", "#define VA_LIN_TABLE static __device__ const", "#else", "#define VA_LIN_TABLE static const", "#endif",
+        table("va_lin_A0", pad), table("va_lin_A0T", pad.T)])
+    return DP, text
 
 
 def _translation_invariant(exprs, xs, D):
@@ -550,11 +666,12 @@ def build_module(header_text, verbose=False, col_variant=None, compile=True):
     return so, hdr
 
 
-def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False, p_rows=False, col_variant=None, compile=True):
+def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False, p_rows=False, col_variant=None, compile=True, linear=True):
     """trace + check + generate + build.  Returns dict(so=, header=, exprs=, col=).
     col_variant: None, or a callable (NE, GHOST[, reach]) -> (eval kernel 3 | 4 | 5, disc, K, w) or None (as
     _capi.eval_plan returns it) naming the instantiation of a column-run kernel to compile for a model that has
-    a column form (NE products per element; 0 = none) and / or a ghosted form (GHOST columns; 0 = none)."""
+    a column form (NE products per element; 0 = none) and / or a ghosted form (GHOST columns; 0 = none).
+    linear=False keeps a dense constant linear part in the element-wise code (linear_split; for comparisons)."""
     if NP > MAX_NP:
         raise NotImplementedError("right-hand sides with more than %d parameters" % MAX_NP)
     exprs, syms = trace(f, D, NP, nstim, stim_ndim, p_rows)
@@ -582,9 +699,12 @@ def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False, p_rows=False, col_
             col = None
         if variant is None or variant[0] != 3:
             ghost = None
-    text = generate_header(exprs, syms, D, NP, nstim, getattr(f, "__name__", "f"), col=col, ghost=ghost)
+    # no column-run kernel for this model: a dense constant linear part goes to the matrix cores
+    lin = linear_split(exprs, syms, D) if (linear and col is None and ghost is None and not p_rows) else None
+    text = generate_header(exprs, syms, D, NP, nstim, getattr(f, "__name__", "f"), col=col, ghost=ghost, lin=lin)
     so, hdr = build_module(text, verbose, variant, compile)
-    return dict(so=so, header=hdr, exprs=exprs, text=text, col=col, ghost=ghost, col_variant=variant)
+    return dict(so=so, header=hdr, exprs=exprs, text=text, col=col, ghost=ghost, col_variant=variant,
+                lin=(None if lin is None else lin[0]))
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -50,7 +50,7 @@ int fail(int code, const char *fmt, ...)
 struct UserRhs {
     // the ONE column-run instantiation the module carries besides its flat kernel, if any (va_user_rhs.hip):
     // (eval kernel 0 / 3 / 4 / 5, DISC, K, W_SCALAR [4] or threads [3], NE [4, 5], GHOST [3])
-    int var[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // (+ the column form's reaches xl, xr, gl, gr [5])
+    int var[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (+ the column form's reaches xl, xr, gl, gr [5]; [10]: the flat kernel carries a dense linear part)
     void (*launch_var)(const Dev *, void *) = nullptr;
     int (*prepare_var)(const Dev *) = nullptr;
     std::string path;
@@ -310,12 +310,20 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
         tmin = dm.RY;
     } else {
         dm.RY = 0; dm.NT = EVAL_THREADS; dm.maxr = 0;
-        // LDS: 3 staged arrays of (T+halo) rows
+        // LDS: 3 staged arrays of (T+halo) rows (4 when the right-hand side has a dense linear part: J^T s of it)
         // ~24 KiB per workgroup (six per CU) measured best (D = 100: T = 8, 349 us against 403 us at
         // T = 18); wider states take 48 KiB, then whatever still gives two owned rows
-        tmax = (int)((24 * 1024) / (3 * sizeof(double) * D)) - HLR;
-        if (tmax < 2) tmax = (int)((48 * 1024) / (3 * sizeof(double) * D)) - HLR;
-        if (tmax < 2) tmax = (int)((150 * 1024) / (3 * sizeof(double) * D)) - HLR;
+        const size_t narr = 3 + (dm.lin ? 1 : 0);
+        auto rows_in = [&](size_t kib) { return (int)((kib * 1024) / (narr * sizeof(double) * D)) - HLR; };
+        tmax = rows_in(24);
+        if (dm.lin) {
+            // the matrix cores take 16 staged rows at a time and every workgroup reads the whole table of the linear
+            // part per product: the smallest budget that stages >= 16 rows, up to 80 KiB (two workgroups per CU)
+            for (size_t kib : {24, 48, 80}) { tmax = rows_in(kib); if (tmax + HLR >= 16) break; }
+        }
+        if (tmax < 2) tmax = rows_in(48);
+        if (tmax < 2) tmax = rows_in(150);
+        if (dm.lin && d->tile_rows > tmax && d->tile_rows <= rows_in(150)) tmax = d->tile_rows;     // (an explicit run length may take the CU's whole LDS)
         tmin = (EVAL_THREADS + D - 1) / D;               // >= one element per lane
     }
     if (tmax < 2) tmax = 2;
@@ -570,7 +578,7 @@ int va_rhs_load_module(const char *path, int32_t *rhs_id)
     }
     if (v[0] < 0 || v[0] > RHS_MAX_NP) { dlclose(u.dl); return fail(VA_EUNSUPPORTED, "%s: NP=%d > %d", path, v[0], RHS_MAX_NP); }
     u.NP = v[0]; u.D = v[1]; u.NSTIM = v[2];
-    if (info_fn vinfo = (info_fn)dlsym(u.dl, "va_user_variant_info")) {        // (writes 10 ints)
+    if (info_fn vinfo = (info_fn)dlsym(u.dl, "va_user_variant_info")) {        // (writes 12 ints)
         vinfo(u.var);
         u.launch_var = (void (*)(const Dev *, void *))dlsym(u.dl, "va_user_launch_variant");
         u.prepare_var = (int (*)(const Dev *))dlsym(u.dl, "va_user_prepare_variant");
@@ -692,6 +700,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
         // the module holds ONE instantiation of a column-run kernel (va_eval_plan named it when the module
         // was generated); a problem that calls for any other geometry runs the module's flat kernel
         const int *v = user->var;
+        dm.lin = v[10] ? 1 : 0;
         pick_eval_geometry(d, dm, dv.g4, (v[0] == 4 || v[0] == 5) ? v[4] : 0, v[0] == 3 ? v[5] : 0, v[0] == 5 ? v + 6 : nullptr, &dv.g5, &ystrip_h);
         const bool ws = d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1;
         const bool fits = dm.emode == v[0] && v[1] == d->disc &&

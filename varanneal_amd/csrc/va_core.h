@@ -63,6 +63,7 @@ struct Dims {
     // L-BFGS kernels (one flat run), and the flat tile kernel uses NPt / NPe.  Static: tdp = 0,
     // NPt = NP, NPe = NPest.
     int tdp, NPt, NPe;
+    int lin;                   // 1: the right-hand side carries a dense constant linear part (RHS::LINEAR; va_eval_lin.h): one more staged array, J^T s of that part
     int bounded;               // bit 0: box bounds on the path vector (ProblemPtrs::lo / hi); bit 1: every variable has both bounds (L-BFGS-B's `boxed`)
     double dt, cme, cfe, rm, rf0;
 };
@@ -150,7 +151,15 @@ template <int DISC> struct Halo {
     static constexpr int HR = 1;                           // rows needed after it
 };
 
+// A right-hand side f = A0 x + rest(x, p, t) whose dense CONSTANT linear part A0 is split off by the generator
+// (codegen.linear_split): RHS::LINEAR is defined, RHS::f / vjp / pgrad describe the rest only, and the tables
+// RHS::lin_A0() = A0 and RHS::lin_A0T() = A0^T (row-major, LIN_DP x LIN_DP, zero-padded to a multiple of 16) carry
+// the linear part -- on the device through the matrix cores (va_eval_lin.h), here with plain loops for the emulator.
+template <class RHS, class = void> struct rhs_linear { static constexpr bool value = false; };
+template <class RHS> struct rhs_linear<RHS, decltype((void)RHS::LINEAR)> { static constexpr bool value = true; };
+
 struct TileCtx {
+    double *js = nullptr;        // [T*D] (LDS): J^T s of the dense linear part, device only
     int n0, R, use_d;            // first owned row, rows staged, trial point x + stp*d ?
     double stp, c;               // c = 2 * rf0_scale * cfe   (rf0 weight applied per element)
     double *xs, *fs, *qs;        // staged rows [R*D] (LDS); fs is re-used for s
@@ -241,10 +250,19 @@ VA_HD void tile_f(const Dims &dm, TileCtx &c, int tid, int nt)
     const int dlr = nt / D, di = nt - dlr * D;
     for (int e = tid; e < tot; e += nt) {
         int row = c.n0 - Halo<DISC>::HL + lr;
-        c.fs[e] = (row >= 0 && row < dm.N)
-                      ? RHS::f(c.xs + lr * D, i, D, dm.tdp ? c.ps + lr * dm.NPt : c.p,
-                               c.tmodel ? c.tmodel[row] : 0.0, c.stim + (size_t)row * c.nstim)
-                      : 0.0;
+        double fv = (row >= 0 && row < dm.N)
+                        ? RHS::f(c.xs + lr * D, i, D, dm.tdp ? c.ps + lr * dm.NPt : c.p,
+                                 c.tmodel ? c.tmodel[row] : 0.0, c.stim + (size_t)row * c.nstim)
+                        : 0.0;
+        if constexpr (rhs_linear<RHS>::value) {
+#ifdef __HIP_DEVICE_COMPILE__
+            fv += c.fs[e];                               // X A0^T, left there by lin_gemm (rows that do not exist are rows of zeros)
+#else
+            const double *A0 = RHS::lin_A0();
+            for (int j = 0; j < D; ++j) fv += A0[i * RHS::LIN_DP + j] * c.xs[lr * D + j];
+#endif
+        }
+        c.fs[e] = fv;
         lr += dlr; i += di;
         if (i >= D) { i -= D; ++lr; }
     }
@@ -392,6 +410,14 @@ VA_HD void tile_g(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &
             const double *st = c.stim + (size_t)m * c.nstim;
             const double *pr = dm.tdp ? c.ps + lr * dm.NPt : c.p;
             double g = direct + RHS::vjp(xr, sr, j, D, pr, tm, st);
+            if constexpr (rhs_linear<RHS>::value) {
+#ifdef __HIP_DEVICE_COMPILE__
+                g += c.js[lt * D + j];                   // S A0 (lin_gemm)
+#else
+                const double *A0 = RHS::lin_A0();
+                for (int i = 0; i < D; ++i) g += sr[i] * A0[i * RHS::LIN_DP + j];
+#endif
+            }
             if (!dm.tdp) RHS::pgrad(xr, sr, j, D, pr, tm, st, acc.v + EP_GP);
             const int l = pp.lmap[j];
             if (l >= 0 && (m % dm.nskip) == 0) {

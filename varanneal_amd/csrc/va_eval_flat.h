@@ -87,6 +87,63 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwork)
 namespace va {
 
 // ------------------------------------------------------------------ K1: eval
+// ------------------------------------------------------------------ dense linear part on the matrix cores
+// dst[r][c] = sum_k src[r][k] Bt[k][c] for r < rows, c < D (row pitch D in LDS); Bt is a zero-padded DP x DP table in
+// global memory (DP a multiple of 16).  v_mfma_f64_16x16x4_f64: lane l feeds A[row = l & 15][k = l >> 4] and
+// B[k = l >> 4][col = l & 15]; result register i of lane l is C[row = (l >> 4) + 4 i][col = l & 15].  A wave takes
+// 16 x 32 output blocks (two accumulators share the A fragment); the B fragments are 128-byte runs of the table
+// (L1 / L2 resident: it is the same for every workgroup).
+__device__ __forceinline__ void lin_gemm(const double *src, int rows, double *dst, int D, const double *Bt, int DP, int tid, int nt)
+{
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6, lo = lane & 15, hi = lane >> 4;
+    const int nRB = (rows + 15) >> 4, nCB2 = (DP + 31) >> 5;
+    for (int blk = wave; blk < nRB * nCB2; blk += nw) {
+        const int rb = blk / nCB2, cb = blk - rb * nCB2;
+        const int row = rb * 16 + lo, c0 = cb * 32 + lo, c1 = c0 + 16;
+        const bool two = cb * 32 + 16 < DP;                           // (wave-uniform)
+        const double *ar = src + row * D;
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        // K in chunks of KU steps of 4: the fragments of the next chunk (LDS reads of the rows, 128-byte runs of the
+        // table from L2) are requested before the 2 KU products of this one are issued
+        constexpr int KU = 4;
+        const double *bp = Bt + hi * DP + c0;
+        double a[KU], b0[KU], b1[KU], an[KU], b0n[KU], b1n[KU];
+        auto fetch = [&](int k0, double *a_, double *b0_, double *b1_) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int ks = k0 + 4 * u;                            // (wave-uniform)
+                a_[u] = 0.0; b0_[u] = 0.0; b1_[u] = 0.0;
+                if (ks < D) {
+                    a_[u] = (row < rows && ks + hi < D) ? ar[ks + hi] : 0.0;     // (the table is zero beyond D, the staged rows are not)
+                    b0_[u] = bp[ks * DP];
+                    if (two) b1_[u] = bp[ks * DP + 16];
+                }
+            }
+        };
+        fetch(0, a, b0, b1);
+        for (int k0 = 0; k0 < D; k0 += 4 * KU) {
+            if (k0 + 4 * KU < D) fetch(k0 + 4 * KU, an, b0n, b1n);
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+                if (k0 + 4 * u < D) {
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b0[u], acc0, 0, 0, 0);
+                    if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b1[u], acc1, 0, 0, 0);
+                }
+#pragma unroll
+            for (int u = 0; u < KU; ++u) { a[u] = an[u]; b0[u] = b0n[u]; b1[u] = b1n[u]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rb * 16 + hi + 4 * i;
+            if (r < rows) {
+                if (c0 < D) dst[r * D + c0] = acc0[i];
+                if (two && c1 < D) dst[r * D + c1] = acc1[i];
+            }
+        }
+    }
+}
+
 template <class RHS, int DISC>
 __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
 {
@@ -107,7 +164,9 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
     c.n0 = tile * dm.T; c.R = R; c.use_d = (phase == PH_LS);
     c.stp = st.stp; c.c = 2.0 * st.rf_scale * dm.cfe;
     c.xs = smem; c.fs = smem + RD; c.qs = smem + 2 * RD;
-    double *red = smem + 3 * RD;
+    constexpr bool LIN = rhs_linear<RHS>::value;
+    if constexpr (LIN) c.js = smem + 3 * RD;
+    double *red = smem + 3 * RD + (LIN ? dm.T * dm.D : 0);
     c.ps = red + (EVAL_THREADS / 64) * EP_N;     // [R * NPt], time-dependent parameters only
     c.xg = dv.x + (size_t)b * dm.ld; c.dg = dv.d + (size_t)b * dm.ld;
     c.gtg = dv.gt + (size_t)b * dm.ld;
@@ -120,6 +179,10 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
     tile_load<DISC>(dm, dv.pp, c, tid, nt);
     if (dm.tdp) tile_load_p<DISC>(dm, dv.pp, b, c, tid, nt);
     __syncthreads();
+    if constexpr (LIN) {                           // f = X A0^T (matrix cores) + rest (tile_f adds it)
+        lin_gemm(c.xs, R, c.fs, dm.D, RHS::lin_A0T(), RHS::LIN_DP, tid, nt);
+        __syncthreads();
+    }
     tile_f<RHS, DISC>(dm, c, tid, nt);
     __syncthreads();
     tile_q<DISC>(dm, dv.pp, c, acc, tid, nt);
@@ -131,6 +194,10 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
     }
     tile_s<DISC>(dm, c, tid, nt);
     __syncthreads();
+    if constexpr (LIN) {                           // J^T s of the linear part: S A0 for the owned rows
+        lin_gemm(c.fs + HL * dm.D, dm.T, c.js, dm.D, RHS::lin_A0(), RHS::LIN_DP, tid, nt);
+        __syncthreads();
+    }
     tile_g<RHS, DISC>(dm, dv.pp, c, acc, tid, nt);
     if (dm.tdp) tile_gp<RHS, DISC>(dm, dv.pp, c, acc, tid, nt);
 
@@ -158,7 +225,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
 inline size_t eval_flat_lds_bytes(const Dims &dm)
 {
     const int HL = dm.disc == DISC_SH ? 2 : 1;
-    return sizeof(double) * ((size_t)3 * (dm.T + HL + 1) * dm.D + (EVAL_THREADS / 64) * EP_N
+    return sizeof(double) * ((size_t)3 * (dm.T + HL + 1) * dm.D + (dm.lin ? (size_t)dm.T * dm.D : 0) + (EVAL_THREADS / 64) * EP_N
                              + (dm.tdp ? (size_t)(dm.T + HL + 1) * dm.NPt : 0));
 }
 inline int eval_flat_grid(const Dims &dm) { return ((dm.B * dm.ntiles + 7) / 8) * 8; }

@@ -43,7 +43,7 @@ int va_user_prepare_eval(const va::Dev *dv)
 //           system) on the wave-private kernel k_eval4; W = 1 for scalar weights
 //   EK = 5: a stencil's column form on the streaming kernel k_eval5 (wide even states, autonomous, scalar weights)
 //   EK = 3: a stencil's ghosted form (struct RhsUserG) on the workgroup kernel k_eval3; W = threads per workgroup
-// (eval kernel or 0, DISC, K, W, products per element [4, 5], ghost columns [3], reaches xl, xr, gl, gr [5])
+// (eval kernel or 0, DISC, K, W, products per element [4, 5], ghost columns [3], reaches xl, xr, gl, gr [5], -, dense linear part)
 #if defined(VA_USER_EK) && VA_USER_EK == 5 && defined(VA_USER_COL)
 #define VA_USER_VARIANT 5
 #elif defined(VA_USER_EK) && VA_USER_EK == 4 && defined(VA_USER_COL)
@@ -53,7 +53,8 @@ int va_user_prepare_eval(const va::Dev *dv)
 #endif
 void va_user_variant_info(int *out)
 {
-    for (int k = 0; k < 10; ++k) out[k] = 0;
+    for (int k = 0; k < 12; ++k) out[k] = 0;
+    out[10] = va::rhs_linear<va::RhsUser>::value ? 1 : 0;     // the flat kernel stages one more array (va_eval_flat.h lin_gemm)
 #ifdef VA_USER_VARIANT
     out[0] = VA_USER_VARIANT; out[1] = VA_USER_DISC; out[2] = VA_USER_K; out[3] = VA_USER_W;
 #if VA_USER_VARIANT == 5
