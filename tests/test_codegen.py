@@ -326,7 +326,7 @@ def test_wide_stencil_gets_the_streaming_variant():
     assert _capi.eval_plan(64, 200, 5000, "trapezoid", 2, 2, reach=(2, 1, 1, 2), Lidx=Lidx) == (5, 1, 0, 0)
     assert _capi.eval_plan(64, 200, 5001, "SimpsonHermite", 2, 2, reach=(2, 1, 1, 2), Lidx=Lidx) == (5, 2, 0, 0)
     assert _capi.eval_plan(64, 200, 5000, "trapezoid", 2, 2, reach=(2, 1, 1, 2), Lidx=Lidx[:-1])[0] == 3      # odd L
-    assert _capi.eval_plan(64, 200, 5000, "trapezoid", 2, 2, reach=(2, 1, 1, 2), Lidx=Lidx, rf_array=True)[0] == 3
+    assert _capi.eval_plan(64, 200, 5000, "trapezoid", 2, 2, reach=(2, 1, 1, 2), Lidx=Lidx, rf_array=True)[0] == 5      # (per-row weights stream too)
     seen = {}
 
     def cb(ne, gh, reach):

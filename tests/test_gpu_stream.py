@@ -96,7 +96,8 @@ def test_sparse_and_dense_observations(capi):
 
 
 def test_fallback_when_the_streaming_kernel_does_not_apply(capi):
-    """odd L, per-row weights: the handle runs a tile kernel instead (and says so); Simpson-Hermite streams"""
+    """odd L, full weight matrices: the handle runs another kernel instead (and says so); Simpson-Hermite and
+    per-row weights stream"""
     from varanneal_amd import twin
     D, N, B = 200, 41, 1
     Y, Lidx, XP, P = make(D, N, B, 3, L=7)
@@ -106,7 +107,9 @@ def test_fallback_when_the_streaming_kernel_does_not_apply(capi):
     with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="SimpsonHermite", eval_kernel=5) as pb:
         assert pb.info()["eval_kernel"] == 5
     with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, np.full((N - 1, D), 4e-6), P, [0], disc="trapezoid", eval_kernel=5) as pb:
-        assert pb.info()["eval_kernel"] == 3
+        assert pb.info()["eval_kernel"] == 5
+    with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, np.full((N - 1, D, D), 4e-6), P, [0], disc="trapezoid", eval_kernel=5) as pb:
+        assert pb.info()["eval_kernel"] == 1
 
 
 def test_timed_evaluation_is_a_complete_evaluation(capi):
@@ -164,3 +167,55 @@ def test_short_ladder_matches_tile_kernel(capi):
             out[ek] = pb.anneal(XP, rf, OPTS)
     assert np.allclose(out[5]["A"], out[3]["A"], rtol=1e-6, atol=0)
     assert np.allclose(out[5]["pest"], out[3]["pest"], rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("disc", ["trapezoid", "SimpsonHermite", "euler", "forwardmap"])
+def test_weight_arrays_and_sparse_data(capi, disc):
+    """(N-1, D) model-error weights, (N_data, L) measurement weights, data at every nskip-th model time
+    (va_ode.py:138-158, 197-222): the rows' weights travel through the ring with the rows; against the oracle"""
+    import va_oracle
+    from varanneal_amd import twin
+    D, B = 200, 2
+    for N, nskip, rm_arr, rf_arr, tile_rows in ((61, 1, True, True, 0), (121, 1, False, True, 40), (97, 2, False, False, 32),
+                                                (91, 3, True, False, 30), (65, 2, True, True, 64)):
+        rng = np.random.RandomState(N + nskip)
+        L = 30
+        Lidx = np.sort(rng.choice(D, L, replace=False))
+        Nd = (N + nskip - 1) // nskip
+        Y = rng.randn(Nd, L)
+        RM = (0.5 + rng.rand(Nd, L)) if rm_arr else 3.0
+        RF = (0.2 + rng.rand(N - 1, D)) if rf_arr else 0.7
+        XP = np.concatenate([2.0 * rng.randn(B, N * D), 7.0 + rng.rand(B, 1)], axis=1)
+        P = XP[:, -1:].copy()
+        with capi.Problem(B, D, N, Y, list(Lidx), twin.DT, RM, RF, P, [0], disc=disc, eval_kernel=5, tile_rows=tile_rows,
+                          merr_nskip=nskip) as pb:
+            assert pb.info()["eval_kernel"] == 5, (N, nskip)
+            A, me, fe, g = pb.action_grad(XP, 2.5)
+        for b in range(B):
+            opb = va_oracle.Problem(D, N, Y, list(Lidx), twin.DT, RM, RF, P[b], [0], disc=disc, merr_nskip=nskip)
+            Ao, meo, feo, go = opb.action_grad(XP[b], 2.5)
+            assert abs(A[b] - Ao) <= RTOL_A * abs(Ao), (disc, N, nskip, b, A[b], Ao)
+            assert abs(me[b] - meo) <= RTOL_A * max(abs(meo), abs(Ao)) and abs(fe[b] - feo) <= RTOL_A * abs(feo), (disc, N, nskip, b)
+            err = np.abs(g[b] - go)
+            assert err.max() <= RTOL_G * np.abs(go).max(), (disc, N, nskip, b, int(err.argmax()), err.max())
+
+
+def test_weight_arrays_minimisation_follows_the_tile_kernel(capi):
+    """line-search launches with the weight images in the ring: same (nit, nfev) as the tile kernel, same end point"""
+    from varanneal_amd import twin
+    D, N, B = 200, 120, 3
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    rng = np.random.RandomState(4)
+    RF = 4e-6 * (0.5 + rng.rand(N - 1, D))
+    XP = np.empty((B, N * D + 1)); P = np.empty((B, 1))
+    for b in range(B):
+        X0, P0 = twin.initial_guess(N, D, b, Y, Lidx)
+        XP[b, :-1] = X0.ravel(); XP[b, -1] = P0[0]; P[b] = P0
+    o = dict(OPTS, maxiter=25)
+    res = {}
+    for ek in (5, 3):
+        with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, RF, P, [0], disc="trapezoid", eval_kernel=ek, tile_rows=(40 if ek == 5 else 0)) as pb:
+            assert pb.info()["eval_kernel"] == ek
+            res[ek] = pb.minimize_lbfgs(XP, 1.5 ** 6, o)
+    assert np.array_equal(res[5]["nit"], res[3]["nit"]) and np.array_equal(res[5]["nfev"], res[3]["nfev"])
+    assert np.allclose(res[5]["A"], res[3]["A"], rtol=1e-9, atol=0) and np.abs(res[5]["x"] - res[3]["x"]).max() <= 1e-6

@@ -29,4 +29,4 @@ for tr in (0,) + tuple(int(a) for a in sys.argv[4:]):
         us = min(pr.eval_timed(3.0, 10) for _ in range(3)) / 10 * 1e3
     fl = 4.0 * N * D * D * B
     print("D=%d N=%d B=%d tile_rows=%d T=%s: %.1f us per evaluation, %.2f TFLOP/s in the two products (%.3f of 78.6), %.3f of 8 TB/s at 16 B per element"
-          % (D, N, B, tr, info.get("T"), us, fl / us / 1e6, fl / us / 1e6 / 78.6, 16.0 * B * N * D / (us * 1e-6) / 8e12), flush=True)
+          % (D, N, B, tr, info["tile_rows"], us, fl / us / 1e6, fl / us / 1e6 / 78.6, 16.0 * B * N * D / (us * 1e-6) / 8e12), flush=True)

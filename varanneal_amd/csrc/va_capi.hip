@@ -148,9 +148,9 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
     // auto: wave-private column runs for narrow states that fill a wave, workgroup column runs up
     // to 1024 columns, flat mapping beyond
     if (dm.emode == 2) dm.emode = 3;                      // (the row-strided kernel of round 1 is gone)
-    // streaming column strips: wide even states, a column form, scalar weights with
+    // streaming column strips: wide even states, a column form, scalar or per-row weights with
     // data at every model time (what every BASELINE config has); anything else keeps the tile kernels
-    const bool ws5 = d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1 && d->L >= 1;
+    const bool ws5 = d->rm_kind <= 1 && d->rf_kind <= 1 && d->merr_nskip >= 1 && d->L >= 1;     // (full matrices: flat kernel)
     const bool can5 = reach5 && g5 && ystrip && !user_rhs && ne > 0 && ws5 && D > 64 && (!sh || (N & 1)) &&
                       tile5_ok(D, reach5[0], reach5[1], reach5[2], reach5[3]);
     if (dm.emode == 5 && !can5) dm.emode = 0;
@@ -189,6 +189,8 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
         auto fits = [&](int nslot, bool lsr) { return (size_t)g.WPG * tile5_wave_doubles(g, nslot, lsr) * sizeof(double) <= 40 * 1024; };
         g.nslot = fits(4, false) ? 4 : 3;
         g.nslot_ls = fits(4, true) ? 4 : 3;
+        g.warr = (d->rm_kind == 1 || d->rf_kind == 1 || d->merr_nskip > 1) ? 1 : 0;
+        if (g.warr) g.nslot = g.nslot_ls = 3;          // (two more images per slot; only the three-slot instantiations exist)
         g.xdpp = (reach5[2] <= 2 && reach5[3] <= 2) ? 1 : 0;
         if (g.YPMAX <= 32 && !(d->L & 1)) {          // (odd L: data rows alternate between 16-byte phases -- not staged by 16-byte pieces)
             *g5 = g;
@@ -766,9 +768,17 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     if (d->rm_kind < 0 || d->rm_kind > 2) { va_problem_destroy(h); return fail(VA_EINVAL, "rm_kind %d", d->rm_kind); }
     const size_t rm_elems = (size_t)dm.N_data * dm.L * (d->rm_kind == 2 ? dm.L : 1);
     int *lidx_d = nullptr;
-    if (d->rm_kind) TRY(h->alloc(&rm_d, rm_elems));
+    const bool warr5 = dm.emode == 5 && dv.g5.warr;      // k_eval5 streams both weight images: scalar weights are spread out into arrays
+    if (warr5) {
+        // (as Y: one row pair in front and behind; L is even on this path)
+        TRY(h->alloc(&rm_d, rm_elems + 4 * (size_t)dm.L + 16));
+        rm_d += dm.L;
+    } else if (d->rm_kind) TRY(h->alloc(&rm_d, rm_elems));
     if (d->rm_kind == 2) TRY(h->alloc(&lidx_d, dm.L));
-    if (d->rf_kind) TRY(h->alloc(&rf_d, (size_t)(dm.N - 1) * dm.D * (d->rf_kind == 2 ? dm.D : 1)));
+    if (warr5) {
+        TRY(h->alloc(&rf_d, (size_t)(dm.N + 3) * dm.D + 16));
+        rf_d += dm.D;
+    } else if (d->rf_kind) TRY(h->alloc(&rf_d, (size_t)(dm.N - 1) * dm.D * (d->rf_kind == 2 ? dm.D : 1)));
     double *lo_d = nullptr, *hi_d = nullptr;
     std::vector<double> lo_h, hi_h;
     if (dm.bounded) {
@@ -798,6 +808,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     std::vector<double> Ys((size_t)dm.N_data * dm.L), rms;
     for (int n = 0; n < dm.N_data; ++n)
         for (int l = 0; l < dm.L; ++l) Ys[(size_t)n * dm.L + l] = d->Y[(size_t)n * dm.L + perm[l]];
+    if (warr5 && d->rm_kind == 0) rms.assign((size_t)dm.N_data * dm.L, d->rm);
     if (d->rm_kind == 1) {
         rms.resize((size_t)dm.N_data * dm.L);
         for (int n = 0; n < dm.N_data; ++n)
@@ -815,16 +826,18 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     H2D(Y_d, Ys.data(), (size_t)dm.N_data * dm.L, double);
     if (dm.NPe) H2D(pidx_d, d->Pidx, dm.NPe, int);
     H2D(P_d, d->P, B * np_seed, double);
-    if (d->rm_kind) H2D(rm_d, d->rm_kind == 1 ? rms.data() : d->rm_array, rm_elems, double);
+    if (d->rm_kind || warr5) H2D(rm_d, d->rm_kind != 2 ? rms.data() : d->rm_array, rm_elems, double);
     if (d->rm_kind == 2) H2D(lidx_d, d->Lidx, dm.L, int);
-    if (d->rf_kind) H2D(rf_d, d->rf0_array, (size_t)(dm.N - 1) * dm.D * (d->rf_kind == 2 ? dm.D : 1), double);
+    std::vector<double> rf_fill;
+    if (warr5 && d->rf_kind == 0) rf_fill.assign((size_t)(dm.N - 1) * dm.D, d->rf0);
+    if (d->rf_kind || warr5) H2D(rf_d, d->rf_kind ? d->rf0_array : rf_fill.data(), (size_t)(dm.N - 1) * dm.D * (d->rf_kind == 2 ? dm.D : 1), double);
     if (dm.bounded) { H2D(lo_d, lo_h.data(), (size_t)dm.ld, double); H2D(hi_d, hi_h.data(), (size_t)dm.ld, double); }
     dv.pp.lo = lo_d; dv.pp.hi = hi_d;
     if (d->t_model) H2D(t_d, d->t_model, (size_t)dm.N, double);
     if (d->n_stim > 0) H2D(st_d, d->stim, (size_t)dm.N * d->n_stim, double);
-    dv.pp.lmap = lmap_d; dv.pp.Y = Y_d; dv.pp.rf0_arr = d->rf_kind == 1 ? rf_d : nullptr;
+    dv.pp.lmap = lmap_d; dv.pp.Y = Y_d; dv.pp.rf0_arr = (d->rf_kind == 1 || warr5) ? rf_d : nullptr;
     dv.pp.rf0_full = d->rf_kind == 2 ? rf_d : nullptr;
-    dv.pp.rm_arr = d->rm_kind == 1 ? rm_d : nullptr;
+    dv.pp.rm_arr = (d->rm_kind == 1 || warr5) ? rm_d : nullptr;
     dv.pp.rm_full = d->rm_kind == 2 ? rm_d : nullptr; dv.pp.Lidx = lidx_d;
     dv.pp.Pidx = pidx_d; dv.pp.Pfull = P_d;
     dv.pp.tmodel = t_d; dv.pp.stim = st_d; dv.pp.nstim = d->n_stim;

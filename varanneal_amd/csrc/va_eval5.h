@@ -52,7 +52,7 @@ template <class RHS, int U> struct T5Gather {
 template <class RHS> struct T5Gather<RHS, -1> { static __device__ __forceinline__ void run(const double *, double *) {} };
 
 // XDPP: the scatter products change lanes through DPP shifts instead of the wave's LDS arrays
-template <class RHS, int DISC, int DC, int NSLOT, bool LSRUN, bool XDPP>
+template <class RHS, int DISC, int DC, int NSLOT, bool LSRUN, bool XDPP, bool WARR>
 __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
 {
     static_assert(!RHS::USES_T && RHS::NSTIM == 0, "autonomous right-hand sides only");
@@ -85,11 +85,13 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int strip = grp * WPG + wave;
     const bool wave_on = strip < gc.NS;                       // (the last workgroup of a row may have idle waves)
-    const int WAVE = tile5_wave_doubles(dv.g5, NSLOT, LSRUN);
+    const int WAVE = tile5_wave_doubles(dv.g5, NSLOT, LSRUN, WARR);
     double *xring = smem + wave * WAVE;
     double *dring = xring + NSLOT * SLOTX;
     double *yring = dring + (LSRUN ? NSLOT * SLOTX : 0);
-    double *prod = yring + NSLOT * SLOTY;
+    double *wfring = yring + NSLOT * SLOTY;                   // WARR: the model-error weights of the staged rows (image like x)
+    double *wmring = wfring + (WARR ? NSLOT * SLOTX : 0);     // WARR: the measurement weights (image like the observations)
+    double *prod = wmring + (WARR ? NSLOT * SLOTY : 0);
     double *outb = prod + NE * PW;                            // [2 rows][64 lanes]: the gradient rows of a slot on their way out
     double *strip_red = xring;                                // after the walk
 
@@ -149,27 +151,49 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
             }
         }
         const double dt = dm.dt, hdt = 0.5 * dm.dt;
-        const double cw = 2.0 * st->rf_scale * dm.cfe * dm.rf0;
-        const double c2 = 2.0 * dm.cme * wobs;
+        // scalar weights: q = cw r, the measurement term c2 (x - y).  Weight arrays / data every nskip-th row (WARR):
+        // the row's own weights come through the ring, q = cw w r and the term is c2 w (x - y), w = 0 where no data
+        const double cw = 2.0 * st->rf_scale * dm.cfe * (WARR ? 1.0 : dm.rf0);
+        const double c2 = 2.0 * dm.cme * (WARR ? (obs ? 1.0 : 0.0) : wobs);
+        const int nskip = WARR ? dm.nskip : 1;
 
         // ---- staging
         const char *xrow = reinterpret_cast<const char *>(xg + (ptrdiff_t)rs * D);   // uniform: first row of slot 0
         const char *drow = reinterpret_cast<const char *>(dg + (ptrdiff_t)rs * D);
         const char *yrow = reinterpret_cast<const char *>(dv.pp.Y + (ptrdiff_t)rs * L);
+        const char *wfrow = reinterpret_cast<const char *>(dv.pp.rf0_arr + (ptrdiff_t)rs * D);       // (WARR only)
         const size_t xstep = (size_t)2 * D * 8, ystep = (size_t)2 * L * 8;
+        // WARR: the lane's data row of the next slot to be requested = its model row / nskip, kept as quotient and
+        // remainder (slots are requested in order, two model rows apart)
+        int ynd = 0, yrem = 0;
+        if constexpr (WARR) {
+            const int r0 = rs + yrr;
+            if (r0 >= 0) { ynd = r0 / nskip; yrem = r0 - ynd * nskip; }
+            else { ynd = -1; yrem = nskip - 1; }               // (the row in front of the path: one data row in front, never used)
+        }
+        const unsigned ycol = (unsigned)(l_start + 2 * ypc) * 8u;
         auto issue = [&](int k, int pos) {
             if (dma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(xrow + k * xstep + xoff), (lds_void_t *)(xring + pos * SLOTX), 16, 0, 0);
             if (LSRUN && use_d) {
                 if (dma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(drow + k * xstep + xoff), (lds_void_t *)(dring + pos * SLOTX), 16, 0, 0);
             }
-            if (ydma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(yrow + k * ystep + yoff), (lds_void_t *)(yring + pos * SLOTY), 16, 0, 0);
+            if constexpr (WARR) {
+                const size_t yo = (size_t)((ptrdiff_t)ynd * L * 8) + ycol;
+                if (ydma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(reinterpret_cast<const char *>(dv.pp.Y) + yo), (lds_void_t *)(yring + pos * SLOTY), 16, 0, 0);
+                if (dma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(wfrow + k * xstep + xoff), (lds_void_t *)(wfring + pos * SLOTX), 16, 0, 0);
+                if (ydma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(reinterpret_cast<const char *>(dv.pp.rm_arr) + yo), (lds_void_t *)(wmring + pos * SLOTY), 16, 0, 0);
+                yrem += 2;
+                while (yrem >= nskip) { yrem -= nskip; ++ynd; }
+            } else {
+                if (ydma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(yrow + k * ystep + yoff), (lds_void_t *)(yring + pos * SLOTY), 16, 0, 0);
+            }
         };
 #pragma unroll
         for (int k = 0; k < P; ++k)
             if (k < nslots) issue(k, k);
 
         // ---- the walk
-        double x0p = 0.0, fp = 0.0, qp = 0.0, yp = 0.0, dp = 0.0, xnp[NB];
+        double x0p = 0.0, fp = 0.0, qp = 0.0, yp = 0.0, dp = 0.0, wfp = 0.0, wmp = 0.0, xnp[NB];
 #pragma unroll
         for (int k = 0; k < NB; ++k) xnp[k] = 0.0;
         double fe = 0.0, me = 0.0, gtd = 0.0, gn2 = 0.0, gmax = 0.0, gp[RHS::NP > 0 ? RHS::NP : 1];
@@ -177,7 +201,13 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
         for (int k = 0; k < RHS::NP; ++k) gp[k] = 0.0;
 
         // finish a row: its direct term and s (the adjoint weight that multiplies df/dx of that row)
-        auto emit_row = [&](double x0, const double *xn, double yv, double dval, double direct, double s, int orow) {
+        // (WARR) the row about to be finished, modulo nskip: data exist where it is 0
+        int mrem = 0;
+        if constexpr (WARR) {
+            const int first = DISC == DISC_SH ? rs + 1 : rs;
+            mrem = first % nskip;
+        }
+        auto emit_row = [&](double x0, const double *xn, double yv, double dval, double wm, double direct, double s, int orow) {
             double e[NE], diag;
             RHS::scatter(col, s, x0, xn, p, 0.0, nullptr, e, diag);
             RHS::pgrad(col, s, x0, xn, p, 0.0, nullptr, gp);
@@ -192,9 +222,17 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
                 wave_sync_lds();                              // (the next row overwrites the arrays)
             }
             const double diff = x0 - yv;
-            me = fma(diff, diff, me);
             double gv = (direct + diag) + RHS::gather(r);
-            gv = fma(c2, diff, gv);
+            if constexpr (WARR) {
+                const double w = mrem == 0 ? wm : 0.0;
+                mrem = mrem + 1 == nskip ? 0 : mrem + 1;
+                const double wd = w * diff;
+                me = fma(wd, diff, me);
+                gv = fma(c2, wd, gv);
+            } else {
+                me = fma(diff, diff, me);
+                gv = fma(c2, diff, gv);
+            }
             if constexpr (LSRUN) {
                 gtd = fma(gv, dval, gtd);
                 gn2 = fma(gv, gv, gn2);
@@ -208,7 +246,7 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
             if constexpr (DISC == DISC_TRAPEZOID) { direct = qp - q; s = -hdt * (qp + q); }
             else if constexpr (DISC == DISC_EULER) { direct = qp - q; s = -dt * q; }
             else { direct = qp; s = -q; }
-            emit_row(x0p, xnp, yp, dp, direct, s, orow);
+            emit_row(x0p, xnp, yp, dp, wmp, direct, s, orow);
             qp = q;
         };
         // rows m0, m0 + 1 (or m0 alone) of the gradient: LDS -> 16-byte stores
@@ -226,7 +264,7 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
             else __builtin_amdgcn_raw_buffer_store_b128(v, grs, voff, m0 * D * 8, 0);
         };
         // one staged row in registers: own column, the stencil's neighbours, observation, own entry of d
-        struct Row { double x0, xn[NB], yv, dval; };
+        struct Row { double x0, xn[NB], yv, dval, wf, wm; };
         auto load_row = [&](int pos, int r01) {
             Row t;
             lds_cvp xr = VA_LDS_CVP(xring + pos * SLOTX + r01 * 2 * PR + xlane);
@@ -236,6 +274,11 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
             t.yv = VA_LDS_CVP(yring + pos * SLOTY + r01 * 2 * YP + ylane)[0];
             t.dval = 0.0;
             if (LSRUN && use_d) t.dval = VA_LDS_CVP(dring + pos * SLOTX + r01 * 2 * PR + xlane)[0];
+            t.wf = 1.0; t.wm = 0.0;
+            if constexpr (WARR) {
+                t.wf = VA_LDS_CVP(wfring + pos * SLOTX + r01 * 2 * PR + xlane)[0];
+                t.wm = obs ? VA_LDS_CVP(wmring + pos * SLOTY + r01 * 2 * YP + ylane)[0] : 0.0;
+            }
             return t;
         };
         // row j enters: f_j, the residual of the interval (j-1, j), and row j-1 is finished; FIRST: only
@@ -257,10 +300,16 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
                 if constexpr (DISC == DISC_TRAPEZOID) r = (t.x0 - x0p) - hdt * (fp + f);
                 else if constexpr (DISC == DISC_EULER) r = (t.x0 - x0p) - dt * fp;
                 else r = t.x0 - fp;
-                fe = fma(r, r, fe);
-                emit(cw * r, orow);
+                if constexpr (WARR) {
+                    const double wr = wfp * r;                // (the weight row of the residual that starts at the state row)
+                    fe = fma(wr, r, fe);
+                    emit(cw * wr, orow);
+                } else {
+                    fe = fma(r, r, fe);
+                    emit(cw * r, orow);
+                }
             }
-            x0p = t.x0; fp = f; yp = t.yv; dp = t.dval;
+            x0p = t.x0; fp = f; yp = t.yv; dp = t.dval; wfp = t.wf; wmp = t.wm;
 #pragma unroll
             for (int k = 0; k < NB; ++k) xnp[k] = t.xn[k];
         };
@@ -270,9 +319,10 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
             if (k + P > nslots) {
                 if (!drained) { VA_WAIT_VM(0); drained = true; }
             } else if (LSRUN && use_d) {
-                if (k < P) VA_WAIT_VM((P - 1) * 3); else VA_WAIT_VM((P - 1) * 4);        // per slot in flight: x, d, Y rows + one gradient store
+                // per slot in flight: x, d, Y rows (+ the two weight images) + one gradient store
+                if (k < P) VA_WAIT_VM((P - 1) * (WARR ? 5 : 3)); else VA_WAIT_VM((P - 1) * (WARR ? 6 : 4));
             } else {
-                if (k < P) VA_WAIT_VM((P - 1) * 2); else VA_WAIT_VM((P - 1) * 3);
+                if (k < P) VA_WAIT_VM((P - 1) * (WARR ? 4 : 2)); else VA_WAIT_VM((P - 1) * (WARR ? 5 : 3));
             }
             __builtin_amdgcn_wave_barrier();
             if (k + P < nslots) issue(k + P, ppos);
@@ -299,12 +349,13 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
                 const double f1 = RHS::f(col, t1.x0, t1.xn, p, 0.0, nullptr);
                 const double r1 = t1.x0 - x0p - (fp + 4.0 * f0 + f1) * dt3;
                 const double r2 = t0.x0 - (0.5 * (x0p + t1.x0) + (fp - f1) * dt4);
-                fe = fma(r1, r1, fe);
-                fe = fma(r2, r2, fe);
-                const double q1 = cw * r1, q2 = cw * r2;
-                emit_row(x0p, xnp, yp, dp, -q1 - 0.5 * q2 + qp - 0.5 * q2p, -dt3 * (q1 + qp) - dt4 * (q2 - q2p), 0);
-                emit_row(t0.x0, t0.xn, t0.yv, t0.dval, q2, -(4.0 * dt3) * q1, 1);
-                x0p = t1.x0; fp = f1; yp = t1.yv; dp = t1.dval; qp = q1; q2p = q2;
+                const double w1 = WARR ? wfp * r1 : r1, w2 = WARR ? t0.wf * r2 : r2;     // (weight rows m and m+1, as va_tile4.h)
+                fe = fma(w1, r1, fe);
+                fe = fma(w2, r2, fe);
+                const double q1 = cw * w1, q2 = cw * w2;
+                emit_row(x0p, xnp, yp, dp, wmp, -q1 - 0.5 * q2 + qp - 0.5 * q2p, -dt3 * (q1 + qp) - dt4 * (q2 - q2p), 0);
+                emit_row(t0.x0, t0.xn, t0.yv, t0.dval, t0.wm, q2, -(4.0 * dt3) * q1, 1);
+                x0p = t1.x0; fp = f1; yp = t1.yv; dp = t1.dval; wfp = t1.wf; wmp = t1.wm; qp = q1; q2p = q2;
 #pragma unroll
                 for (int k = 0; k < NB; ++k) xnp[k] = t1.xn[k];
             };
@@ -331,7 +382,7 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
                 ppos = ppos + 1 == NSLOT ? 0 : ppos + 1;
             }
             if (n1 == N) {                                    // the path's last row: no interval starts there
-                emit_row(x0p, xnp, yp, dp, qp - 0.5 * q2p, -dt3 * qp + dt4 * q2p, 0);
+                emit_row(x0p, xnp, yp, dp, wmp, qp - 0.5 * q2p, -dt3 * qp + dt4 * q2p, 0);
                 flush(N - 1, gvoff1);
             }
         } else {
@@ -372,8 +423,8 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
         if (!drained) VA_WAIT_VM(0);
 
         // ---- the lane's sums (lanes outside the strip's own columns computed ghosts: not theirs to count)
-        acc.v[EP_FE] = own ? dm.rf0 * fe : 0.0;
-        acc.v[EP_ME] = own ? wobs * me : 0.0;
+        acc.v[EP_FE] = own ? (WARR ? fe : dm.rf0 * fe) : 0.0;
+        acc.v[EP_ME] = own ? (WARR ? me : wobs * me) : 0.0;
         acc.v[EP_GTD] = own ? gtd : 0.0;
         acc.v[EP_GN2] = own ? gn2 : 0.0;
         acc.v[EP_GMAX] = own ? gmax : 0.0;
@@ -411,14 +462,38 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
 
 inline size_t eval5_lds_bytes(const Dev &dv)
 {
-    return sizeof(double) * (size_t)dv.g5.WPG * tile5_wave_doubles(dv.g5, dv.lsrun ? dv.g5.nslot_ls : dv.g5.nslot, dv.lsrun != 0);
+    return sizeof(double) * (size_t)dv.g5.WPG * tile5_wave_doubles(dv.g5, dv.lsrun ? dv.g5.nslot_ls : dv.g5.nslot, dv.lsrun != 0, dv.g5.warr != 0);
 }
 
 // launch (or, once per handle and device, opt in to > 64 KiB of LDS) the instantiation the handle's geometry and
 // this launch's kind call for: ring depth and "line-search points possible" are template parameters
+// weight arrays / data every nskip-th row (Geo5::warr): a three-slot ring only
+template <class RHS, int DISC, int DC, bool XDPP>
+inline hipError_t eval5_slots_w(const Dev &dv, bool prepare, hipStream_t s)
+{
+    const int threads = 64 * dv.g5.WPG;
+    if (prepare) {
+        hipError_t err = hipSuccess;
+        Dev t = dv;
+        for (int ls = 0; ls < 2; ++ls) {
+            t.lsrun = ls;
+            if (eval5_lds_bytes(t) <= 64 * 1024) continue;
+            hipError_t e = ls ? hipFuncSetAttribute((const void *)k_eval5<RHS, DISC, DC, 3, true, XDPP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                              : hipFuncSetAttribute((const void *)k_eval5<RHS, DISC, DC, 3, false, XDPP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) err = e;
+        }
+        return err;
+    }
+    const size_t lds = eval5_lds_bytes(dv);
+    const int grid = ((dv.dm.B * dv.dm.ntiles + 7) / 8) * 8;
+    if (dv.lsrun) hipLaunchKernelGGL((k_eval5<RHS, DISC, DC, 3, true, XDPP, true>), dim3(grid), dim3(threads), lds, s, dv);
+    else hipLaunchKernelGGL((k_eval5<RHS, DISC, DC, 3, false, XDPP, true>), dim3(grid), dim3(threads), lds, s, dv);
+    return hipSuccess;
+}
 template <class RHS, int DISC, int DC, bool XDPP>
 inline hipError_t eval5_slots(const Dev &dv, bool prepare, hipStream_t s)
 {
+    if (dv.g5.warr) return eval5_slots_w<RHS, DISC, DC, XDPP>(dv, prepare, s);
     const int threads = 64 * dv.g5.WPG;
     if (prepare) {
         hipError_t err = hipSuccess;
@@ -428,7 +503,7 @@ inline hipError_t eval5_slots(const Dev &dv, bool prepare, hipStream_t s)
             if (eval5_lds_bytes(t) <= 64 * 1024) continue;
             const int ns = ls ? t.g5.nslot_ls : t.g5.nslot;
             hipError_t e = hipSuccess;
-#define VA_E5_ATTR(NSL, LS) e = hipFuncSetAttribute((const void *)k_eval5<RHS, DISC, DC, NSL, LS, XDPP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+#define VA_E5_ATTR(NSL, LS) e = hipFuncSetAttribute((const void *)k_eval5<RHS, DISC, DC, NSL, LS, XDPP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
             if (ls) { if (ns == 3) VA_E5_ATTR(3, true); else VA_E5_ATTR(4, true); }
             else { if (ns == 3) VA_E5_ATTR(3, false); else VA_E5_ATTR(4, false); }
 #undef VA_E5_ATTR
@@ -439,7 +514,7 @@ inline hipError_t eval5_slots(const Dev &dv, bool prepare, hipStream_t s)
     const size_t lds = eval5_lds_bytes(dv);
     const int ns = dv.lsrun ? dv.g5.nslot_ls : dv.g5.nslot;
     const int grid = ((dv.dm.B * dv.dm.ntiles + 7) / 8) * 8;
-#define VA_E5_GO(NSL, LS) hipLaunchKernelGGL((k_eval5<RHS, DISC, DC, NSL, LS, XDPP>), dim3(grid), dim3(threads), lds, s, dv)
+#define VA_E5_GO(NSL, LS) hipLaunchKernelGGL((k_eval5<RHS, DISC, DC, NSL, LS, XDPP, false>), dim3(grid), dim3(threads), lds, s, dv)
     if (dv.lsrun) { if (ns == 3) VA_E5_GO(3, true); else VA_E5_GO(4, true); }
     else { if (ns == 3) VA_E5_GO(3, false); else VA_E5_GO(4, false); }
 #undef VA_E5_GO

@@ -108,7 +108,7 @@ __device__ __forceinline__ void lin_gemm(const double *src, int rows, double *ds
         // table from L2) are requested before the 2 KU products of this one are issued
         constexpr int KU = 4;
         const double *bp = Bt + hi * DP + c0;
-        double a[KU], b0[KU], b1[KU], an[KU], b0n[KU], b1n[KU];
+        double a[KU], b0[KU], b1[KU], an[KU] = {}, b0n[KU] = {}, b1n[KU] = {};
         auto fetch = [&](int k0, double *a_, double *b0_, double *b1_) {
 #pragma unroll
             for (int u = 0; u < KU; ++u) {

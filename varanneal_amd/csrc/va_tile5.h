@@ -39,6 +39,7 @@ struct Geo5 {
     int nslot, nslot_ls;  // ring slots: plain evaluation / launches that may hold line-search points
     int ne;               // products per element of the model's column form (LDS arrays of the non-DPP exchange)
     int xdpp;             // scatter products change lanes through DPP shifts (gather reach <= 2) instead of LDS
+    int warr;             // the rows' weights come through the ring too: (N-1, D) RF / (N_data, L) RM arrays, data every nskip-th row
 };
 
 template <class RHS> VA_HD constexpr int t5_xl()
@@ -118,11 +119,11 @@ VA_HD constexpr int t5_wrap(int c, int D) { return c < 0 ? c + D : (c >= D ? c -
 
 // doubles of LDS one wave needs: x ring (+ d ring), observation ring, product arrays.  The reduction strip
 // and the tail's copy of the seed state re-use the rings after the walk.
-VA_HD constexpr int tile5_wave_doubles(const Geo5 &g, int nslot, bool ls)
+VA_HD constexpr int tile5_wave_doubles(const Geo5 &g, int nslot, bool ls, bool warr = false)
 {
     const int ne = g.ne;
     const int slotx = 4 * g.PR, sloty = 4 * g.YPMAX;
-    const int rings = nslot * (slotx * (ls ? 2 : 1) + sloty) + ne * g.PW + 128;     // (+ the gradient rows of a slot on their way out)
+    const int rings = nslot * (slotx * ((ls ? 2 : 1) + (warr ? 1 : 0)) + sloty * (warr ? 2 : 1)) + ne * g.PW + 128;     // (+ the gradient rows of a slot on their way out)
     const int minimum = T4_STRIP + 64;        // reduction strip + SeedHot copy (512 B)
     return ((rings > minimum ? rings : minimum) + 15) & ~15;
 }
