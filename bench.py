@@ -194,9 +194,10 @@ def extra_c4(device, steps=60):
 def extra_variant(device, steps=1000, **kw):
     """One (f)3 variant of the C3 shape (reference: va_ode.py:147-148, 203-209, 404-437, 555-558):
     complete evaluations of 64 seeds, HIP events.  kw: disc=, N=, rf_vec= (RF0 of shape (D,) resized over time),
-    rm_vec= (RM of shape (N_data, L)), nskip= (dt_model = dt_data / nskip)."""
+    rm_vec= (RM of shape (N_data, L)), nskip= (dt_model = dt_data / nskip), D= (200: the same variants at C4's width,
+    where the streaming kernel k_eval5 carries them)."""
     from varanneal_amd import _capi, twin
-    D, B = 20, 64
+    D, B = kw.get("D", 20), 64
     disc, N, nskip = kw.get("disc", "trapezoid"), kw.get("N", 1000), kw.get("nskip", 1)
     Y, Lidx, XP, P = make_inputs(D, N, B, 0)
     RM, RF0 = 4.0, 4e-6
@@ -216,6 +217,28 @@ def extra_variant(device, steps=1000, **kw):
                                                           "_nskip%d" % nskip if nskip > 1 else ""),
             "eval_kernel": info["eval_kernel"], "run_rows": info["run_rows"], "us_per_eval_launch": ks * 1e6, "evals_per_s": B / ks,
             "bytes_alg_per_launch": balg, "frac": balg / ks / 1e9 / HBM_PEAK_GBS}
+
+
+def extra_linear(device, steps=200):
+    """A generated model with a dense constant linear part (f = C x - p1 x^3 + p0, C a fixed 20 x 20 matrix) at the C3
+    shape: the generator splits C off and the flat kernel forms X C^T and S C on v_mfma_f64_16x16x4_f64
+    (codegen.linear_split, csrc/va_eval_flat.h lin_gemm; north_star: MFMA for a dense D x D linear map).  Complete
+    evaluations of 64 seeds, HIP events; the two products are 4 N D^2 flop per seed."""
+    from varanneal_amd import _capi, codegen, twin
+    D, N, B = 20, 1000, 64
+    m = codegen.module_for(twin.dense_coupling_model(D, 1)[0], D, 2)
+    Y, Lidx, XP, _ = make_inputs(D, N, B, 0)
+    P = np.tile(np.array([1.5, 0.3]), (B, 1))
+    XP = np.concatenate([XP[:, :N * D], P], axis=1)
+    with _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 0.3, P, [0, 1], disc="trapezoid", rhs=_capi.load_rhs_module(m["so"]), device=device) as pb:
+        info = pb.info()
+        pb.action_grad(XP, 2.0)
+        pb.eval_timed(2.0, max(steps // 10, 2))
+        ks = pb.eval_timed(2.0, steps) * 1e-3 / steps
+    flops = 4.0 * N * D * D * B
+    return {"workload": "dense_coupling_D%d_N%d_B%d_trapezoid" % (D, N, B), "linear_part_on_mfma": m["lin"] is not None,
+            "eval_kernel": info["eval_kernel"], "tile_rows": info["tile_rows"], "us_per_eval_launch": ks * 1e6, "evals_per_s": B / ks,
+            "mfma_TFLOPs": flops / ks / 1e12, "frac": bytes_alg(B, N, D, 2, N, len(Lidx)) / ks / 1e9 / HBM_PEAK_GBS}
 
 
 def extra_nnet(device, key, steps):
@@ -579,6 +602,9 @@ def main():
             out["extra"] = {"ladder": extra_ladder(local_rank, D, N, B, Y, Lidx, XP, P),
                             "c4": extra_c4(local_rank),
                             "c3_sh": extra_variant(local_rank, disc="SimpsonHermite", N=1001),      # (what Lorenz96_anneal.py:85 runs)
+                            "c4_sh": extra_variant(local_rank, steps=30, D=200, disc="SimpsonHermite", N=5001),
+                            "c4_rf": extra_variant(local_rank, steps=30, D=200, N=5000, rf_vec=True),
+                            "lin_d20": extra_linear(local_rank),
                             "c5": extra_nnet(local_rank, "c5", 2000), "c5x": extra_nnet(local_rank, "c5x", 40)}
         print(json.dumps(out), flush=True)
     pb.close()

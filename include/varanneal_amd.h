@@ -130,7 +130,7 @@ int va_rhs_load_module(const char *path, int32_t *rhs_id);
 int va_eval_plan(const va_problem_desc *desc, int32_t ne, int32_t ghost, int32_t *out);
 /* The same for a column form whose reaches are known: reach[4] = {xl, xr, gl, gr} = how many columns to the left /
  * right f reads (xl, xr) and the adjoint gather receives from (gl, gr).  Wide even states (D > 64) with
- * scalar or per-row weights, data at every model time and an even number of observed columns then run the
+ * scalar or per-row weights (any merr_nskip) then run the
  * streaming kernel k_eval5 (csrc/va_eval5.h): out = (5, disc, 0, 0).  Follows desc->Lidx (needs L and Lidx). */
 int va_eval_plan_reach(const va_problem_desc *desc, int32_t ne, int32_t ghost, const int32_t *reach, int32_t *out);
 

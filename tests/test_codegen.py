@@ -325,7 +325,8 @@ def test_wide_stencil_gets_the_streaming_variant():
     Lidx = list(range(0, 200, 5))
     assert _capi.eval_plan(64, 200, 5000, "trapezoid", 2, 2, reach=(2, 1, 1, 2), Lidx=Lidx) == (5, 1, 0, 0)
     assert _capi.eval_plan(64, 200, 5001, "SimpsonHermite", 2, 2, reach=(2, 1, 1, 2), Lidx=Lidx) == (5, 2, 0, 0)
-    assert _capi.eval_plan(64, 200, 5000, "trapezoid", 2, 2, reach=(2, 1, 1, 2), Lidx=Lidx[:-1])[0] == 3      # odd L
+    assert _capi.eval_plan(64, 200, 5000, "trapezoid", 2, 2, reach=(2, 1, 1, 2), Lidx=Lidx[:-1])[0] == 5      # (odd L: a pad column on the device)
+    assert _capi.eval_plan(64, 201, 5000, "trapezoid", 2, 2, reach=(2, 1, 1, 2), Lidx=Lidx)[0] == 3            # odd D: rows are not 16-byte aligned
     assert _capi.eval_plan(64, 200, 5000, "trapezoid", 2, 2, reach=(2, 1, 1, 2), Lidx=Lidx, rf_array=True)[0] == 5      # (per-row weights stream too)
     seen = {}
 

@@ -77,9 +77,7 @@ def test_sparse_and_dense_observations(capi):
     import va_oracle
     from varanneal_amd import twin
     D, N, B = 200, 70, 2
-    for Lidx in ([0, 1], list(range(0, 200)), [150, 151, 152, 199], list(range(3, 200, 2))[:98]):
-        if len(Lidx) % 2:
-            continue
+    for Lidx in ([0, 1], list(range(0, 200)), [150, 151, 152, 199], list(range(3, 200, 2))[:98], [77]):
         rng = np.random.RandomState(len(Lidx))
         Y = rng.randn(N, len(Lidx))
         XP = np.concatenate([2.0 * rng.randn(B, N * D), 7.0 + rng.rand(B, 1)], axis=1)
@@ -96,12 +94,12 @@ def test_sparse_and_dense_observations(capi):
 
 
 def test_fallback_when_the_streaming_kernel_does_not_apply(capi):
-    """odd L, full weight matrices: the handle runs another kernel instead (and says so); Simpson-Hermite and
-    per-row weights stream"""
+    """odd D (rows that are not 16-byte aligned), full weight matrices: the handle runs another kernel instead (and
+    says so); Simpson-Hermite, per-row weights and an odd number of observed columns stream"""
     from varanneal_amd import twin
     D, N, B = 200, 41, 1
-    Y, Lidx, XP, P = make(D, N, B, 3, L=7)
-    with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", eval_kernel=5) as pb:
+    Y, Lidx, XP, P = make(201, N, B, 3, L=8)
+    with capi.Problem(B, 201, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", eval_kernel=5) as pb:
         assert pb.info()["eval_kernel"] == 3
     Y, Lidx, XP, P = make(D, N, B, 3)
     with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="SimpsonHermite", eval_kernel=5) as pb:
@@ -110,6 +108,30 @@ def test_fallback_when_the_streaming_kernel_does_not_apply(capi):
         assert pb.info()["eval_kernel"] == 5
     with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, np.full((N - 1, D, D), 4e-6), P, [0], disc="trapezoid", eval_kernel=5) as pb:
         assert pb.info()["eval_kernel"] == 1
+
+
+@pytest.mark.parametrize("disc", ["trapezoid", "SimpsonHermite"])
+def test_odd_number_of_observed_columns(capi, disc):
+    """L odd: the data rows get a pad column on the device (they are staged by 16-byte pieces); with and without
+    per-row measurement weights"""
+    import va_oracle
+    from varanneal_amd import twin
+    for D, N, L in ((200, 61, 7), (200, 45, 41), (130, 51, 1)):
+        check_vs_oracle(capi, D, N, 2, disc, 30, seed=L, L=L)
+    D, N, B, L = 200, 61, 2, 9
+    rng = np.random.RandomState(9)
+    Lidx = np.sort(rng.choice(D, L, replace=False))
+    Y = rng.randn(N, L)
+    RM = 0.5 + rng.rand(N, L)
+    XP = np.concatenate([2.0 * rng.randn(B, N * D), 7.0 + rng.rand(B, 1)], axis=1)
+    P = XP[:, -1:].copy()
+    with capi.Problem(B, D, N, Y, list(Lidx), twin.DT, RM, 0.7, P, [0], disc=disc, eval_kernel=5, tile_rows=24) as pb:
+        assert pb.info()["eval_kernel"] == 5
+        A, me, fe, g = pb.action_grad(XP, 2.5)
+    for b in range(B):
+        Ao, meo, feo, go = va_oracle.Problem(D, N, Y, list(Lidx), twin.DT, RM, 0.7, P[b], [0], disc=disc).action_grad(XP[b], 2.5)
+        assert abs(A[b] - Ao) <= RTOL_A * abs(Ao) and abs(me[b] - meo) <= RTOL_A * max(abs(meo), abs(Ao))
+        assert np.abs(g[b] - go).max() <= RTOL_G * np.abs(go).max()
 
 
 def test_timed_evaluation_is_a_complete_evaluation(capi):

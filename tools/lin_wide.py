@@ -1,4 +1,4 @@
-"""usage: python3 tools/lin_wide.py [D N B]  -- a dense-coupling model (tests/test_gpu_codegen.py _coupled) at a wide shape:
+"""usage: python3 tools/lin_wide.py [D N B]  -- a dense-coupling model (varanneal_amd/twin.py dense_coupling_model) at a wide shape:
 us per complete evaluation and the matrix-core rate of its two products (X C^T and S C: 4 N D^2 flop per seed)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,14 +7,7 @@ import numpy as np
 from varanneal_amd import _capi, codegen, twin
 
 D, N, B = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (200, 5000, 64)
-C = np.random.RandomState(D).randn(D, D) / np.sqrt(D)
-
-
-def coupled(t, x, p):
-    return x @ C.T - p[1] * x ** 3 + p[0]
-
-
-m = codegen.module_for(coupled, D, 2)
+m = codegen.module_for(twin.dense_coupling_model(D, D)[0], D, 2)
 assert m["lin"] is not None
 Lidx = list(range(0, D, 5))
 rng = np.random.RandomState(0)

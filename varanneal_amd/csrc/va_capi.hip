@@ -192,7 +192,8 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
         g.warr = (d->rm_kind == 1 || d->rf_kind == 1 || d->merr_nskip > 1) ? 1 : 0;
         if (g.warr) g.nslot = g.nslot_ls = 3;          // (two more images per slot; only the three-slot instantiations exist)
         g.xdpp = (reach5[2] <= 2 && reach5[3] <= 2) ? 1 : 0;
-        if (g.YPMAX <= 32 && !(d->L & 1)) {          // (odd L: data rows alternate between 16-byte phases -- not staged by 16-byte pieces)
+        g.LY = (d->L + 1) & ~1;                        // (data rows are staged by 16-byte pieces: an odd L gets a pad column on the device)
+        if (g.YPMAX <= 32) {
             *g5 = g;
             dm.RY = 0; dm.NT = 64 * g.WPG; dm.maxr = 2; dm.T = g.SEGL;
             dm.ntiles = g.NSEG * g.NSG;
@@ -758,8 +759,9 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
 #define TRY(x) do { rc = (x); if (rc) { va_problem_destroy(h); return rc; } } while (0)
     TRY(h->alloc(&lmap_d, dm.D));
     // (two rows + a line of padding: the streaming kernel stages observation rows by whole 16-byte pieces, two rows at a time)
-    TRY(h->alloc(&Y_d, (size_t)dm.N_data * dm.L + 4 * (size_t)dm.L + 16));   // (k_eval5 stages row pairs: one pair before the first row, one past the last)
-    Y_d += 2 * (size_t)(dm.L / 2) + (dm.L & 1) * 2;       // an even number of doubles >= L: the data keep their 16-byte alignment
+    const size_t LY = dm.emode == 5 ? (size_t)dv.g5.LY : (size_t)dm.L;        // row pitch of Y (and of the RM image of k_eval5) on the device
+    TRY(h->alloc(&Y_d, (size_t)dm.N_data * LY + 4 * LY + 16));   // (k_eval5 stages row pairs: one pair before the first row, one past the last)
+    Y_d += 2 * (LY / 2) + (LY & 1) * 2;                   // an even number of doubles >= L: the data keep their 16-byte alignment
     int *ystrip_d = nullptr;
     if (dm.emode == 5) TRY(h->alloc(&ystrip_d, ystrip_h.size()));
     const size_t np_seed = tdp ? (size_t)dm.N * dm.NPt : (size_t)dm.NPt;       // parameters stored per seed
@@ -771,8 +773,8 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     const bool warr5 = dm.emode == 5 && dv.g5.warr;      // k_eval5 streams both weight images: scalar weights are spread out into arrays
     if (warr5) {
         // (as Y: one row pair in front and behind; L is even on this path)
-        TRY(h->alloc(&rm_d, rm_elems + 4 * (size_t)dm.L + 16));
-        rm_d += dm.L;
+        TRY(h->alloc(&rm_d, (size_t)dm.N_data * LY + 4 * LY + 16));
+        rm_d += LY;
     } else if (d->rm_kind) TRY(h->alloc(&rm_d, rm_elems));
     if (d->rm_kind == 2) TRY(h->alloc(&lidx_d, dm.L));
     if (warr5) {
@@ -805,14 +807,14 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     for (int l = 0; l < dm.L; ++l) perm[l] = l;
     if (d->rm_kind != 2) std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return d->Lidx[a] < d->Lidx[b]; });
     for (int l = 0; l < dm.L; ++l) lidx_sorted[l] = d->Lidx[perm[l]];
-    std::vector<double> Ys((size_t)dm.N_data * dm.L), rms;
+    std::vector<double> Ys((size_t)dm.N_data * LY, 0.0), rms;
     for (int n = 0; n < dm.N_data; ++n)
-        for (int l = 0; l < dm.L; ++l) Ys[(size_t)n * dm.L + l] = d->Y[(size_t)n * dm.L + perm[l]];
-    if (warr5 && d->rm_kind == 0) rms.assign((size_t)dm.N_data * dm.L, d->rm);
+        for (int l = 0; l < dm.L; ++l) Ys[(size_t)n * LY + l] = d->Y[(size_t)n * dm.L + perm[l]];
+    if (warr5 && d->rm_kind == 0) rms.assign((size_t)dm.N_data * LY, d->rm);
     if (d->rm_kind == 1) {
-        rms.resize((size_t)dm.N_data * dm.L);
+        rms.assign((size_t)dm.N_data * LY, 0.0);
         for (int n = 0; n < dm.N_data; ++n)
-            for (int l = 0; l < dm.L; ++l) rms[(size_t)n * dm.L + l] = d->rm_array[(size_t)n * dm.L + perm[l]];
+            for (int l = 0; l < dm.L; ++l) rms[(size_t)n * LY + l] = d->rm_array[(size_t)n * dm.L + perm[l]];
     }
     std::vector<int> lmap(dm.D, -1);
     for (int l = 0; l < dm.L; ++l) lmap[lidx_sorted[l]] = l;
@@ -823,10 +825,10 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
         if (e_ != hipSuccess) { va_problem_destroy(h); return fail(VA_EHIP, "H2D %s: %s", #dst, hipGetErrorString(e_)); } } while (0)
     H2D(lmap_d, lmap.data(), dm.D, int);
     if (dm.emode == 5) { H2D(ystrip_d, ystrip_h.data(), ystrip_h.size(), int); dv.ystrip = ystrip_d; }
-    H2D(Y_d, Ys.data(), (size_t)dm.N_data * dm.L, double);
+    H2D(Y_d, Ys.data(), (size_t)dm.N_data * LY, double);
     if (dm.NPe) H2D(pidx_d, d->Pidx, dm.NPe, int);
     H2D(P_d, d->P, B * np_seed, double);
-    if (d->rm_kind || warr5) H2D(rm_d, d->rm_kind != 2 ? rms.data() : d->rm_array, rm_elems, double);
+    if (d->rm_kind || warr5) H2D(rm_d, d->rm_kind != 2 ? rms.data() : d->rm_array, d->rm_kind != 2 ? rms.size() : rm_elems, double);
     if (d->rm_kind == 2) H2D(lidx_d, d->Lidx, dm.L, int);
     std::vector<double> rf_fill;
     if (warr5 && d->rf_kind == 0) rf_fill.assign((size_t)(dm.N - 1) * dm.D, d->rf0);

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
     ThreadAcc acc;
     acc.clear();
     if (wave_on) {
-        const int N = dm.N, L = dm.L;
+        const int N = dm.N, L = dv.g5.LY;                     // (L: the row pitch of Y / RM on the device, even)
         const int c0 = tile5_c0(D, gc.NS, strip);
         const int cws = tile5_c0(D, gc.NS, strip + 1) - c0;
         const int n0 = sg * SEGL, n1 = (n0 + SEGL) < N ? (n0 + SEGL) : N;

@@ -39,6 +39,7 @@ struct Geo5 {
     int nslot, nslot_ls;  // ring slots: plain evaluation / launches that may hold line-search points
     int ne;               // products per element of the model's column form (LDS arrays of the non-DPP exchange)
     int xdpp;             // scatter products change lanes through DPP shifts (gather reach <= 2) instead of LDS
+    int LY;               // row pitch of the observation (and RM) rows on the device: L rounded up to even
     int warr;             // the rows' weights come through the ring too: (N-1, D) RF / (N_data, L) RM arrays, data every nskip-th row
 };
 

@@ -141,3 +141,14 @@ def nnet_initial_guess(structure, M, seed_index, weights_only=True):
         if not weights_only:
             Pidx += list(range(boff[n], boff[n] + int(structure[n + 1])))
     return X0, P0, Pidx
+
+
+def dense_coupling_model(D, seed=1):
+    """a model with a dense constant linear part: f = C x - p1 x^3 + p0 with a fixed D x D matrix C (NOT from the
+    reference: the shape BASELINE north_star names for the matrix cores, "a dense D x D linear map"); bench.py
+    extra.lin_d20, tools/lin_wide.py, __graft_entry__.build().  Returns (f, C)."""
+    C = np.random.RandomState(seed).randn(D, D) / np.sqrt(D)
+
+    def coupled(t, x, p):
+        return x @ C.T - p[1] * x ** 3 + p[0]
+    return coupled, C
