@@ -186,12 +186,12 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
         }
         // ring depth: four slots (three requested ahead) while four workgroups still share a CU's 160 KiB, else three.
         // Measured at C4 (profiles/r03_e5_experiments.txt): 3 and 4 slots equal; 6 slots drop a workgroup per CU (+33 %)
+        g.xdpp = (reach5[2] <= 2 && reach5[3] <= 2) ? 1 : 0;
         auto fits = [&](int nslot, bool lsr) { return (size_t)g.WPG * tile5_wave_doubles(g, nslot, lsr) * sizeof(double) <= 40 * 1024; };
         g.nslot = fits(4, false) ? 4 : 3;
         g.nslot_ls = fits(4, true) ? 4 : 3;
         g.warr = (d->rm_kind == 1 || d->rf_kind == 1 || d->merr_nskip > 1) ? 1 : 0;
         if (g.warr) g.nslot = g.nslot_ls = 3;          // (two more images per slot; only the three-slot instantiations exist)
-        g.xdpp = (reach5[2] <= 2 && reach5[3] <= 2) ? 1 : 0;
         g.LY = (d->L + 1) & ~1;                        // (data rows are staged by 16-byte pieces: an odd L gets a pad column on the device)
         if (g.YPMAX <= 32) {
             *g5 = g;

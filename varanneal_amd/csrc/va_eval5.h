@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
     double *wfring = yring + NSLOT * SLOTY;                   // WARR: the model-error weights of the staged rows (image like x)
     double *wmring = wfring + (WARR ? NSLOT * SLOTX : 0);     // WARR: the measurement weights (image like the observations)
     double *prod = wmring + (WARR ? NSLOT * SLOTY : 0);
-    double *outb = prod + NE * PW;                            // [2 rows][64 lanes]: the gradient rows of a slot on their way out
+    double *outb = prod + (XDPP ? 0 : NE * PW);                          // [2 rows][64 lanes]: the gradient rows of a slot on their way out
     double *strip_red = xring;                                // after the walk
 
     ThreadAcc acc;

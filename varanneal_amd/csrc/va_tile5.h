@@ -118,13 +118,14 @@ VA_HD constexpr bool tile5_ok(int D, int xl, int xr, int gl, int gr)
 
 VA_HD constexpr int t5_wrap(int c, int D) { return c < 0 ? c + D : (c >= D ? c - D : c); }
 
-// doubles of LDS one wave needs: x ring (+ d ring), observation ring, product arrays.  The reduction strip
+// doubles of LDS one wave needs: x ring (+ d ring), observation ring, product arrays (none when the products change
+// lanes through DPP shifts).  The reduction strip
 // and the tail's copy of the seed state re-use the rings after the walk.
 VA_HD constexpr int tile5_wave_doubles(const Geo5 &g, int nslot, bool ls, bool warr = false)
 {
     const int ne = g.ne;
     const int slotx = 4 * g.PR, sloty = 4 * g.YPMAX;
-    const int rings = nslot * (slotx * ((ls ? 2 : 1) + (warr ? 1 : 0)) + sloty * (warr ? 2 : 1)) + ne * g.PW + 128;     // (+ the gradient rows of a slot on their way out)
+    const int rings = nslot * (slotx * ((ls ? 2 : 1) + (warr ? 1 : 0)) + sloty * (warr ? 2 : 1)) + (g.xdpp ? 0 : ne * g.PW) + 128;     // (+ the gradient rows of a slot on their way out)
     const int minimum = T4_STRIP + 64;        // reduction strip + SeedHot copy (512 B)
     return ((rings > minimum ? rings : minimum) + 15) & ~15;
 }
