@@ -124,3 +124,40 @@ def test_wide_models_run_the_streaming_kernel_through_the_drop_in():
         res[key] = (a.A_array.copy(), a.nit_array.copy())
         a.close()
     assert np.array_equal(res["builtin"][1], res["traced"][1]) and np.allclose(res["builtin"][0], res["traced"][0], rtol=1e-9)
+
+
+def test_wide_models_with_per_component_weights_and_simpson_hermite():
+    """the same two models through the drop-in with what the tutorials use on top: RF0 of shape (D,) (one model-error
+    weight per component, va_ode.py:631-634), RM of shape (L,), Simpson-Hermite, an ODD number of observed columns
+    -- all on the streaming kernel (weights through the ring, interval walk, pad column); built-in and traced
+    agree, and the first rung agrees with the oracle's minimisation"""
+    import va_oracle
+    from varanneal_amd import twin, va_ode
+    D, N, B = 100, 161, 3
+    Lidx = list(range(0, D, 5))[:19]
+    t, Y, _, _ = twin.make_twin(D, N, Lidx=Lidx)
+    X0 = np.empty((B, N, D)); P0 = np.empty((B, 1))
+    for s in range(B):
+        X0[s], P0[s] = twin.initial_guess(N, D, s, Y, Lidx)
+    RF0 = 4e-6 * (1.0 + 0.05 * np.arange(D))
+    RM = 4.0 * (1.0 + 0.1 * np.arange(len(Lidx)))
+    opts = {'gtol': 1e-8, 'ftol': 1e-8, 'maxiter': 15, 'maxfun': 1000}
+
+    def damped_l96(t, x, p):
+        return np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - p[1] * x + p[0]
+    res = {}
+    for key, f, P in (("builtin", twin.l96, P0), ("traced", damped_l96, np.hstack([P0, np.ones((B, 1))]))):
+        a = va_ode.Annealer()
+        a.set_model(f, D)
+        a.set_data(Y, t=t)
+        a.anneal(X0.copy(), P.copy(), 1.5, [0, 1], RM, RF0, Lidx, [0], disc="SimpsonHermite", opt_args=opts, verbose=False)
+        assert a._pb.info()["eval_kernel"] == 5
+        res[key] = (a.A_array.copy(), a.nit_array.copy(), a.minpaths.copy() if hasattr(a, "minpaths") else None)
+        a.close()
+    assert np.array_equal(res["builtin"][1], res["traced"][1]) and np.allclose(res["builtin"][0], res["traced"][0], rtol=1e-9)
+    XP = np.append(X0[0].ravel(), P0[0])
+    XP[:N * D].reshape(N, D)[:, Lidx] = Y                                   # init_to_data (va_ode.py:677-678)
+    opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, np.resize(RM, Y.shape), np.resize(RF0, (N - 1, D)), P0[0], [0],
+                            disc="SimpsonHermite")
+    x, A, st, nit, nfev = opb.minimize_lbfgs(XP, 1.0, opts)
+    assert nit == res["builtin"][1][0][0] and abs(A - res["builtin"][0][0][0]) <= 1e-7 * abs(A)
