@@ -241,3 +241,43 @@ def test_weight_arrays_minimisation_follows_the_tile_kernel(capi):
             res[ek] = pb.minimize_lbfgs(XP, 1.5 ** 6, o)
     assert np.array_equal(res[5]["nit"], res[3]["nit"]) and np.array_equal(res[5]["nfev"], res[3]["nfev"])
     assert np.allclose(res[5]["A"], res[3]["A"], rtol=1e-9, atol=0) and np.abs(res[5]["x"] - res[3]["x"]).max() <= 1e-6
+
+
+def test_random_shapes_against_the_oracle(capi):
+    """a seeded sweep over widths, lengths, segment lengths, numbers of observed columns, weight kinds, data strides
+    and discretisations -- every combination the streaming kernel accepts -- against the oracle"""
+    import va_oracle
+    from varanneal_amd import twin
+    rng = np.random.RandomState(20260)
+    discs = ["trapezoid", "SimpsonHermite", "euler", "forwardmap"]
+    for case in range(36):
+        D = 2 * int(rng.randint(33, 131))
+        nskip = int(rng.choice([1, 1, 2, 3]))
+        disc = discs[case % 4]
+        Nd = int(rng.randint(18, 70))
+        N = (Nd - 1) * nskip + 1
+        if disc == "SimpsonHermite" and N % 2 == 0:
+            Nd += 1; N = (Nd - 1) * nskip + 1
+            if N % 2 == 0:                      # (nskip odd, Nd even -> N even again: take nskip = 2)
+                nskip = 2; N = (Nd - 1) * nskip + 1
+        B = int(rng.randint(1, 4))
+        L = int(rng.randint(1, D // 2))
+        Lidx = np.sort(rng.choice(D, L, replace=False))
+        Y = rng.randn(Nd, L)
+        RM = (0.5 + rng.rand(Nd, L)) if rng.rand() < 0.4 else 2.0
+        RF = (0.2 + rng.rand(N - 1, D)) if rng.rand() < 0.4 else 0.9
+        tile_rows = int(rng.choice([0, 32, 34, 48, N]))
+        XP = np.concatenate([2.0 * rng.randn(B, N * D), 7.0 + rng.rand(B, 1)], axis=1)
+        P = XP[:, -1:].copy()
+        tag = (case, D, N, B, L, nskip, disc, tile_rows, np.ndim(RM), np.ndim(RF))
+        with capi.Problem(B, D, N, Y, list(Lidx), twin.DT, RM, RF, P, [0], disc=disc, eval_kernel=5, tile_rows=tile_rows,
+                          merr_nskip=nskip) as pb:
+            assert pb.info()["eval_kernel"] == 5, tag
+            A, me, fe, g = pb.action_grad(XP, 1.7)
+        for b in range(B):
+            opb = va_oracle.Problem(D, N, Y, list(Lidx), twin.DT, RM, RF, P[b], [0], disc=disc, merr_nskip=nskip)
+            Ao, meo, feo, go = opb.action_grad(XP[b], 1.7)
+            assert abs(A[b] - Ao) <= RTOL_A * abs(Ao), tag
+            assert abs(me[b] - meo) <= RTOL_A * max(abs(meo), abs(Ao)) and abs(fe[b] - feo) <= RTOL_A * abs(feo), tag
+            err = np.abs(g[b] - go)
+            assert err.max() <= RTOL_G * np.abs(go).max(), tag + (int(err.argmax()), err.max())

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
         const char *xrow = reinterpret_cast<const char *>(xg + (ptrdiff_t)rs * D);   // uniform: first row of slot 0
         const char *drow = reinterpret_cast<const char *>(dg + (ptrdiff_t)rs * D);
         const char *yrow = reinterpret_cast<const char *>(dv.pp.Y + (ptrdiff_t)rs * L);
-        const char *wfrow = reinterpret_cast<const char *>(dv.pp.rf0_arr + (ptrdiff_t)rs * D);       // (WARR only)
+        const char *wfrow = WARR ? reinterpret_cast<const char *>(dv.pp.rf0_arr + (ptrdiff_t)rs * D) : nullptr;
         const size_t xstep = (size_t)2 * D * 8, ystep = (size_t)2 * L * 8;
         // WARR: the lane's data row of the next slot to be requested = its model row / nskip, kept as quotient and
         // remainder (slots are requested in order, two model rows apart)
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
                 if (dma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(drow + k * xstep + xoff), (lds_void_t *)(dring + pos * SLOTX), 16, 0, 0);
             }
             if constexpr (WARR) {
-                const size_t yo = (size_t)((ptrdiff_t)ynd * L * 8) + ycol;
+                const ptrdiff_t yo = (ptrdiff_t)ynd * L * 8 + (ptrdiff_t)ycol;
                 if (ydma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(reinterpret_cast<const char *>(dv.pp.Y) + yo), (lds_void_t *)(yring + pos * SLOTY), 16, 0, 0);
                 if (dma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(wfrow + k * xstep + xoff), (lds_void_t *)(wfring + pos * SLOTX), 16, 0, 0);
                 if (ydma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(reinterpret_cast<const char *>(dv.pp.rm_arr) + yo), (lds_void_t *)(wmring + pos * SLOTY), 16, 0, 0);
