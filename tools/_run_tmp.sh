@@ -1,7 +1,11 @@
-one() { python bench.py --no-cpu --no-extra --steps 3000 --warmup 300 "$@" 2>/dev/null | python -c "
+one() { python bench.py --workload c4 --no-cpu --no-extra --steps 100 --warmup 20 "$@" 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        j=json.loads(l); r=j['roofline']; c=j['config']; print('kernel_us=%6.3f frac=%.3f tune=%s' % (r['kernel_us'], r['frac'], c['tune']))
+        j=json.loads(l); r=j['roofline']; c=j['config']; print('$TAG %-36s kernel_us=%7.2f frac=%.3f seg_rows=%d' % (r['kernel'], r['kernel_us'], r['frac'], c['tile_rows']))
 "; }
-one; for p in 2 3 4 5 7 9 -2 -4 -6; do one --tune prio=$p; done; one
+for rep in 1 2; do
+TAG=ring4 one
+TAG=ring6 VARANNEAL_AMD_LIB=$PWD/varanneal_amd/libvaranneal_amd_ring6.so one
+TAG=ring6-seg250 VARANNEAL_AMD_LIB=$PWD/varanneal_amd/libvaranneal_amd_ring6.so one --tile-rows 250
+done
