@@ -309,8 +309,10 @@ def timed_steps(pb, rf, steps, A, dist, world, torch, barrier):
     issued once after the timed steps and timed on its own: it is per job, not per step.  Its
     buffers and the communicator are set up (and warmed) before the clock starts."""
     recv = mine = None
+    cdev = "cuda"
     if dist is not None:
-        mine = torch.from_numpy(np.ascontiguousarray(A)).cuda()
+        cdev = "cuda" if dist.get_backend() == "nccl" else "cpu"      # (gloo: the one-GPU rehearsal of the multi-rank path)
+        mine = torch.from_numpy(np.ascontiguousarray(A)).to(cdev)
         recv = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
         dist.all_gather_into_tensor(recv, mine)          # warm-up: communicator, RCCL kernels
     barrier()
@@ -324,7 +326,7 @@ def timed_steps(pb, rf, steps, A, dist, world, torch, barrier):
         dist.all_gather_into_tensor(recv, mine)          # the single RCCL gather of the job
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t1) * 1e3
-        tmax = torch.tensor([wall, kernel_ms, gather_ms], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([wall, kernel_ms, gather_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall, kernel_ms, gather_ms = (float(v) for v in tmax)
     return wall, kernel_ms, gather_ms
@@ -503,9 +505,14 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of a multi-rank run (nccl = RCCL; gloo only for the CPU rehearsal "
                          "of the launcher in tests/)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of the multi-rank timed path on a box with ONE GPU: every rank runs its shard on cuda:0 "
+                         "(needs --backend gloo: RCCL refuses two ranks on one device); recorded in config.rehearsal")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.share_gpu and args.backend != "gloo":
+        ap.error("--share-gpu needs --backend gloo")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: start the N ranks (one process per GPU) as CHILD processes of a
@@ -530,11 +537,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:
             sys.stderr.write("bench.py: process group has %d ranks, --gpus %d\n" % (dist.get_world_size(), args.gpus))
             sys.exit(2)
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     if args.workload in NNET_WORKLOADS:
@@ -586,7 +598,8 @@ def main():
             "config": {"workload": w["name"], "seeds_per_gpu": B, "D": D, "N": N, "L": len(Lidx),
                        "disc": "trapezoid", "tile_rows": info["tile_rows"], "ntiles": info["ntiles"],
                        "parallelism": "seeds sharded, %d per GPU" % B, "final_gather_ms": gather_ms,
-                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "env": env_set, "tune": tune},
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "env": env_set, "tune": tune,
+                       "rehearsal": ("%d ranks share one GPU, collectives over gloo" % world) if args.share_gpu else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "step": "complete S1 evaluation: A, me, fe formed in the same launch (va_epilogue.h)",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(w["name"]),

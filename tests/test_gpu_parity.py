@@ -529,3 +529,25 @@ def test_tuning_knobs_leave_every_bit_alone(capi, D, N, B):
         else:
             for a, b2 in zip(ref, got):
                 assert np.array_equal(a, b2), knobs
+
+
+def test_bench_two_ranks_share_the_gpu():
+    """the multi-rank timed path of bench.py end to end on one card: `--gpus 2 --backend gloo --share-gpu` starts two
+    ranks (children of a launcher that never touches the GPU), each runs its own 64 seeds on cuda:0 between the
+    barriers, the actions are gathered once, rank 0 prints ONE line with the whole job's throughput"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "200",
+                        "--warmup", "20", "--no-cpu", "--no-extra"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["rccl_ranks"] == 2 and rec["config"]["rehearsal"]
+    assert rec["config"]["seeds_per_gpu"] == 64 and rec["scaling"] == "weak"
+    # whole-job value = 2 x 64 seeds x steps / (max over ranks of the bracketed wall time)
+    assert abs(rec["value"] - 2 * 64 * 200 / (rec["ms_per_step"] * 1e-3 * 200)) <= 1e-6 * rec["value"]
+    assert rec["ms_per_step"] * 1e3 >= 0.9 * rec["roofline"]["kernel_us"] and rec["config"]["final_gather_ms"] > 0.0
