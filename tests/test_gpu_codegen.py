@@ -175,6 +175,47 @@ def test_bounded_device_minimiser_is_lbfgsb_step_for_step():
             assert np.abs(r["x"][B - 1] - rs.x).max() <= 1e-6
 
 
+def test_bounded_device_minimiser_random_boxes():
+    """a seeded sweep of box shapes for the device's L-BFGS-B: random finite / one-sided / absent bounds per variable,
+    variables fixed by l = u, starting points outside the box (projected first), Simpson-Hermite and trapezoid, several
+    widths -- (nit, nfev, status) and the end point of the oracle's L-BFGS-B, which is SciPy's step for step"""
+    import va_oracle
+    from varanneal_amd import twin
+    rng = np.random.RandomState(77)
+    for case in range(8):
+        D = int(rng.choice([6, 10, 20]))
+        disc = "SimpsonHermite" if case % 3 == 2 else "trapezoid"
+        N = int(rng.randint(20, 45)) | (1 if disc == "SimpsonHermite" else 0)
+        B = 2
+        t, Y, _, Lidx = twin.make_twin(D, N)
+        XP = np.empty((B, N * D + 1)); P = np.empty((B, 1))
+        for b in range(B):
+            X0, P0 = twin.initial_guess(N, D, b + case, Y, Lidx)
+            XP[b, :-1] = X0.ravel(); XP[b, -1] = P0[0]; P[b] = P0
+        bnds = []
+        for i in range(N * D + 1):
+            kind = rng.randint(0, 6)
+            c = XP[0, i]
+            if kind == 0: bnds.append((None, None))
+            elif kind == 1: bnds.append((c - rng.rand() * 2.0, None))
+            elif kind == 2: bnds.append((None, c + rng.rand() * 2.0))
+            elif kind == 3: bnds.append((c + 0.1, c + 0.1 + rng.rand()))           # the start lies outside
+            elif kind == 4 and i % 7 == 0: bnds.append((c, c))                     # fixed
+            else: bnds.append((c - rng.rand() * 3.0, c + rng.rand() * 3.0))
+        o = {'gtol': 1e-8, 'ftol': 1e-10, 'maxiter': int(rng.choice([4, 12, 30])), 'maxfun': 100000}
+        with _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc=disc, bounds=bnds) as pb:
+            r = pb.minimize_lbfgs(XP, 20.0, o)
+        lo = np.array([-np.inf if q[0] is None else q[0] for q in bnds]); hi = np.array([np.inf if q[1] is None else q[1] for q in bnds])
+        assert np.all(r["x"] >= lo) and np.all(r["x"] <= hi), case
+        for b in range(B):
+            opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[b], [0], disc=disc)
+            x, A, st, nit, nfev = opb.minimize_lbfgs(XP[b], 20.0, o, bounds=bnds, exact=True)
+            assert (r["nit"][b], r["nfev"][b], r["status"][b]) == (nit, nfev, st), (case, b, D, N, disc, o["maxiter"], r["nit"][b], nit, r["nfev"][b], nfev)
+            # (same iteration and evaluation counts; rounding differences between the two arithmetic orders grow along an
+            #  ill-conditioned run: 1.6e-8 on A after 4-30 iterations here)
+            assert abs(r["A"][b] - A) <= 1e-6 * abs(A) and np.abs(r["x"][b] - x).max() <= 1e-5, (case, b, abs(r["A"][b] - A) / abs(A))
+
+
 # ---- generated models on the wave-private column-run kernel (codegen.column_form, va_eval_plan) ---------------
 def _l96_user(t, x, p):
     """Lorenz-96 as a user would write it (not the registry's callable): traced, recognised as a stencil"""
