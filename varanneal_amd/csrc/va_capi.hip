@@ -224,10 +224,16 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
                 if (best < 0 || cost <= best) { best = cost; K = k; }
             }
         } else {
+            // a few workgroups per CU, all resident at once: the busiest CU sets the time.  Pick the K whose (workgroups per
+            // CU, rounded up) x (rows per lane + fixed per-workgroup cost) is smallest, e.g. C3 (64 seeds, N = 1000):
+            // K = 7 gives 12 tiles x 64 = 768 workgroups = exactly 3 per CU.  Simpson-Hermite (even K; 8 runs at two waves
+            // per SIMD, so only two workgroups per CU are resident): rounds of resident workgroups x rows per lane --
+            // N = 1001: K = 4 -> 2 rounds x 6 rows (11.4 us) against 2 x 8 at K = 6 (11.7) and 2 x 10 at K = 8 (12.1)
             long best = -1;
-            for (int k = 5; k <= 8; ++k) {
+            for (int k = sh ? 4 : 5; k <= 8; ++k) {
                 if (sh && (k & 1)) continue;              // Simpson-Hermite runs start on even rows
-                const long cost = ((ntl(k) + 255) / 256) * (k + 2) * 4 + (k == 6 ? 0 : 1);     // ties go to 6
+                const long per_round = sh ? 256L * (k <= 7 ? 3 : 2) : 256L;
+                const long cost = ((ntl(k) + per_round - 1) / per_round) * (k + 2) * 4 + (k == 6 ? 0 : 1);     // ties go to 6
                 if (best < 0 || cost < best) { best = cost; K = k; }
             }
         }
