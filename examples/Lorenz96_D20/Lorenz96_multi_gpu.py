@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--N", type=int, default=200)
     ap.add_argument("--nbeta", type=int, default=30)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a box with one GPU: every rank uses cuda:0 and the gather runs over gloo "
+                         "(RCCL refuses two ranks on one device)")
     args = ap.parse_args()
 
     import torch
@@ -37,8 +40,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if args.share_gpu:
+        local_rank = 0
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     D, N = args.D, args.N
     t, Y, _, Lidx = twin.make_twin(D, N)                          # identical bytes on every rank

@@ -161,3 +161,27 @@ def test_wide_models_with_per_component_weights_and_simpson_hermite():
                             disc="SimpsonHermite")
     x, A, st, nit, nfev = opb.minimize_lbfgs(XP, 1.0, opts)
     assert nit == res["builtin"][1][0][0] and abs(A - res["builtin"][0][0][0]) <= 1e-7 * abs(A)
+
+
+def test_seed_sharding_two_ranks_on_one_card(tmp_path):
+    """examples/Lorenz96_D20/Lorenz96_multi_gpu.py as a 2-rank job (`--share-gpu`: both ranks on cuda:0, the closing
+    gather over gloo) against the same seeds in one process: every seed's ladder is identical to the last bit whichever
+    rank, and whichever batch, annealed it (the reference's array job: submit_multiM.sh:14-30)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "examples", "Lorenz96_D20", "Lorenz96_multi_gpu.py")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    args = ["--seeds", "5", "--N", "100", "--nbeta", "4"]
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    # (both runs with --share-gpu: a process group over gloo -- RCCL's bootstrap alone can take minutes on a box without a network)
+    r = subprocess.run([sys.executable, script] + args + ["--share-gpu", "--out", one], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29671", script] + args + ["--share-gpu", "--out", two], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = np.load(one), np.load(two)
+    for k in ("A", "flags", "k", "nfev"):
+        assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+    assert a["A"].shape == (5, 4)
