@@ -431,3 +431,31 @@ def test_translation_invariant_models_get_a_switch_free_flat_form():
     assert abs(A[0] - A0) <= 1e-12 * abs(A0) and np.abs(g[0] - g0).max() <= 1e-10 * np.abs(g0).max()
     # a model that is not translation-invariant keeps the switch
     assert "switch (i)" in codegen.module_for(nakl, 4, 18, nstim=1, stim_ndim=1, compile=False)["text"]
+
+
+def test_linear_module_with_stimulus_and_explicit_time():
+    """a dense linear part next to a rest that reads the stimulus and the time (f(t, x, (p, stim)), va_ode.py:345-354):
+    the split leaves both in the element-wise code -- switch-free, they are the same for every component -- and the
+    emulator's gradient matches complex-step"""
+    D, NP, N = 16, 2, 25
+    C = np.random.RandomState(3).randn(D, D) / 4.0
+
+    def driven(t, x, ps):
+        p, stim = ps
+        drive = p[0] * stim * np.cos(0.3 * t)
+        return x @ C.T - p[1] * x ** 3 + drive[:, None]
+    m = codegen.module_for(driven, D, NP, nstim=1, stim_ndim=1, compile=False)
+    assert m["lin"] is not None and np.array_equal(m["lin"], C) and "switch (i)" not in m["text"]
+    rng = np.random.RandomState(0)
+    t = 0.05 * np.arange(N)
+    stim = np.sin(1.3 * t) + 0.1 * rng.randn(N)
+    Y = rng.randn(N, 4); Lidx = [1, 4, 9, 15]
+    P = np.array([0.8, 0.2])
+    XP = np.append(rng.randn(N * D), P)
+    for disc in ("trapezoid", "SimpsonHermite"):
+        fun = lambda z: va_oracle.numpy_action_generic(driven, z, D, N, Y, Lidx, 0.05, 2.0, 0.5, NP, [0, 1], P, disc, t_model=t, stim=stim)
+        g0 = va_oracle.complex_step_grad(fun, XP)
+        desc, keep = _capi.make_desc(1, D, N, Y, Lidx, 0.05, 2.0, 0.5, P[None, :], [0, 1], disc=disc, rhs=1000, t_model=t, stim=stim)
+        A, me, fe, g = emul.action_grad(desc, 8, XP[None, :], 1.0, user_header=m["header"])
+        assert abs(A[0] - fun(XP)[0]) <= 1e-12 * abs(A[0])
+        assert np.abs(g[0] - g0).max() <= 1e-10 * np.abs(g0).max()

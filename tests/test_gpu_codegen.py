@@ -545,3 +545,32 @@ def test_dense_linear_part_at_c3_shape_timed():
     A0 = va_oracle.numpy_action_generic(f, XP[5], D, N, Y, Lidx, twin.DT, 4.0, 0.3 * 2.0, 2, [0, 1], P, "trapezoid")[0]
     assert abs(A[5] - A0) <= 1e-12 * abs(A0)
     print("dense coupling D = 20, N = 1000, 64 seeds, us per complete evaluation:", {k: round(v, 2) for k, v in us.items()})
+
+
+def test_dense_linear_part_with_stimulus_and_time():
+    """the split model of tests/test_codegen.py::test_linear_module_with_stimulus_and_explicit_time on the device:
+    X C^T and S C on the matrix cores, the stimulus / time terms in the element-wise rest"""
+    D, NP, N, B = 16, 2, 25, 2
+    C = np.random.RandomState(3).randn(D, D) / 4.0
+
+    def driven(t, x, ps):
+        p, stim = ps
+        drive = p[0] * stim * np.cos(0.3 * t)
+        return x @ C.T - p[1] * x ** 3 + drive[:, None]
+    m = codegen.module_for(driven, D, NP, nstim=1, stim_ndim=1)
+    assert m["lin"] is not None
+    rng = np.random.RandomState(0)
+    t = 0.05 * np.arange(N)
+    stim = np.sin(1.3 * t) + 0.1 * rng.randn(N)
+    Y = rng.randn(N, 4); Lidx = [1, 4, 9, 15]
+    P = np.array([0.8, 0.2])
+    XP = np.concatenate([rng.randn(B, N * D), np.tile(P, (B, 1))], axis=1)
+    for disc in ("trapezoid", "SimpsonHermite", "euler"):
+        with _capi.Problem(B, D, N, Y, Lidx, 0.05, 2.0, 0.5, np.tile(P, (B, 1)), [0, 1], disc=disc, rhs=_capi.load_rhs_module(m["so"]),
+                           t_model=t, stim=stim) as pr:
+            A, me, fe, g = pr.action_grad(XP, 1.0)
+        fun = lambda z: va_oracle.numpy_action_generic(driven, z, D, N, Y, Lidx, 0.05, 2.0, 0.5, NP, [0, 1], P, disc, t_model=t, stim=stim)
+        for b in range(B):
+            assert abs(A[b] - fun(XP[b])[0]) <= 1e-12 * abs(A[b]), (disc, b)
+        g0 = va_oracle.complex_step_grad(fun, XP[1])
+        assert np.abs(g[1] - g0).max() <= 1e-10 * np.abs(g0).max(), disc
