@@ -167,9 +167,12 @@ def test_seed_sharding_two_ranks_on_one_card(tmp_path):
     """examples/Lorenz96_D20/Lorenz96_multi_gpu.py as a 2-rank job (`--share-gpu`: both ranks on cuda:0, the closing
     gather over gloo) against the same seeds in one process: every seed's ladder is identical to the last bit whichever
     rank, and whichever batch, annealed it (the reference's array job: submit_multiM.sh:14-30)"""
-    import os, subprocess, sys
+    import os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = os.path.join(root, "examples", "Lorenz96_D20", "Lorenz96_multi_gpu.py")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -179,7 +182,7 @@ def test_seed_sharding_two_ranks_on_one_card(tmp_path):
     r = subprocess.run([sys.executable, script] + args + ["--share-gpu", "--out", one], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29671", script] + args + ["--share-gpu", "--out", two], env=env, capture_output=True, text=True, timeout=600)
+                        "--master-port", str(port), script] + args + ["--share-gpu", "--out", two], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     a, b = np.load(one), np.load(two)
     for k in ("A", "flags", "k", "nfev"):
