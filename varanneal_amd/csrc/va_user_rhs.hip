@@ -41,7 +41,7 @@ int va_user_prepare_eval(const va::Dev *dv)
 // was generated (va_eval_plan; -DVA_USER_EK=3|4 -DVA_USER_DISC -DVA_USER_K -DVA_USER_W):
 //   EK = 4: the model's column form (struct RhsUserCol: a translation-invariant stencil, or a small dense
 //           system) on the wave-private kernel k_eval4; W = 1 for scalar weights
-//   EK = 5: a stencil's column form on the streaming kernel k_eval5 (wide even states, autonomous, scalar weights)
+//   EK = 5: a stencil's column form on the streaming kernel k_eval5 (wide even states, autonomous)
 //   EK = 3: a stencil's ghosted form (struct RhsUserG) on the workgroup kernel k_eval3; W = threads per workgroup
 // (eval kernel or 0, DISC, K, W, products per element [4, 5], ghost columns [3], reaches xl, xr, gl, gr [5], -, dense linear part)
 #if defined(VA_USER_EK) && VA_USER_EK == 5 && defined(VA_USER_COL)
