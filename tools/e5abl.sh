@@ -1,17 +1,16 @@
 #!/bin/bash
-# usage: tools/e5abl.sh  -- C4 on the streaming kernel: ablation builds (staging only / staging + stores / full) on one box
-one() { python bench.py --workload c4 --eval-kernel 5 --no-cpu --no-extra --steps 60 --warmup 10 "$@" 2>/dev/null | python -c "
+# usage: tools/e5abl.sh  -- C4 on the streaming kernel, measurement builds on one box (python -m varanneal_amd._build --variant e5ablN -DVA_E5_ABLATE=N):
+#   1 the staging ring alone | 2 ring + the gradient stores of a copy | 3 the ring alone, every wave reading ONE contiguous run | full
+one() { python bench.py --workload c4 --no-cpu --no-extra --steps 60 --warmup 10 "$@" 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        j=json.loads(l); r=j['roofline']; c=j['config']; print('%-10s kernel_us=%7.2f frac=%.3f seg_rows=%d env=%s' % ('$TAG', r['kernel_us'], r['frac'], c['tile_rows'], {k: v for k, v in c['env'].items() if k != 'VARANNEAL_AMD_LIB'}))
+        j=json.loads(l); r=j['roofline']; c=j['config']; print('%-10s kernel_us=%7.2f seg_rows=%d' % ('$TAG', r['kernel_us'], c['tile_rows']))
 "; }
-for ns in 3 4; do
-  for t in abl1 abl2; do TAG=$t VARANNEAL_AMD_LIB=$PWD/varanneal_amd/libvaranneal_amd_$t.so VA_E5_NSLOT=$ns one; done
-  TAG=full VA_E5_NSLOT=$ns one
+for rep in 1 2; do
+  for v in 1 2 3; do
+    so=$PWD/varanneal_amd/libvaranneal_amd_e5abl$v.so
+    [ -f $so ] && TAG=abl$v VARANNEAL_AMD_LIB=$so one "$@"
+  done
+  TAG=full one "$@"
 done
-TAG=full VA_E5_NSLOT=4 VA_E5_XDPP=0 one
-TAG=full VA_E5_NSLOT=3 one --tile-rows 250
-TAG=full VA_E5_NSLOT=3 one --tile-rows 210
-TAG=full VA_E5_NSLOT=3 one --tile-rows 158
-TAG=full VA_E5_NSLOT=4 one --tile-rows 626
