@@ -281,3 +281,38 @@ def test_random_shapes_against_the_oracle(capi):
             assert abs(me[b] - meo) <= RTOL_A * max(abs(meo), abs(Ao)) and abs(fe[b] - feo) <= RTOL_A * abs(feo), tag
             err = np.abs(g[b] - go)
             assert err.max() <= RTOL_G * np.abs(go).max(), tag + (int(err.argmax()), err.max())
+
+
+@pytest.mark.parametrize("disc", ["SimpsonHermite", "euler"])
+def test_line_search_launches_with_weights_and_sparse_data(capi, disc):
+    """minimisation on the streaming kernel with everything at once: per-row RF and RM weights, data at every 2nd model
+    time, an odd number of observed columns, several segments -- the iteration and evaluation counts of the tile kernel
+    and of the oracle, the same end point"""
+    import va_oracle
+    from varanneal_amd import twin
+    D, Nd, nskip, B = 200, 61, 2, 2
+    N = (Nd - 1) * nskip + 1
+    rng = np.random.RandomState(12)
+    L = 41
+    Lidx = np.sort(rng.choice(D, L, replace=False))
+    t, Yfull, _, _ = twin.make_twin(D, N, Lidx=list(Lidx))
+    Y = Yfull[::nskip]
+    RM = 4.0 * (0.5 + rng.rand(Nd, L))
+    RF = 4e-6 * (0.5 + rng.rand(N - 1, D))
+    XP = np.empty((B, N * D + 1)); P = np.empty((B, 1))
+    for b in range(B):
+        X0, P0 = twin.initial_guess(N, D, b)
+        XP[b, :-1] = X0.ravel(); XP[b, -1] = P0[0]; P[b] = P0
+    o = dict(OPTS, maxiter=20)
+    res = {}
+    for ek in (5, 3):
+        with capi.Problem(B, D, N, Y, list(Lidx), twin.DT / nskip, RM, RF, P, [0], disc=disc, eval_kernel=ek, merr_nskip=nskip,
+                          tile_rows=(40 if ek == 5 else 0)) as pb:
+            assert pb.info()["eval_kernel"] == ek
+            res[ek] = pb.minimize_lbfgs(XP, 1.5 ** 4, o)
+    assert np.array_equal(res[5]["nit"], res[3]["nit"]) and np.array_equal(res[5]["nfev"], res[3]["nfev"])
+    for b in range(B):
+        opb = va_oracle.Problem(D, N, Y, list(Lidx), twin.DT / nskip, RM, RF, P[b], [0], disc=disc, merr_nskip=nskip)
+        x, A, st, nit, nfev = opb.minimize_lbfgs(XP[b], 1.5 ** 4, o)
+        assert (res[5]["nit"][b], res[5]["nfev"][b], res[5]["status"][b]) == (nit, nfev, st), (disc, b)
+        assert abs(res[5]["A"][b] - A) <= 1e-6 * abs(A) and np.abs(res[5]["x"][b] - x).max() <= 1e-6
