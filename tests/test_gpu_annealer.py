@@ -188,3 +188,32 @@ def test_seed_sharding_two_ranks_on_one_card(tmp_path):
     for k in ("A", "flags", "k", "nfev"):
         assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
     assert a["A"].shape == (5, 4)
+
+
+def test_wide_model_with_a_finer_model_grid_through_the_drop_in():
+    """dt_model = dt_data / 2 at D = 100 (va_ode.py:555-558: a measurement at every second model time), trapezoid and
+    Simpson-Hermite: the streaming kernel (data rows by quotient / remainder, weight 0 between measurements); first
+    rungs against the oracle's minimisation"""
+    import va_oracle
+    from varanneal_amd import twin, va_ode
+    D, Nd, B = 100, 61, 2
+    N = 2 * (Nd - 1) + 1
+    Lidx = list(range(0, D, 4))
+    t, Yfull, _, _ = twin.make_twin(D, N, Lidx=Lidx, dt=twin.DT / 2)
+    Y, td = Yfull[::2], t[::2]
+    X0 = np.empty((B, N, D)); P0 = np.empty((B, 1))
+    for s in range(B):
+        X0[s], P0[s] = twin.initial_guess(N, D, s, Y, Lidx, nskip=2)
+    opts = {'gtol': 1e-8, 'ftol': 1e-8, 'maxiter': 12, 'maxfun': 1000}
+    for disc in ("trapezoid", "SimpsonHermite"):
+        a = va_ode.Annealer()
+        a.set_model(twin.l96, D)
+        a.set_data(Y, t=td)
+        a.anneal(X0.copy(), P0.copy(), 1.5, [0, 1], 4.0, 4e-6, Lidx, [0], dt_model=twin.DT / 2, disc=disc, opt_args=opts, verbose=False)
+        assert a._pb.info()["eval_kernel"] == 5 and a.merr_nskip == 2 and a.N_model == N
+        A_dev, nit_dev = a.A_array.copy(), a.nit_array.copy()
+        a.close()
+        for s in range(B):
+            opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT / 2, 4.0, 4e-6, P0[s], [0], disc=disc, merr_nskip=2)
+            x, A, st, nit, nfev = opb.minimize_lbfgs(np.append(X0[s].ravel(), P0[s]), 1.0, opts)
+            assert nit == nit_dev[s][0] and abs(A - A_dev[s][0]) <= 1e-7 * abs(A), (disc, s)
