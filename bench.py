@@ -53,6 +53,7 @@ F64_MFMA_PEAK_TFLOPS = 78.6    # MI355X FP64 matrix = FP64 vector rate (half the
                                # MI355X_MICROARCH.md; v_mfma_f64_16x16x4_f64: 2048 flop / 64 cycles / SIMD)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 RF_SCALE = 1.5 ** 15           # mid-ladder RF (value does not change the work)
+RAMP_MS = 2.0                  # untimed launches of the same kernel before a clock starts: the GPU's clocks ramp under load
 
 
 def bytes_alg(B, N, D, NPest, N_data, L):
@@ -133,6 +134,29 @@ def cpu_baseline(D, N, Y, Lidx, XP, P, budget_s=10.0):
                       % (n, D, N, dt, os.cpu_count() or 0)}
 
 
+def cpu_baseline_numpy(D, N, Y, Lidx, XP, P, budget_s=3.0):
+    """the array-op-for-array-op NumPy twin of the reference's action
+    (oracle/va_oracle.py numpy_action follows varanneal/va_ode.py:130-234, 358-380 line by line) -- the VALUE only,
+    as the reference's own `A` computes it; the reference then needs 2 forward + 1 reverse ADOL-C tape sweeps per
+    (A, grad A) on top (_autodiffmin.py:57-58) and re-records the tape at every beta step (va_ode.py:786): quoted
+    cost structure, not re-measured (ADOL-C exists on no box of this pipeline)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import va_oracle
+    from varanneal_amd import twin
+    pb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[0], [0], disc="trapezoid")
+    pb.numpy_action(XP[0], RF_SCALE)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        pb.numpy_action(XP[n % len(XP)], RF_SCALE)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "A-only evals/s", "cores": 1, "kind": "port (NumPy twin of va_ode.py:130-234)",
+            "sample": "%d action VALUES (no gradient) of the same D=%d N=%d paths in %.1f s" % (n, D, N, dt),
+            "reference_cost_structure": "quoted, not measured: each (A, grad A) = 2 forward + 1 reverse sweeps of the ADOL-C "
+                                        "tape (_autodiffmin.py:57-58); the tape is re-recorded in Python at every beta step "
+                                        "(va_ode.py:786, _autodiffmin.py:79-80; BASELINE.md section 1: 74 % of the published run's wall time)"}
+
+
 def usable_cpus():
     """host CPUs this process may actually use: its affinity mask, capped by the container's CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -173,6 +197,15 @@ def cpu_baseline_all(D, N, Y, Lidx, XP, P, budget_s=8.0):
                       "threads (%d usable of %d host cores)" % (n, D, N, dt, nt, usable_cpus(), os.cpu_count() or 0)}
 
 
+def event_timed(pb, rf, steps):
+    """seconds per launch by HIP events: graph prepared, clocks ramped by the same launches (RAMP_MS), then `steps`"""
+    pb.eval_timed_prepare(rf, steps)
+    ms = 0.0
+    while ms < RAMP_MS:
+        ms += pb.eval_timed(rf, steps)
+    return pb.eval_timed(rf, steps) * 1e-3 / steps
+
+
 def extra_c4(device, steps=60):
     """BASELINE config 4 as one GPU's shard: D=200, N=5000, L=80, 64 seeds; complete evaluations."""
     from varanneal_amd import _capi, twin
@@ -182,8 +215,7 @@ def extra_c4(device, steps=60):
     with _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", device=device) as pb:
         info = pb.info()
         pb.action_grad(XP, RF_SCALE)
-        pb.eval_timed(RF_SCALE, 10)
-        ks = pb.eval_timed(RF_SCALE, steps) * 1e-3 / steps
+        ks = event_timed(pb, RF_SCALE, steps)
     balg = bytes_alg(B, N, D, 1, N, len(Lidx))
     return {"workload": w["name"], "kernel": kernel_name(D, info) + ("" if B * info["ntiles"] <= 2048 else " + k_finalize_eval"),
             "traffic": pmc_traffic(w["name"]),
@@ -210,8 +242,7 @@ def extra_variant(device, steps=1000, **kw):
     with _capi.Problem(B, D, N, Y, Lidx, twin.DT, RM, RF0, P, [0], disc=disc, merr_nskip=nskip, device=device, tile_rows=kw.get("tile_rows", 0)) as pb:
         info = pb.info()
         pb.action_grad(XP, RF_SCALE)
-        pb.eval_timed(RF_SCALE, max(steps // 10, 2))
-        ks = pb.eval_timed(RF_SCALE, steps) * 1e-3 / steps
+        ks = event_timed(pb, RF_SCALE, steps)
     balg = bytes_alg(B, N, D, 1, Y.shape[0], len(Lidx)) + (8 * (N - 1) * D if kw.get("rf_vec") else 0) + (8 * Y.size if kw.get("rm_vec") else 0)
     return {"workload": "lorenz96_D%d_N%d_B%d_%s%s%s%s" % (D, N, B, disc, "_rfvec" if kw.get("rf_vec") else "", "_rmvec" if kw.get("rm_vec") else "",
                                                           "_nskip%d" % nskip if nskip > 1 else ""),
@@ -233,8 +264,7 @@ def extra_linear(device, steps=200):
     with _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 0.3, P, [0, 1], disc="trapezoid", rhs=_capi.load_rhs_module(m["so"]), device=device) as pb:
         info = pb.info()
         pb.action_grad(XP, 2.0)
-        pb.eval_timed(2.0, max(steps // 10, 2))
-        ks = pb.eval_timed(2.0, steps) * 1e-3 / steps
+        ks = event_timed(pb, 2.0, steps)
     flops = 4.0 * N * D * D * B
     return {"workload": "dense_coupling_D%d_N%d_B%d_trapezoid" % (D, N, B), "linear_part_on_mfma": m["lin"] is not None,
             "eval_kernel": info["eval_kernel"], "tile_rows": info["tile_rows"], "us_per_eval_launch": ks * 1e6, "evals_per_s": B / ks,
@@ -258,8 +288,7 @@ def extra_nnet(device, key, steps):
     rf = 1.1 ** 100
     with _capi.NnetProblem(B, s, din, dout, [np.arange(s[0]), np.arange(s[-1])], RM, RF0, P, Pidx, device=device) as pb:
         pb.action_grad(XP, rf)
-        pb.eval_timed(rf, max(steps // 10, 2))
-        ks = pb.eval_timed(rf, steps) * 1e-3 / steps
+        ks = event_timed(pb, rf, steps)
     flops = B * M * float(np.sum(3 * 2 * s[1:] * s[:-1]))
     return {"workload": w["name"], "us_per_eval_launch": ks * 1e6, "evals_per_s": B / ks, "flops_alg_per_launch": flops,
             "achieved_TFLOPs": flops / ks / 1e12, "frac_of_f64_mfma_peak": flops / ks / 1e12 / F64_MFMA_PEAK_TFLOPS}
@@ -302,9 +331,12 @@ def extra_ladder(device, D, N, B, Y, Lidx, XP, P, nbeta=30):
                     "seed batch sit in the 256 MiB Infinity Cache, so rates above the HBM figure are possible"}
 
 
-def timed_steps(pb, rf, steps, A, dist, world, torch, barrier):
+def timed_steps(pb, rf, steps, warmup, A, dist, world, torch, barrier):
     """EXACTLY `steps` batched evaluations between two (barrier + synchronize) brackets; returns
-    (wall seconds, kernel ms by HIP events, gather ms), each the MAX over ranks.  The run's one
+    (wall seconds, kernel ms by HIP events, gather ms, ramp launches), the times the MAX over ranks.  Before the
+    clock starts: the graph of the timed call's chunk of launches is captured, instantiated and uploaded
+    (va_eval_timed_prepare), and the same launches run untimed -- at least `warmup` of them and at least RAMP_MS of
+    device time -- so that what is timed is `steps` launches at the clocks a running job sees.  The run's one
     collective -- the RCCL all-gather of the per-seed actions that closes a multi-GPU job -- is
     issued once after the timed steps and timed on its own: it is per job, not per step.  Its
     buffers and the communicator are set up (and warmed) before the clock starts."""
@@ -315,6 +347,11 @@ def timed_steps(pb, rf, steps, A, dist, world, torch, barrier):
         mine = torch.from_numpy(np.ascontiguousarray(A)).to(cdev)
         recv = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
         dist.all_gather_into_tensor(recv, mine)          # warm-up: communicator, RCCL kernels
+    pb.eval_timed_prepare(rf, steps)
+    ramp, ramp_ms = 0, 0.0
+    while ramp < max(warmup, 1) or ramp_ms < RAMP_MS:
+        ramp_ms += pb.eval_timed(rf, steps)              # (same chunk as the timed call: its graph is replayed, not rebuilt)
+        ramp += steps
     barrier()
     t0 = time.perf_counter()
     kernel_ms = pb.eval_timed(rf, steps)                 # HIP events on the launch stream
@@ -329,7 +366,7 @@ def timed_steps(pb, rf, steps, A, dist, world, torch, barrier):
         tmax = torch.tensor([wall, kernel_ms, gather_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall, kernel_ms, gather_ms = (float(v) for v in tmax)
-    return wall, kernel_ms, gather_ms
+    return wall, kernel_ms, gather_ms, ramp
 
 
 def nnet_main(args, rank, local_rank, world, dist, torch):
@@ -354,8 +391,7 @@ def nnet_main(args, rank, local_rank, world, dist, torch):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-    pb.eval_timed(rf, max(args.warmup, 1))
-    wall, kernel_ms, gather_ms = timed_steps(pb, rf, args.steps, A, dist, world, torch, barrier)
+    wall, kernel_ms, gather_ms, ramp = timed_steps(pb, rf, args.steps, args.warmup, A, dist, world, torch, barrier)
     if rank != 0:
         return
     # three products per layer transition: Z = X W^T, dX = delta W, dW = delta^T X
@@ -371,9 +407,10 @@ def nnet_main(args, rank, local_rank, world, dist, torch):
         "config": {"workload": w["name"], "seeds_per_gpu": B, "structure": [int(v) for v in s], "M": M,
                    "n_var": int(XP.shape[1]), "parallelism": "seeds sharded, %d per GPU" % B,
                    "final_gather_ms": gather_ms, "rccl_ranks": dist.get_world_size() if dist is not None else 1,
-                   "env": bench_env()},
+                   "ramp_launches": ramp, "env": bench_env()},
         "roofline": {"bound": "mfma", "achieved": flops / ks / 1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": flops / ks / 1e12 / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "frac": flops / ks / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                     "frac_wall": flops * args.steps / wall / 1e12 / F64_MFMA_PEAK_TFLOPS, "traffic": None,
                      "kernel": "k_nnet_fwd + k_nnet_bwd_x + k_nnet_bwd_w (+ pack, pred): one evaluation",
                      "kernel_us": ks * 1e6, "flops_alg_per_launch": flops, "bytes_alg_per_launch": balg,
                      "hbm_frac_of_8TBs": balg / ks / 1e9 / HBM_PEAK_GBS},
@@ -482,7 +519,7 @@ def dry_run(args, rank, world, env_set):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks of the job, one per GPU (default: WORLD_SIZE if the job was launched already, else 1)")
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS) + sorted(NNET_WORKLOADS))
@@ -509,6 +546,8 @@ def main():
                     help="rehearsal of the multi-rank timed path on a box with ONE GPU: every rank runs its shard on cuda:0 "
                          "(needs --backend gloo: RCCL refuses two ranks on one device); recorded in config.rehearsal")
     args = ap.parse_args()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))      # (torchrun ... bench.py without --gpus: the job's size)
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     if args.share_gpu and args.backend != "gloo":
@@ -582,8 +621,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pb.eval_timed(RF_SCALE, max(args.warmup, 1))
-    wall, kernel_ms, gather_ms = timed_steps(pb, RF_SCALE, args.steps, A, dist, world, torch, barrier)
+    wall, kernel_ms, gather_ms, ramp = timed_steps(pb, RF_SCALE, args.steps, args.warmup, A, dist, world, torch, barrier)
 
     if rank == 0:
         balg = bytes_alg(B, N, D, 1, N, len(Lidx))
@@ -598,11 +636,14 @@ def main():
             "config": {"workload": w["name"], "seeds_per_gpu": B, "D": D, "N": N, "L": len(Lidx),
                        "disc": "trapezoid", "tile_rows": info["tile_rows"], "ntiles": info["ntiles"],
                        "parallelism": "seeds sharded, %d per GPU" % B, "final_gather_ms": gather_ms,
-                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "env": env_set, "tune": tune,
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "ramp_launches": ramp, "env": env_set, "tune": tune,
                        "rehearsal": ("%d ranks share one GPU, collectives over gloo" % world) if args.share_gpu else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "step": "complete S1 evaluation: A, me, fe formed in the same launch (va_epilogue.h)",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(w["name"]),
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # the same fraction from the host's wall clock around the K steps (the clock `value` uses)
+                         "frac_wall": balg * args.steps / wall / 1e9 / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(w["name"]),
                          "kernel": kernel_name(D, info, args.generated),
                          "kernel_us": kern_s * 1e6, "bytes_alg_per_launch": balg},
             "cpu_baseline": None,
@@ -610,6 +651,7 @@ def main():
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(D, N, Y, Lidx, XP, P)
             out["cpu_baseline_all"] = cpu_baseline_all(D, N, Y, Lidx, XP, P)
+            out["cpu_baseline_numpy"] = cpu_baseline_numpy(D, N, Y, Lidx, XP, P)
         if world == 1 and args.workload == "c3" and not args.no_extra:
             pb.close()
             out["extra"] = {"ladder": extra_ladder(local_rank, D, N, B, Y, Lidx, XP, P),

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VA_ABI_VERSION 11
+#define VA_ABI_VERSION 12
 
 enum { VA_OK = 0, VA_EINVAL = -1, VA_ENOMEM = -2, VA_EHIP = -3, VA_EUNSUPPORTED = -4,
        VA_ESTATE = -5 };
@@ -149,7 +149,14 @@ int va_problem_info(va_handle h, int64_t *n_var, int64_t *ld_internal, int32_t *
 #define VA_TUNE_GRAD_SC1 2   /* 1: gradient stores write through (default with FOLD)                                   */
 #define VA_TUNE_PRIO 3       /* 1: later-dispatched workgroups of a CU issue at higher priority (default)            */
 #define VA_TUNE_GRAPH 4      /* 1: ladder cycles and timed evaluations are replayed from a hipGraph (default)        */
+#define VA_TUNE_PERSIST 5    /* 1: ladders of few seeds on short paths run as ONE cooperative launch of the persistent
+                              * per-seed kernel (csrc/va_persist.h: every vector of the minimisation resident in LDS),
+                              * when the problem is eligible (default); 0: always the three-launch cycle.  Same
+                              * arithmetic, different order of the partial sums: results agree to rounding, not bit for bit */
 int va_problem_tune(va_handle h, int32_t what, int32_t value);
+/* 1 if va_anneal / va_minimize_lbfgs on this handle run the persistent per-seed kernel, with its geometry
+ * (workgroups per seed, time rows per workgroup); 0 otherwise. */
+int va_problem_persistent(va_handle h, int32_t *workgroups_per_seed, int32_t *rows_per_workgroup);
 
 /* Which evaluation kernel the handle runs (the values of va_problem_desc.eval_kernel: 1 flat,
  * 3 workgroup column runs, 4 wave-private column runs, 5 streaming column strips) and the rows per lane run
@@ -193,11 +200,16 @@ int va_get_minpath(va_handle h, int32_t seed, int32_t beta_idx, double *out);
  * the last va_action_grad / va_anneal call), bracketed by HIP events on the handle's stream;
  * returns elapsed ms. */
 int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms);
+/* Everything va_eval_timed(h, rf_scale, iters, ..) would otherwise do before its first launch -- arming the seeds,
+ * capturing / instantiating / uploading the hipGraph of the chunk of launches it replays -- done now, so that a caller
+ * who brackets va_eval_timed with a wall clock of its own (bench.py) times the launches only.  The graph is keyed on
+ * the bytes of the device image it captured: any later change of the handle makes va_eval_timed rebuild it. */
+int va_eval_timed_prepare(va_handle h, double rf_scale, int32_t iters);
 
 /* Measurement hook for bench.py: `iters` launches each of the two L-BFGS vector kernels (k_update,
  * k_direction) with every seed's history full (lbfgs_m pairs), bracketed by HIP events; returns the
  * elapsed ms of each.  Overwrites the resident paths and the L-BFGS state: evaluate / anneal again
- * from host data afterwards. */
+ * from host data afterwards.  VA_EUNSUPPORTED for a bounded handle (its third launch is k_lbfgsb_dir). */
 int va_lbfgs_timed(va_handle h, int32_t iters, float *ms_update, float *ms_direction);
 /* Measurement only: `iters` evaluation launches as a ladder cycle makes them (every seed at a line-search trial
  * point x + stp*d, the tail runs one line-search step), each after re-arming the seeds; *ms_eval = the launches'
@@ -210,6 +222,10 @@ int va_read_eval_outputs(va_handle h, double *A, double *me, double *fe, double 
 
 /* Profiling hook: copy the first n doubles of the L-BFGS inner-product partial table to the host. */
 int va_debug_read_partials(va_handle h, double *out, int64_t n);
+
+/* Profiling hook: the first n doubles of the persistent kernel's update-partial table (a -DVA_PZ_STAMPS measurement
+ * build of the library leaves its per-phase tick sums there). */
+int va_debug_read_persist(va_handle h, double *out, int64_t n);
 
 /* Cumulative counters since create: batched eval launches, seed-evaluations,
  * L-BFGS cycles. */

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(capi):
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(capi.EXPORTS) == names
-    assert lib.va_abi_version() == capi.ABI_VERSION == 11
+    assert lib.va_abi_version() == capi.ABI_VERSION == 12
 
 
 def test_rhs_module_loader_rejects_bad_paths(capi, tmp_path):

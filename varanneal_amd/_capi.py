@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VARANNEAL_AMD_LIB", os.path.join(_HERE, "libvaranneal_amd.so"))   # (env: diagnostic builds)
 
 VA_OK = 0
-ABI_VERSION = 11         # VA_ABI_VERSION of include/varanneal_amd.h
+ABI_VERSION = 12         # VA_ABI_VERSION of include/varanneal_amd.h
 ERRNAMES = {-1: "VA_EINVAL", -2: "VA_ENOMEM", -3: "VA_EHIP", -4: "VA_EUNSUPPORTED", -5: "VA_ESTATE"}
 DISC = {"euler": 0, "trapezoid": 1, "SimpsonHermite": 2, "forwardmap": 3}
 RHS = {"lorenz96": 0}
@@ -198,6 +198,7 @@ def lib():
                             C.POINTER(LbfgsOpts), c_dp, c_dp, c_ip, c_ip, c_lp, c_dp]
     L.va_get_minpath.argtypes = [h, C.c_int32, C.c_int32, c_dp]
     L.va_eval_timed.argtypes = [h, C.c_double, C.c_int32, C.POINTER(C.c_float)]
+    L.va_eval_timed_prepare.argtypes = [h, C.c_double, C.c_int32]
     L.va_get_counters.argtypes = [h, c_lp, c_lp, c_lp]
     L.va_comm_unique_id.argtypes = [C.c_char_p]
     L.va_comm_create.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(h)]
@@ -210,9 +211,13 @@ def lib():
     L.va_debug_read_partials.argtypes = [h, c_dp, C.c_int64]
     L.va_problem_eval_kernel.argtypes = [h, c_ip, c_ip]
     L.va_problem_tune.argtypes = [h, C.c_int32, C.c_int32]
+    L.va_debug_read_persist.argtypes = [h, c_dp, C.c_int64]
+    L.va_debug_read_persist.restype = C.c_int
+    L.va_problem_persistent.argtypes = [h, c_ip, c_ip]
+    L.va_problem_persistent.restype = C.c_int
     for fn in ("va_device_count", "va_rhs_load_module", "va_act_load_module", "va_eval_plan", "va_eval_plan_reach", "va_problem_eval_kernel", "va_problem_tune", "va_problem_tune", "va_problem_create", "va_nnet_problem_create",
                "va_problem_info", "va_action_grad",
-               "va_minimize_lbfgs", "va_anneal", "va_get_minpath", "va_eval_timed",
+               "va_minimize_lbfgs", "va_anneal", "va_get_minpath", "va_eval_timed", "va_eval_timed_prepare",
                "va_get_counters", "va_debug_read_partials", "va_read_eval_outputs", "va_lbfgs_timed", "va_eval_ls_timed",
                "va_comm_unique_id", "va_comm_create", "va_gather_results"):
         getattr(L, fn).restype = C.c_int
@@ -222,7 +227,7 @@ def lib():
 
 EXPORTS = ["va_abi_version", "va_last_error", "va_device_count", "va_rhs_load_module", "va_act_load_module", "va_eval_plan", "va_eval_plan_reach", "va_problem_eval_kernel", "va_problem_tune", "va_problem_create",
            "va_problem_destroy", "va_problem_info", "va_action_grad", "va_minimize_lbfgs",
-           "va_anneal", "va_get_minpath", "va_eval_timed", "va_get_counters", "va_nnet_problem_create", "va_debug_read_partials",
+           "va_anneal", "va_get_minpath", "va_eval_timed", "va_eval_timed_prepare", "va_problem_persistent", "va_debug_read_persist", "va_get_counters", "va_nnet_problem_create", "va_debug_read_partials",
            "va_read_eval_outputs", "va_lbfgs_timed", "va_eval_ls_timed", "va_comm_unique_id", "va_comm_create", "va_comm_destroy",
            "va_gather_results"]
 
@@ -353,7 +358,19 @@ class Problem(object):
         return dict(n_var=nv.value, ld=ld.value, tile_rows=T.value, ntiles=nt.value, eval_kernel=ek.value,
                     run_rows=rr.value)
 
-    TUNE = {"fold": 1, "grad_sc1": 2, "prio": 3, "graph": 4}      # VA_TUNE_* of include/varanneal_amd.h
+    TUNE = {"fold": 1, "grad_sc1": 2, "prio": 3, "graph": 4, "persist": 5}      # VA_TUNE_* of include/varanneal_amd.h
+
+    def debug_read_persist(self, n):
+        out = np.empty(n)
+        check(self._L.va_debug_read_persist(self._h, out.ctypes.data_as(c_dp), n))
+        return out
+
+    def persistent(self):
+        """(workgroups per seed, time rows per workgroup) when ladders on this handle run the persistent per-seed
+        kernel (csrc/va_persist.h), else None"""
+        g, t = C.c_int32(), C.c_int32()
+        on = self._L.va_problem_persistent(self._h, C.byref(g), C.byref(t))
+        return (g.value, t.value) if on else None
 
     def tune(self, **knobs):
         """performance knobs that change no result: fold= (tail inside the evaluation kernel), grad_sc1=, prio=, graph="""
@@ -410,6 +427,10 @@ class Problem(object):
                                 nfev.ctypes.data_as(c_lp), mp.ctypes.data_as(c_dp) if want_paths else None))
         return dict(x=XP if xp_device is None else None, A=ame[:, :, 0], me=ame[:, :, 1],
                     fe=ame[:, :, 2], pest=pest, status=st, nit=nit, nfev=nfev, minpaths=mp)
+
+    def eval_timed_prepare(self, rf_scale, iters):
+        """arm the seeds and build / upload the hipGraph eval_timed(rf_scale, iters) replays (nothing timed)"""
+        check(self._L.va_eval_timed_prepare(self._h, float(rf_scale), int(iters)))
 
     def eval_timed(self, rf_scale, iters):
         ms = C.c_float()

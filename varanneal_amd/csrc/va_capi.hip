@@ -6,6 +6,7 @@
 // until every seed has climbed its whole RF ladder.  No per-iteration host sync:
 // the host only polls a device counter of unfinished seeds every few cycles.
 #include <dlfcn.h>
+#include <link.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,6 +21,7 @@
 #include "va_device.h"
 #include "va_nnet.h"
 #include "va_eval_flat.h"
+#include "va_persist.h"
 
 using namespace va;
 
@@ -57,6 +59,7 @@ struct UserRhs {
     void *dl = nullptr;
     void (*launch)(const Dev *, void *) = nullptr;
     int (*prepare)(const Dev *) = nullptr;
+    int (*seed_kernel)(const Dev *, int, void *) = nullptr;      // the persistent per-seed ladder kernel (va_persist.h), if the module carries it
     int NP = 0, D = 0, NSTIM = 0;
 };
 struct UserAct {
@@ -75,12 +78,21 @@ struct va_problem_s {
     int device = 0, rhs = 0, keep_paths = 0;
     void (*user_launch)(const Dev *, void *) = nullptr;
     int (*user_prepare)(const Dev *) = nullptr;
+    int (*user_seed)(const Dev *, int, void *) = nullptr;
     NnetActLaunch user_act = nullptr;  // generated activation module's launcher (nn.act >= NNET_USER)
+    // few seeds, short paths: the whole ladder in ONE cooperative launch, every vector of the minimisation resident in
+    // the LDS of pz_G workgroups per seed (va_persist.h); chosen at create when the slices fit and all are co-resident
+    bool persist = false, tune_persist = true;
+    int pz_G = 0, pz_T = 0;
+    void *pz_misc = nullptr;           // device: [abort flag (int), pad, cycles (unsigned long long)]
     bool is_nnet = false;              // feed-forward-network action (va_nnet.hip) instead of an ODE path
     bool fold = false;                 // the evaluation kernel runs the tail itself (last arriver of each seed)
     bool tune_graph = true;            // ladder cycles / timed evaluations replayed from a hipGraph (va_problem_tune)
     hipGraphExec_t timed_gexec = nullptr;   // va_eval_timed's chunk of launches
     int timed_chunk = 0;
+    Dev timed_dv;                      // the device image the chunk was captured with (kernels take it by value):
+    NnetDev timed_nn;                  //   the graph is replayed only while h->dv / h->nn still equal these bytes
+    double timed_armed_rf = -1.0;      // >= 0: every seed sits in PH_START at this rf_scale (S1 launches leave it so)
     NnetDev nn;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -110,6 +122,7 @@ namespace {
 // evaluation is several kernels, so its tail stays a launch of its own.
 void run_eval(va_handle h, int epi)
 {
+    if (epi != EPI_FINALIZE) h->timed_armed_rf = -1.0;      // (line-search launches move the seeds' states)
     h->dv.lsrun = epi == EPI_LS ? 1 : 0;       // (S1 evaluations put every seed in PH_START: no line-search points)
     if (h->is_nnet ? !h->nn.small : !h->fold) {
         // (large grids: a workgroup that waits for its arrival to come back holds its LDS and wave
@@ -449,17 +462,46 @@ int set_opts(va_handle h, const va_lbfgs_opts *o)
     return VA_OK;
 }
 
+// Is a rocprofiler-sdk tool (rocprofv3, rocprof-compute) loaded into this process?  Replaying ONE hipGraphExec of 192
+// kernel nodes ~900 times under rocprofv3 --kernel-trace ends in a SIGSEGV 13 frames below hipGraphLaunch, inside the
+// runtime / tool libraries (round 4: tools/ex1_probe.py --nbeta 101 --graph 1 under the profiler, at a 1 MiB-aligned
+// address; the same ladder with plain launches under the profiler, and with the graph without it, runs).  A fault
+// inside a HIP call cannot be turned into an error code, so the ladder does not replay graphs while such a tool is
+// attached -- the profiler then also sees every kernel as a dispatch of its own.  (HIP itself links only
+// librocprofiler-register.so; the sdk and its tool library arrive with the profiler.)
+bool profiler_attached()
+{
+    static const bool attached = [] {
+        bool found = false;
+        dl_iterate_phdr([](struct dl_phdr_info *info, size_t, void *out) -> int {
+            const char *n = info->dlpi_name;
+            if (n && (strstr(n, "librocprofiler-sdk.so") || strstr(n, "librocprofiler-sdk-tool"))) { *(bool *)out = true; return 1; }
+            return 0;
+        }, &found);
+        return found;
+    }();
+    return attached;
+}
+
 // the kernel cycle until no seed is left (or the evaluation budget bound is hit)
+int run_ladder_persist(va_handle h, const double *rf_scale, int nbeta, bool *fell_back);
+
 int run_ladder(va_handle h, const double *rf_scale, int nbeta)
 {
     Dev &dv = h->dv;
     if (nbeta < 1 || nbeta > dv.max_beta) return fail(VA_EINVAL, "nbeta=%d outside [1, max_beta=%d]", nbeta, dv.max_beta);
+    if (h->persist && h->tune_persist) {
+        bool fell_back = false;
+        const int rc = run_ladder_persist(h, rf_scale, nbeta, &fell_back);
+        if (!fell_back) return rc;
+    }
     HIPCHK(hipMemcpyAsync(h->d_rf, rf_scale, sizeof(double) * nbeta, hipMemcpyHostToDevice, h->stream));
     dv.nbeta = nbeta; h->last_nbeta = nbeta;
     *h->h_nactive = dv.dm.B;
     HIPCHK(hipMemcpyAsync(dv.n_active, h->h_nactive, sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(dv.dpp, 0, sizeof(double) * dv.dm.B * dv.dm.nchunks * DP_N, h->stream));
     launch_init_states(dv, PH_START, -1.0, h->stream);
+    h->timed_armed_rf = -1.0;
     if (dv.dm.bounded) launch_clamp_x(dv, h->stream);
     // every cycle costs each live seed at least one evaluation
     const double per_step = (double)dv.o.maxfun + dv.o.maxls + 4.0;
@@ -472,7 +514,7 @@ int run_ladder(va_handle h, const double *rf_scale, int nbeta)
     // that batch of 192 launches is captured ONCE into a hipGraph and replayed.  The kernels take the device image
     // by value, so the graph is private to this call (ladder length, options).
     hipGraphExec_t gexec = nullptr;
-    bool use_graph = h->tune_graph;
+    bool use_graph = h->tune_graph && !profiler_attached();
     auto enqueue = [&](int n) {
         for (int k = 0; k < n; ++k) {
             run_eval(h, EPI_LS);
@@ -510,6 +552,48 @@ int run_ladder(va_handle h, const double *rf_scale, int nbeta)
     h->n_cycles += cyc; h->n_eval_launch += cyc;
     h->n_seed_evals = h->n_seed_evals_direct + (int64_t)*(unsigned long long *)(h->h_nactive + 2);
     HIPCHK(hipGetLastError());
+    return VA_OK;
+}
+
+// The same ladder as ONE cooperative launch of the persistent per-seed kernel.  *fell_back: the launch was refused (the
+// workgroups cannot all be resident, e.g. another process holds CUs): nothing has run, take the three-launch cycle.
+int run_ladder_persist(va_handle h, const double *rf_scale, int nbeta, bool *fell_back)
+{
+    Dev &dv = h->dv;
+    *fell_back = false;
+    const double per_step = (double)dv.o.maxfun + dv.o.maxls + 4.0;
+    const double bound = per_step * nbeta;
+    const long long max_cycles = bound > 4e18 ? (long long)4e18 : (long long)bound;
+    Dev dvp = dv;
+    dvp.dm.T = h->pz_T; dvp.dm.ntiles = h->pz_G; dvp.dm.nprow = h->pz_G;
+    dvp.nbeta = nbeta; dvp.pz.max_cycles = max_cycles;
+    HIPCHK(hipMemsetAsync(dv.pz.bar, 0, (size_t)dv.dm.B * 256, h->stream));
+    HIPCHK(hipMemsetAsync(h->pz_misc, 0, 16, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_rf, rf_scale, sizeof(double) * nbeta, hipMemcpyHostToDevice, h->stream));
+    dv.nbeta = nbeta; h->last_nbeta = nbeta;
+    *h->h_nactive = dv.dm.B;
+    HIPCHK(hipMemcpyAsync(dv.n_active, h->h_nactive, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    launch_init_states(dv, PH_START, -1.0, h->stream);
+    h->timed_armed_rf = -1.0;
+    const hipError_t e = h->user_seed ? (hipError_t)h->user_seed(&dvp, 1, (void *)h->stream) : seed_kernel_builtin(dvp, true, h->stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        h->persist = false;           // (for the rest of this handle's life)
+        *fell_back = true;
+        return VA_OK;
+    }
+    struct { int abort_flag, pad; unsigned long long cycles; } misc = {0, 0, 0ull};
+    HIPCHK(hipMemcpyAsync(h->h_nactive, dv.n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_nactive + 2, dv.n_evals, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&misc, h->pz_misc, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    const long long cyc = (long long)(misc.cycles / (unsigned long long)(dv.dm.B > 0 ? 1 : 1));
+    h->n_cycles += cyc; h->n_eval_launch += cyc;
+    h->n_seed_evals = h->n_seed_evals_direct + (int64_t)*(unsigned long long *)(h->h_nactive + 2);
+    if (misc.abort_flag == 1) return fail(VA_ESTATE, "persistent ladder: a grid barrier timed out (the seed's %d workgroups were not all resident)", h->pz_G);
+    if (misc.abort_flag == 2) return fail(VA_ESTATE, "ladder did not finish within %lld cycles", max_cycles);
+    if (*h->h_nactive > 0) return fail(VA_ESTATE, "persistent ladder ended with %d live seeds", *h->h_nactive);
     return VA_OK;
 }
 
@@ -578,6 +662,7 @@ int va_rhs_load_module(const char *path, int32_t *rhs_id)
     info_fn info = (info_fn)dlsym(u.dl, "va_user_rhs_info");
     u.launch = (void (*)(const Dev *, void *))dlsym(u.dl, "va_user_launch_eval");
     u.prepare = (int (*)(const Dev *))dlsym(u.dl, "va_user_prepare_eval");
+    u.seed_kernel = (int (*)(const Dev *, int, void *))dlsym(u.dl, "va_user_seed_kernel");
     if (!info || !u.launch || !u.prepare) { dlclose(u.dl); return fail(VA_EINVAL, "%s lacks va_user_rhs_info / va_user_launch_eval / va_user_prepare_eval", path); }
     int v[5] = {0, 0, 0, 0, 0};
     info(v);
@@ -684,6 +769,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     h->device = d->device; h->rhs = d->rhs; h->keep_paths = d->keep_paths;
     h->user_launch = user ? user->launch : nullptr;
     h->user_prepare = user ? user->prepare : nullptr;
+    h->user_seed = user ? user->seed_kernel : nullptr;
     if (d->stream) h->stream = (hipStream_t)d->stream;
     else {
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -850,6 +936,28 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     dv.pp.Pidx = pidx_d; dv.pp.Pfull = P_d;
     dv.pp.tmodel = t_d; dv.pp.stim = st_d; dv.pp.nstim = d->n_stim;
 
+    // few seeds, short paths: can the whole minimisation live in LDS?  (flat tile phases: any right-hand side, any
+    // discretisation, weight arrays, merr_nskip, full weight matrices; not bounds, time-dependent parameters, a dense
+    // linear part, or the padded observation rows of the streaming kernel)
+    if (!dm.bounded && !tdp && !dm.lin && dm.emode != 5 && (!user || user->seed_kernel)) {
+        int G = 0, T = 0, ncu = 0;
+        HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d->device));
+        if (persist_geometry(dm.N, dm.D, dm.NPest, m, dm.disc, 160 * 1024, &G, &T) && (long)B * G <= ncu) {
+            Dev dvp = dv;
+            dvp.dm.T = T; dvp.dm.ntiles = G;
+            const hipError_t e = h->user_seed ? (hipError_t)h->user_seed(&dvp, 0, nullptr) : seed_kernel_builtin(dvp, false, nullptr);
+            if (e == hipSuccess) {
+                h->persist = true; h->pz_G = G; h->pz_T = T;
+                TRY(h->alloc(&dv.pz.evp, B * G * EP_N)); TRY(h->alloc(&dv.pz.upp, B * G * UP_N));
+                TRY(h->alloc(&dv.pz.edge, B * G * PZ_EDGE_ROWS * dm.D)); TRY(h->alloc(&dv.pz.gdp, B * G));
+                TRY(h->alloc(&dv.pz.bar, B * 32));
+                unsigned long long *misc = nullptr;
+                TRY(h->alloc(&misc, 2));
+                h->pz_misc = misc;
+                dv.pz.abort_flag = (int *)misc; dv.pz.cycles = misc + 1;
+            } else (void)hipGetLastError();
+        }
+    }
     TRY(finish_create(h));
 #undef TRY
 #undef H2D
@@ -1081,6 +1189,15 @@ int va_problem_eval_kernel(va_handle h, int32_t *eval_kernel, int32_t *run_rows)
     return VA_OK;
 }
 
+int va_problem_persistent(va_handle h, int32_t *workgroups_per_seed, int32_t *rows_per_workgroup)
+{
+    if (!h) return 0;
+    const bool on = h->persist && h->tune_persist;
+    if (workgroups_per_seed) *workgroups_per_seed = on ? h->pz_G : 0;
+    if (rows_per_workgroup) *rows_per_workgroup = on ? h->pz_T : 0;
+    return on ? 1 : 0;
+}
+
 int va_action_grad(va_handle h, const double *XP, int64_t ld, int32_t mem, double rf_scale,
                    double *A, double *me, double *fe, double *grad, int64_t ldg)
 {
@@ -1092,6 +1209,7 @@ int va_action_grad(va_handle h, const double *XP, int64_t ld, int32_t mem, doubl
     Dev &dv = h->dv;
     if ((rc = copy_in(h, XP, ld, mem))) return rc;
     launch_init_states(dv, PH_START, rf_scale, h->stream);
+    h->timed_armed_rf = rf_scale;
     run_eval(h, EPI_FINALIZE);
     const hipMemcpyKind k = mem == VA_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     HIPCHK(hipMemcpyAsync(A, dv.outA, sizeof(double) * dv.dm.B, k, h->stream));
@@ -1160,37 +1278,86 @@ int va_get_minpath(va_handle h, int32_t seed, int32_t beta_idx, double *out)
     return VA_OK;
 }
 
+namespace {
+// The graph of `chunk` S1 evaluations va_eval_timed replays, built (or kept) OUTSIDE any timed region.  A host thread
+// issues launches ~3.7 us apart, which would be the number measured for any kernel shorter than that (the kernel
+// boundary is the same either way: MI355X_MICROARCH.md, "boundary: eager = hipGraph").  The kernels take the device
+// image by value, so the graph is keyed on the bytes of h->dv / h->nn as run_eval(EPI_FINALIZE) leaves them.
+int timed_chunk_of(int iters) { return iters < 250 ? iters : 250; }
+
+bool timed_graph_current(va_handle h, int chunk)
+{
+    return h->timed_gexec && h->timed_chunk == chunk && h->tune_graph &&
+           memcmp(&h->timed_dv, &h->dv, sizeof(Dev)) == 0 && memcmp(&h->timed_nn, &h->nn, sizeof(NnetDev)) == 0;
+}
+
+void timed_graph_drop(va_handle h)
+{
+    if (h->timed_gexec) { (void)hipGraphExecDestroy(h->timed_gexec); h->timed_gexec = nullptr; }
+}
+
+int timed_prepare(va_handle h, double rf_scale, int iters)
+{
+    Dev &dv = h->dv;
+    if (h->timed_armed_rf != rf_scale) {
+        launch_init_states(dv, PH_START, rf_scale, h->stream);
+        h->timed_armed_rf = rf_scale;
+    }
+    if (!h->tune_graph || iters < 8) { timed_graph_drop(h); return VA_OK; }
+    const int chunk = timed_chunk_of(iters);
+    // (the fields run_eval writes, as it will leave them: the comparison below must not see a stale line-search launch)
+    h->dv.lsrun = 0;
+    h->dv.epi = (h->is_nnet ? !h->nn.small : !h->fold) ? EPI_NONE : EPI_FINALIZE;
+    if (timed_graph_current(h, chunk)) return VA_OK;
+    timed_graph_drop(h);
+    hipGraph_t g = nullptr;
+    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        for (int i = 0; i < chunk; ++i) run_eval(h, EPI_FINALIZE);
+        if (hipStreamEndCapture(h->stream, &g) != hipSuccess || !g ||
+            hipGraphInstantiate(&h->timed_gexec, g, nullptr, nullptr, 0) != hipSuccess) h->timed_gexec = nullptr;
+        if (g) (void)hipGraphDestroy(g);
+    }
+    if (!h->timed_gexec) { (void)hipGetLastError(); return VA_OK; }      // plain launches then
+    h->timed_chunk = chunk;
+    memcpy(&h->timed_dv, &h->dv, sizeof(Dev)); memcpy(&h->timed_nn, &h->nn, sizeof(NnetDev));
+    (void)hipGraphUpload(h->timed_gexec, h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return VA_OK;
+}
+}  // namespace
+
+int va_eval_timed_prepare(va_handle h, double rf_scale, int32_t iters)
+{
+    if (!h || iters < 1 || !(rf_scale >= 0.0)) return fail(VA_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    return timed_prepare(h, rf_scale, iters);
+}
+
 int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms)
 {
-    if (!h || !elapsed_ms || iters < 1) return fail(VA_EINVAL, "bad argument");
+    if (!h || !elapsed_ms || iters < 1 || !(rf_scale >= 0.0)) return fail(VA_EINVAL, "bad argument");
     HIPCHK(hipSetDevice(h->device));
     Dev &dv = h->dv;
-    launch_init_states(dv, PH_START, rf_scale, h->stream);
-    // Each launch forms A, me, fe and the full gradient.  The launches are replayed from a hipGraph in chunks:
-    // a host thread issues ~3.7 us apart, which would be the number measured for any kernel shorter than that
-    // (the same kernel boundary either way: MI355X_MICROARCH.md, "boundary: eager = hipGraph").
-    const int chunk = iters < 250 ? iters : 250;          // (one graph serves the warm-up call and the timed call)
-    if (h->timed_gexec && (h->timed_chunk != chunk || !h->tune_graph)) { (void)hipGraphExecDestroy(h->timed_gexec); h->timed_gexec = nullptr; }
-    if (h->tune_graph && iters >= 8 && !h->timed_gexec) {
-        // (kept on the handle: the warm-up call builds it, the timed call replays it)
-        hipGraph_t g = nullptr;
-        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            for (int i = 0; i < chunk; ++i) run_eval(h, EPI_FINALIZE);
-            if (hipStreamEndCapture(h->stream, &g) != hipSuccess || !g ||
-                hipGraphInstantiate(&h->timed_gexec, g, nullptr, nullptr, 0) != hipSuccess) h->timed_gexec = nullptr;
-            if (g) (void)hipGraphDestroy(g);
-        }
-        if (!h->timed_gexec) (void)hipGetLastError();
-        else { h->timed_chunk = chunk; (void)hipGraphUpload(h->timed_gexec, h->stream); }
-    }
-    hipGraphExec_t gexec = (h->tune_graph && iters >= 8) ? h->timed_gexec : nullptr;
+    // Each launch forms A, me, fe and the full gradient.  After va_eval_timed_prepare(h, rf_scale, iters) nothing
+    // below but the launches themselves is issued: the seeds are armed and the chunk's graph is instantiated and
+    // uploaded; without it (or after anything changed the handle) the same preparation happens here first.
+    int rc = timed_prepare(h, rf_scale, iters);
+    if (rc) return rc;
+    const int chunk = timed_chunk_of(iters);
+    hipGraphExec_t gexec = (iters >= 8 && timed_graph_current(h, chunk)) ? h->timed_gexec : nullptr;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     int done = 0;
     if (gexec)
         for (; done + chunk <= iters; done += chunk) HIPCHK(hipGraphLaunch(gexec, h->stream));
     for (; done < iters; ++done) run_eval(h, EPI_FINALIZE);
     HIPCHK(hipEventRecord(h->ev1, h->stream));
-    HIPCHK(hipEventSynchronize(h->ev1));
+    {
+        // (polled: a blocking wait hands the thread to the kernel's scheduler, and its wake-up would be part of
+        // whatever wall clock the caller keeps around this call)
+        hipError_t q;
+        while ((q = hipEventQuery(h->ev1)) == hipErrorNotReady) {}
+        if (q != hipSuccess) return fail(VA_EHIP, "hipEventQuery: %s", hipGetErrorString(q));
+    }
     HIPCHK(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
     HIPCHK(hipGetLastError());
     h->n_eval_launch += iters; h->n_seed_evals += (int64_t)iters * dv.dm.B;
@@ -1201,7 +1368,7 @@ int va_eval_timed(va_handle h, double rf_scale, int32_t iters, float *elapsed_ms
 int va_problem_tune(va_handle h, int32_t what, int32_t value)
 {
     if (!h) return fail(VA_EINVAL, "null handle");
-    if (h->timed_gexec) { (void)hipGraphExecDestroy(h->timed_gexec); h->timed_gexec = nullptr; }      // (captured with the old settings)
+    timed_graph_drop(h);      // (captured with the old settings)
     switch (what) {
     case VA_TUNE_FOLD:
         if (h->is_nnet) return fail(VA_EUNSUPPORTED, "the network action chooses its tail by the net's size");
@@ -1209,6 +1376,7 @@ int va_problem_tune(va_handle h, int32_t what, int32_t value)
     case VA_TUNE_GRAD_SC1: h->dv.gaux = value != 0 ? 1 : 0; break;
     case VA_TUNE_PRIO: h->dv.prio = value != 0 ? 1 : 0; break;
     case VA_TUNE_GRAPH: h->tune_graph = value != 0; break;
+    case VA_TUNE_PERSIST: h->tune_persist = value != 0; break;
     default: return fail(VA_EINVAL, "unknown tuning knob %d", what);
     }
     return VA_OK;
@@ -1341,16 +1509,21 @@ int va_lbfgs_timed(va_handle h, int32_t iters, float *ms_update, float *ms_direc
     if (!h || !ms_update || !ms_direction || iters < 1) return fail(VA_EINVAL, "bad argument");
     HIPCHK(hipSetDevice(h->device));
     Dev &dv = h->dv;
+    // (a bounded handle's third launch is k_lbfgsb_dir, whose cost depends on the active set and the breakpoints
+    // crossed: it has no "steady state" to arm -- profile it inside a real bounded ladder instead)
+    if (dv.dm.bounded) return fail(VA_EUNSUPPORTED, "va_lbfgs_timed times k_direction; a bounded handle runs k_lbfgsb_dir");
     dv.sticky = 1;
+    h->timed_armed_rf = -1.0;
+    auto dir = [&]() { launch_direction(dv, h->stream); };
     launch_arm_full_history(dv, h->stream);
-    launch_update(dv, h->stream); launch_direction(dv, h->stream);           // warm-up
+    launch_update(dv, h->stream); dir();           // warm-up
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     for (int i = 0; i < iters; ++i) launch_update(dv, h->stream);
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventSynchronize(h->ev1));
     HIPCHK(hipEventElapsedTime(ms_update, h->ev0, h->ev1));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    for (int i = 0; i < iters; ++i) launch_direction(dv, h->stream);
+    for (int i = 0; i < iters; ++i) dir();
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventSynchronize(h->ev1));
     HIPCHK(hipEventElapsedTime(ms_direction, h->ev0, h->ev1));
@@ -1368,6 +1541,7 @@ int va_eval_ls_timed(va_handle h, double rf_scale, int32_t iters, float *ms_eval
     HIPCHK(hipSetDevice(h->device));
     Dev &dv = h->dv;
     float both = 0.f, arm = 0.f;
+    h->timed_armed_rf = -1.0;
     for (int pass = 0; pass < 2; ++pass) {
         launch_arm_ls(dv, rf_scale, h->stream);
         if (pass == 0) run_eval(h, EPI_LS);                                  // warm-up
@@ -1411,6 +1585,17 @@ int va_debug_read_partials(va_handle h, double *out, int64_t n)
     if (n > have) return fail(VA_EINVAL, "n=%lld > %lld partials", (long long)n, (long long)have);
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(out, dv.upp, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return VA_OK;
+}
+
+int va_debug_read_persist(va_handle h, double *out, int64_t n)
+{
+    if (!h || !out || n < 0) return fail(VA_EINVAL, "bad argument");
+    if (!h->dv.pz.upp) return fail(VA_ESTATE, "the handle has no persistent-kernel buffers");
+    if (n > (int64_t)h->dv.dm.B * h->pz_G * UP_N) return fail(VA_EINVAL, "n too large");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(out, h->dv.pz.upp, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return VA_OK;
 }

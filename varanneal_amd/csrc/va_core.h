@@ -165,6 +165,8 @@ struct TileCtx {
     double *xs, *fs, *qs;        // staged rows [R*D] (LDS); fs is re-used for s
     const double *xg, *dg;       // this seed's x (and d) in global memory
     double *gtg;                 // this seed's gradient output
+    long goff = 0;               // gtg / dg are indexed by (path index - goff): 0 for the seed's global vectors, the slice's
+                                 // first element when they are a workgroup's LDS-resident slice (va_persist.h)
     const double *tmodel, *stim; // per-row time / stimulus (NULL / unused for autonomous RHS)
     int nstim;
     double *ps;                  // time-dependent parameters: staged rows [R*NPt] (LDS)
@@ -442,8 +444,8 @@ VA_HD void tile_g(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &
                 }
             }
             const long gi = (long)m * D + j;
-            c.gtg[gi] = g;
-            if (c.use_d) acc.v[EP_GTD] += g * c.dg[gi];
+            c.gtg[gi - c.goff] = g;
+            if (c.use_d) acc.v[EP_GTD] += g * c.dg[gi - c.goff];
             acc.v[EP_GN2] += g * g;
             acc.v[EP_GMAX] = fmax(acc.v[EP_GMAX], fabs(pp.lo ? proj_grad(xr[j], g, pp.lo[gi], pp.hi[gi]) : g));
         }

@@ -21,6 +21,15 @@ constexpr int CNT_STRIDE = 64;
 // what the last-arriving wave of an evaluation does with the seed's partial sums (va_epilogue.h)
 enum { EPI_NONE = 0, EPI_FINALIZE = 1, EPI_LS = 2 };
 
+// The persistent per-seed kernel's exchange buffers (va_persist.h): G workgroups per seed
+struct Persist {
+    double *evp, *upp, *edge, *gdp;   // [B][G][EP_N] eval partials, [B][G][UP_N] update partials, [B][G][3 D] halo rows, [B][G] g.d partials
+    unsigned long long *bar;          // [B] x 256 B: the seed's monotonic barrier counter
+    unsigned long long *cycles;       // cycles run by the last launch (summed over seeds)
+    int *abort_flag;                  // 0; 1 a grid barrier timed out (workgroups not co-resident); 2 cycle budget exceeded
+    long long max_cycles;
+};
+
 // Everything a kernel needs, passed by value as the kernel argument.
 struct Dev {
     Dims dm;
@@ -61,6 +70,7 @@ struct Dev {
     // breakpoints t, variable status iwhere ([B][ld] each); S'Y, S'S, T ([B][3 m m]); d'd of the direction in use ([B])
     double *lb_z, *lb_r, *lb_xp, *lb_t, *lb_mat, *lb_dtd;
     int *lb_iwhere;
+    Persist pz;
 };
 
 // launch wrappers (va_kernels.hip); all asynchronous on `s`
@@ -80,6 +90,9 @@ int eval_grid(const Dims &dm);
 // bounded problems: L-BFGS-B's direction step in k_direction's place (va_lbfgsb.hip)
 void launch_lbfgsb_dir(const Dev &dv, hipStream_t s);
 hipError_t prepare_lbfgsb(const Dev &dv);
+// the persistent per-seed ladder kernel for the built-in right-hand side (va_persist.h): launch == false opts the
+// instantiation in to its LDS on the current device, launch == true is a cooperative launch of B * ntiles workgroups
+hipError_t seed_kernel_builtin(const Dev &dv, bool launch, hipStream_t s);
 // streaming column strips (va_eval5.hip)
 void launch_eval5(const Dev &dv, hipStream_t s);
 hipError_t prepare_eval5(const Dev &dv);

@@ -24,6 +24,7 @@
 #include "va_eval3.h"
 #include "va_eval4.h"
 #include "va_tile5.h"
+#include "va_persist.h"
 
 namespace va {
 
@@ -152,6 +153,8 @@ hipError_t prepare_eval(const Dev &dv, int rhs)
     eval_dispatch(dv, rhs, op);
     return op.err;
 }
+
+hipError_t seed_kernel_builtin(const Dev &dv, bool launch, hipStream_t s) { return seed_kernel_op<RhsL96>(dv, launch, s); }
 
 // ------------------------------------------------------------------ K2: tails as kernels of their own
 // (the network action, whose evaluation is several kernels, and grids too large to fold the tail

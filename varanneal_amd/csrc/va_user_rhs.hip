@@ -11,6 +11,7 @@
 #include "va_eval3.h"
 #include "va_eval4.h"
 #include "va_eval5.h"
+#include "va_persist.h"
 
 #ifndef VA_USER_RHS_HEADER
 #error "compile with -DVA_USER_RHS_HEADER='\"path/to/generated_header.h\"'"
@@ -35,6 +36,12 @@ void va_user_launch_eval(const va::Dev *dv, void *stream)
 int va_user_prepare_eval(const va::Dev *dv)
 {
     return (int)va::prepare_eval_rhs<va::RhsUser>(*dv);
+}
+
+// the persistent per-seed ladder kernel (va_persist.h) for this model: few seeds, short paths
+int va_user_seed_kernel(const va::Dev *dv, int launch, void *stream)
+{
+    return (int)va::seed_kernel_op<va::RhsUser>(*dv, launch != 0, (hipStream_t)stream);
 }
 
 // Besides the flat kernel a module may carry ONE instantiation of a column-run kernel, named when the module
