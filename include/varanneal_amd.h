@@ -153,6 +153,7 @@ int va_problem_info(va_handle h, int64_t *n_var, int64_t *ld_internal, int32_t *
                               * per-seed kernel (csrc/va_persist.h: every vector of the minimisation resident in LDS),
                               * when the problem is eligible (default); 0: always the three-launch cycle.  Same
                               * arithmetic, different order of the partial sums: results agree to rounding, not bit for bit */
+#define VA_TUNE_PERSIST_ROWS 6   /* time rows per workgroup of the persistent kernel (0: the library's choice); VA_EINVAL when not admissible */
 int va_problem_tune(va_handle h, int32_t what, int32_t value);
 /* 1 if va_anneal / va_minimize_lbfgs on this handle run the persistent per-seed kernel, with its geometry
  * (workgroups per seed, time rows per workgroup); 0 otherwise. */
@@ -223,8 +224,8 @@ int va_read_eval_outputs(va_handle h, double *A, double *me, double *fe, double 
 /* Profiling hook: copy the first n doubles of the L-BFGS inner-product partial table to the host. */
 int va_debug_read_partials(va_handle h, double *out, int64_t n);
 
-/* Profiling hook: the first n doubles of the persistent kernel's update-partial table (a -DVA_PZ_STAMPS measurement
- * build of the library leaves its per-phase tick sums there). */
+/* Profiling hook: the per-phase tick sums (100 MHz) a -DVA_PZ_STAMPS measurement build of the persistent kernel leaves
+ * behind (n <= 14 doubles; zeros from the product library). */
 int va_debug_read_persist(va_handle h, double *out, int64_t n);
 
 /* Cumulative counters since create: batched eval launches, seed-evaluations,

@@ -55,11 +55,16 @@ CASES = {
 }
 
 
+ROWS = int(os.environ.get("PZ_ROWS", "0"))
+
+
 def run(q, persist):
     rf = 1.5 ** np.arange(q["nbeta"])
     with _capi.Problem(q["B"], q["D"], q["N"], q["Y"], q["Lidx"], q["dt"], 4.0, q["RF0"], q["P"], [0], disc=q["disc"],
                        merr_nskip=q["nskip"], max_beta=q["nbeta"], keep_paths=1) as pb:
         pb.tune(persist=persist)
+        if persist and ROWS:
+            pb.tune(persist_rows=ROWS)
         geo = pb.persistent()
         pb.anneal(q["XP"].copy(), rf[:2], OPTS, want_paths=True)                 # warm-up
         c0 = pb.counters()["cycles"]
@@ -68,12 +73,12 @@ def run(q, persist):
         dt = time.time() - t0
         cyc = pb.counters()["cycles"] - c0
         if persist and os.environ.get("VARANNEAL_AMD_LIB", "").endswith("_pzst.so"):
-            st = pb.debug_read_persist(13)
-            names = ["trial", "barA+halo", "tile phases", "block reduce", "barB+sum", "ls_step", "update+dots", "barC+sum", "coeffs", "direction", "-", "loop top"]
-            n = max(st[12], 1.0)
+            st = pb.debug_read_persist(14)
+            names = ["trial", "tile phases", "wave sums", "publish+dots", "gather ev", "ls_step|gather dots", "dot sums+params", "coeffs", "update+direction", "-", "-", "-", "loop top"]
+            n = max(st[13], 1.0)
             print("   stamps (workgroup 0 of seed 0, us per cycle over %d cycles): " % n +
-                  "  ".join("%s %.2f" % (names[i], st[i] * 0.01 / n) for i in range(12) if i != 10) +
-                  "  | total %.2f" % (st[:12].sum() * 0.01 / n), flush=True)
+                  "  ".join("%s %.2f" % (names[i], st[i] * 0.01 / n) for i in range(13) if names[i] != "-") +
+                  "  | total %.2f | shader clock %.0f MHz" % ((st[:9].sum() + st[11:13].sum()) * 0.01 / n, st[9] / max(st[10], 1.0) * 100.0), flush=True)
     return r, dt, cyc, geo
 
 

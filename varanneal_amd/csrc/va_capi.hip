@@ -83,8 +83,9 @@ struct va_problem_s {
     // few seeds, short paths: the whole ladder in ONE cooperative launch, every vector of the minimisation resident in
     // the LDS of pz_G workgroups per seed (va_persist.h); chosen at create when the slices fit and all are co-resident
     bool persist = false, tune_persist = true;
-    int pz_G = 0, pz_T = 0;
-    void *pz_misc = nullptr;           // device: [abort flag (int), pad, cycles (unsigned long long)]
+    int pz_G = 0, pz_T = 0, pz_maxG = 0;
+    void *pz_misc = nullptr;           // device: [abort flag (int), pad, cycles (unsigned long long), stamps (PZ_NSTAMP doubles)]
+    size_t pz_xch_bytes = 0;
     bool is_nnet = false;              // feed-forward-network action (va_nnet.hip) instead of an ODE path
     bool fold = false;                 // the evaluation kernel runs the tail itself (last arriver of each seed)
     bool tune_graph = true;            // ladder cycles / timed evaluations replayed from a hipGraph (va_problem_tune)
@@ -567,7 +568,7 @@ int run_ladder_persist(va_handle h, const double *rf_scale, int nbeta, bool *fel
     Dev dvp = dv;
     dvp.dm.T = h->pz_T; dvp.dm.ntiles = h->pz_G; dvp.dm.nprow = h->pz_G;
     dvp.nbeta = nbeta; dvp.pz.max_cycles = max_cycles;
-    HIPCHK(hipMemsetAsync(dv.pz.bar, 0, (size_t)dv.dm.B * 256, h->stream));
+    HIPCHK(hipMemsetAsync(dv.pz.xch, 0, h->pz_xch_bytes, h->stream));           // (tags restart at 1 with every launch)
     HIPCHK(hipMemsetAsync(h->pz_misc, 0, 16, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_rf, rf_scale, sizeof(double) * nbeta, hipMemcpyHostToDevice, h->stream));
     dv.nbeta = nbeta; h->last_nbeta = nbeta;
@@ -942,19 +943,21 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     if (!dm.bounded && !tdp && !dm.lin && dm.emode != 5 && (!user || user->seed_kernel)) {
         int G = 0, T = 0, ncu = 0;
         HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d->device));
-        if (persist_geometry(dm.N, dm.D, dm.NPest, m, dm.disc, 160 * 1024, &G, &T) && (long)B * G <= ncu) {
+        h->pz_maxG = ncu / (int)B;
+        if (h->pz_maxG >= 1 && persist_geometry(dm.N, dm.D, dm.L, dm.NP, dm.NPest, m, dm.disc, PZ_LDS_BYTES, h->pz_maxG, 0, &G, &T)) {
             Dev dvp = dv;
             dvp.dm.T = T; dvp.dm.ntiles = G;
             const hipError_t e = h->user_seed ? (hipError_t)h->user_seed(&dvp, 0, nullptr) : seed_kernel_builtin(dvp, false, nullptr);
             if (e == hipSuccess) {
                 h->persist = true; h->pz_G = G; h->pz_T = T;
-                TRY(h->alloc(&dv.pz.evp, B * G * EP_N)); TRY(h->alloc(&dv.pz.upp, B * G * UP_N));
-                TRY(h->alloc(&dv.pz.edge, B * G * PZ_EDGE_ROWS * dm.D)); TRY(h->alloc(&dv.pz.gdp, B * G));
-                TRY(h->alloc(&dv.pz.bar, B * 32));
+                // (sized for the most workgroups a seed may get: va_problem_tune may choose other slices)
+                const size_t units = B * 2 * (size_t)h->pz_maxG * (size_t)pz_row_granules(dm.D) * 2;     // 8-byte units: 16 per granule pair
+                TRY(h->alloc(&dv.pz.xch, units));
+                h->pz_xch_bytes = units * 8;
                 unsigned long long *misc = nullptr;
-                TRY(h->alloc(&misc, 2));
+                TRY(h->alloc(&misc, 2 + PZ_NSTAMP));
                 h->pz_misc = misc;
-                dv.pz.abort_flag = (int *)misc; dv.pz.cycles = misc + 1;
+                dv.pz.abort_flag = (int *)misc; dv.pz.cycles = misc + 1; dv.pz.stamps = (double *)(misc + 2);
             } else (void)hipGetLastError();
         }
     }
@@ -1377,6 +1380,16 @@ int va_problem_tune(va_handle h, int32_t what, int32_t value)
     case VA_TUNE_PRIO: h->dv.prio = value != 0 ? 1 : 0; break;
     case VA_TUNE_GRAPH: h->tune_graph = value != 0; break;
     case VA_TUNE_PERSIST: h->tune_persist = value != 0; break;
+    case VA_TUNE_PERSIST_ROWS: {
+        if (!h->persist) return fail(VA_ESTATE, "the handle does not run the persistent kernel");
+        int G = 0, T = 0;
+        const Dims &dm = h->dv.dm;
+        if (!persist_geometry(dm.N, dm.D, dm.L, dm.NP, dm.NPest, dm.m, dm.disc, PZ_LDS_BYTES, h->pz_maxG, value, &G, &T))
+            return fail(VA_EINVAL, "%d rows per workgroup: not an admissible slice (>= 2 rows everywhere, even for SimpsonHermite, "
+                                   "at most %d workgroups per seed, LDS)", value, h->pz_maxG);
+        h->pz_G = G; h->pz_T = T;
+        break;
+    }
     default: return fail(VA_EINVAL, "unknown tuning knob %d", what);
     }
     return VA_OK;
@@ -1592,10 +1605,10 @@ int va_debug_read_partials(va_handle h, double *out, int64_t n)
 int va_debug_read_persist(va_handle h, double *out, int64_t n)
 {
     if (!h || !out || n < 0) return fail(VA_EINVAL, "bad argument");
-    if (!h->dv.pz.upp) return fail(VA_ESTATE, "the handle has no persistent-kernel buffers");
-    if (n > (int64_t)h->dv.dm.B * h->pz_G * UP_N) return fail(VA_EINVAL, "n too large");
+    if (!h->dv.pz.stamps) return fail(VA_ESTATE, "the handle has no persistent-kernel buffers");
+    if (n > PZ_NSTAMP) return fail(VA_EINVAL, "n > %d", PZ_NSTAMP);
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemcpyAsync(out, h->dv.pz.upp, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(out, h->dv.pz.stamps, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return VA_OK;
 }

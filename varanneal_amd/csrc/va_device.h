@@ -21,12 +21,12 @@ constexpr int CNT_STRIDE = 64;
 // what the last-arriving wave of an evaluation does with the seed's partial sums (va_epilogue.h)
 enum { EPI_NONE = 0, EPI_FINALIZE = 1, EPI_LS = 2 };
 
-// The persistent per-seed kernel's exchange buffers (va_persist.h): G workgroups per seed
+// The persistent per-seed kernel's exchange area (va_persist.h): G workgroups per seed
 struct Persist {
-    double *evp, *upp, *edge, *gdp;   // [B][G][EP_N] eval partials, [B][G][UP_N] update partials, [B][G][3 D] halo rows, [B][G] g.d partials
-    unsigned long long *bar;          // [B] x 256 B: the seed's monotonic barrier counter
+    unsigned long long *xch;          // [B][2 buffers][G rows][granule pairs of 16 bytes]: one row per workgroup and cycle
     unsigned long long *cycles;       // cycles run by the last launch (summed over seeds)
-    int *abort_flag;                  // 0; 1 a grid barrier timed out (workgroups not co-resident); 2 cycle budget exceeded
+    int *abort_flag;                  // 0; 1 a poll timed out (workgroups not co-resident); 2 cycle budget exceeded
+    double *stamps;                   // measurement builds (-DVA_PZ_STAMPS) leave their per-phase tick sums here
     long long max_cycles;
 };
 

@@ -3,27 +3,29 @@
 // BASELINE configs 1-2).  There the three-launch L-BFGS cycle (va_kernels.hip) is pure latency: each kernel costs a
 // dependent graph node (~1.6 us) plus 4-8 us of round trips for a few kilobytes of work.
 //
-// Here a seed is owned by G co-resident workgroups (cooperative launch), workgroup w keeping ITS slice of T time rows
-// of every vector of the minimisation ON CHIP for the whole ladder: x, g, the trial gradient, the direction and all
-// 2m history vectors live in LDS (C2: 32 workgroups x 32 rows, 149 KB each).  A cycle is what the three launches do,
-// in the same order, between workgroup barriers:
-//   evaluation   x (or x + stp*d) of the own rows into the staging rows; the first / last rows of the slice are
-//                published for the neighbours' halo (sc1 stores);  GRID BARRIER A;  f, residuals, q, s, gradient rows
-//                by the flat tile phases of va_core.h (any right-hand side, any discretisation, weights, merr_nskip);
-//                the slice's partial sums are published;  GRID BARRIER B;  EVERY workgroup adds the G partial rows in
-//                the same fixed order and runs the same More'-Thuente / L-BFGS-B / ladder step (va_core.h ls_step,
-//                _autodiffmin.py:72-95, va_ode.py:707-789) on its own copy of the seed's state: identical inputs,
-//                identical decisions, nothing to broadcast;
-//   update       x += stp*d, (s, y) into their history slot, g <- g_t, all inner products of the compact form; partial
-//                sums published;  GRID BARRIER C;  every workgroup solves for the direction coefficients
-//                (Byrd-Nocedal-Schnabel compact form: pz_coeffs, the LDS-resident twin of coeffs_wave);
-//   direction    d = cg g + sum_j cY_j Y_j + cS_j S_j on the own slice; its g.d partial travels with barrier A of the
-//                next evaluation.
-// Three grid barriers per accepted iterate, two per extra line-search trial, no launch, no atomics on data.  A grid
-// barrier = own stores drained (s_waitcnt vmcnt(0)) + workgroup barrier + one agent-scope atomic add on the seed's
-// monotonic counter + a bounded spin (wall clock: a seed whose workgroups are not all resident aborts the launch through
-// a flag every spinning workgroup polls -- every wave reaches an exit).  Partial sums are added in a fixed order: results
-// do not depend on timing.
+// Here a seed is owned by G co-resident 1024-thread workgroups (cooperative launch), workgroup w keeping ITS slice of T
+// time rows of every vector of the minimisation ON CHIP for the whole ladder: x, g, the trial gradient, the direction
+// and all 2m history vectors live in LDS (C2: 29-32 workgroups, ~150 KB each) -- each with the slice's halo rows, which
+// every workgroup keeps up to date itself (all vector operations of L-BFGS are element-wise), so that the trial point
+// x + stp*d of the halo rows never has to be fetched.  What a workgroup cannot form alone is exchanged ONCE per cycle:
+//   evaluation   x (or x + stp*d) of the slice + halo into the staging rows; f, residuals, q, s, gradient rows by the
+//                flat tile phases of va_core.h (any right-hand side, any discretisation, weight arrays, merr_nskip);
+//   speculation  the inner products the update WOULD need if this point is accepted (k_update's: y.g_t, s.g_t, y.y, s.y,
+//                S_j.g_t, Y_j.g_t, S_j.y, Y_j.y with y = g_t - g, s = stp*d) -- a history vector per wave;
+//   all-gather   one row per workgroup: the evaluation's partial sums, those inner products, the g.d partial of the
+//                direction in use, and the first / last gradient rows of the slice (the neighbours' halo), published as
+//                self-validating granules -- each double as one 16-byte sc1 store {lo, tag, hi, tag}, tag = cycle number,
+//                two alternating buffers -- and polled by EVERY workgroup with sc1 loads: no counter, no atomic, no
+//                barrier (MI355X_MICROARCH.md, price list: handoff-1to1 / allgather; granules need no ordering);
+//   decision     every workgroup adds the G rows in the same fixed order and runs the same More'-Thuente / L-BFGS-B /
+//                ladder step (va_core.h ls_step; _autodiffmin.py:72-95, va_ode.py:707-789) on its own copy of the seed's
+//                state: identical inputs, identical decisions, nothing to broadcast;
+//   update       the compact-form coefficients (Byrd-Nocedal-Schnabel; pz_coeffs, the LDS twin of coeffs_wave), then ONE
+//                element-wise pass: x += stp*d, (s, y) into their slot, g <- g_t, d = cg g + sum_j cY_j Y_j + cS_j S_j.
+// Every poll is bounded (a seed whose workgroups are not all resident aborts the launch through a flag every poller
+// reads: every wave reaches an exit).  Partial sums are added in a fixed order: results do not depend on timing.
+// Not for bounded problems (clamps, k_lbfgsb_dir), time-dependent parameters or a dense linear part: those keep the
+// three-launch cycle.
 //
 // Compiled into libvaranneal_amd.so for the built-in Lorenz-96 and into every generated right-hand-side module.
 #pragma once
@@ -32,105 +34,94 @@
 namespace va {
 
 // measurement build (-DVA_PZ_STAMPS, never the product): thread 0 of workgroup 0 of seed 0 accumulates the wall-clock
-// ticks (100 MHz) between consecutive marks of the cycle and leaves the sums in the first words of pz.upp
+// ticks (100 MHz) between consecutive marks of the cycle and leaves the sums in pz.stamps
 #ifdef VA_PZ_STAMPS
 #define PZ_MARK(i) do { if (tid == 0) { const long long t_ = wall_clock64(); pz_acc[i] += t_ - pz_prev; pz_prev = t_; } } while (0)
 #else
 #define PZ_MARK(i) do {} while (0)
 #endif
 
-constexpr int PZ_THREADS = 256;
+#ifndef PZ_THREADS_N
+#define PZ_THREADS_N 1024
+#endif
+constexpr int PZ_THREADS = PZ_THREADS_N;
 constexpr int PZ_WAVES = PZ_THREADS / 64;
-constexpr int PZ_EDGE_ROWS = 3;                 // per workgroup: its last two rows (right neighbour's left halo), its first row
-constexpr long long PZ_SPIN_LIMIT = 400000000;  // wall_clock64() ticks (100 MHz): 4 s
+constexpr int PZ_EDGE_ROWS = 3;                 // per workgroup: its last two gradient rows (right neighbour's left halo), its first row
+constexpr int PZ_GDO = EP_N + UP_N;             // columns of an exchange row: [0, EP_N) evaluation partials, [EP_N, EP_N + UP_N) update
+constexpr int PZ_HALO = PZ_GDO + 1;             //   partials, g.d partial, then PZ_EDGE_ROWS * D halo entries
+constexpr unsigned PZ_POLL_LIMIT = 1u << 22;    // polls of one granule before the launch is abandoned (seconds)
+constexpr int PZ_NSTAMP = 14;
+constexpr int PZ_MREG = 10;                     // history lengths up to this keep the coefficient solve in registers
 
-// LDS doubles of one workgroup (T rows per slice, history length m)
-VA_HD size_t persist_lds_doubles(int T, int D, int NPest, int m, int HL)
+VA_HD int pz_row_granules(int D) { return PZ_HALO + PZ_EDGE_ROWS * D; }
+
+// columns of the sums part of an exchange row that a cycle can use: evaluation partials, g.d, update partials
+VA_HD int pz_sum_cols(int NP, int m) { return EP_GP + NP + 1 + UP_OLD + 4 * m; }
+
+// LDS doubles of one workgroup (T rows per slice, history length m, G workgroups per seed)
+VA_HD size_t persist_lds_doubles(int T, int D, int L, int NP, int NPest, int m, int HL, int G)
 {
-    const size_t nv = (size_t)T * D + NPest, RD = (size_t)(T + HL + 1) * D;
-    return (4 + 2 * (size_t)m) * nv + 3 * RD + (size_t)PZ_WAVES * UP_N + UP_N + EP_N + 2 * (size_t)m * m + 3 * MAX_M
-           + sizeof(SeedHot) / 8 + 8;
+    const size_t RD = (size_t)(T + HL + 1) * D, nvh = RD + NPest;
+    return (4 + 2 * (size_t)m) * nvh + 3 * RD + (size_t)PZ_WAVES * EP_N + 2 * (size_t)PZ_HALO + 2 * (size_t)m * m + 3 * MAX_M
+           + sizeof(SeedHot) / 8 + 8 + (size_t)G * pz_sum_cols(NP, m)
+           + 2 * (size_t)(T + 1) * L + RD + (size_t)(D + RHS_MAX_NP) / 2 + 2;      // the slice's observations, weight rows, column map
 }
 
-// slice geometry: the fewest workgroups whose slices fit the CU's LDS; every slice holds at least two rows;
-// Simpson-Hermite slices start on even rows (an interval's three rows then reach one row past the slice: HR = 1)
-inline bool persist_geometry(int N, int D, int NPest, int m, int disc, size_t lds_bytes, int *G, int *T)
+// slice geometry.  Every slice holds at least two rows; Simpson-Hermite slices start on even rows (an interval's three
+// rows then reach one row past the slice: HR = 1).  want_T > 0: that many rows per slice, if admissible; 0: the
+// largest slices the LDS holds, i.e. the fewest workgroups -- per cycle the vector work of a workgroup is mostly fixed
+// overhead (barriers, LDS round trips), while the all-gather grows with the number of rows polled (measured:
+// profiles/r04_persist_sweep.txt).
+constexpr size_t PZ_LDS_BYTES = 160 * 1024;
+inline bool persist_geometry_ok(int N, int D, int L, int NP, int NPest, int m, int disc, size_t lds_bytes, int max_G, int T)
 {
     const bool sh = disc == DISC_SH;
-    const int HL = sh ? 2 : 1;
-    int Tmax = 0;
-    for (int t = 2; t <= N; ++t) {
-        if (persist_lds_doubles(t, D, NPest, m, HL) * 8 > lds_bytes) break;
-        Tmax = t;
+    if (T < 2 || (sh && (T & 1))) return false;
+    const int G = (N + T - 1) / T;
+    if (G > max_G || N - (G - 1) * T < 2) return false;
+    return persist_lds_doubles(T, D, L, NP, NPest, m, sh ? 2 : 1, G) * 8 <= lds_bytes;
+}
+inline bool persist_geometry(int N, int D, int L, int NP, int NPest, int m, int disc, size_t lds_bytes, int max_G, int want_T, int *G, int *T)
+{
+    if (want_T > 0) {
+        if (!persist_geometry_ok(N, D, L, NP, NPest, m, disc, lds_bytes, max_G, want_T)) return false;
+        *T = want_T; *G = (N + want_T - 1) / want_T;
+        return true;
     }
-    if (Tmax < 2) return false;
-    for (int g = (N + Tmax - 1) / Tmax; g <= N / 2 + 1; ++g) {
-        int t = (N + g - 1) / g;
-        if (sh && (t & 1)) ++t;
-        if (t > Tmax || t < 2) continue;
-        if ((long)(g - 1) * t < N && N - (g - 1) * t >= 2) { *G = g; *T = t; return true; }
-    }
+    for (int t = N; t >= 2; --t)
+        if (persist_geometry_ok(N, D, L, NP, NPest, m, disc, lds_bytes, max_G, t)) { *T = t; *G = (N + t - 1) / t; return true; }
     return false;
 }
 
-struct PzBarrier {
-    unsigned long long *cnt;      // the seed's monotonic arrival counter
-    unsigned long long gen;       // barriers passed so far
-    int *abort_flag;
-    int G;
-};
+typedef unsigned pz_v4u __attribute__((ext_vector_type(4)));
 
-// returns false (workgroup-uniform) when the launch is being abandoned
-__device__ __forceinline__ bool pz_grid_barrier(PzBarrier &bar, int tid, int *lds_ok)
+// one double as two self-validating 8-byte granules {lo, tag}, {hi, tag}, written by ONE 16-byte write-through store
+__device__ __forceinline__ void pz_put(__amdgpu_buffer_rsrc_t r, int granule, double v, unsigned tag)
 {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own published stores acknowledged
-    __syncthreads();
-    bar.gen += 1;
-    if (tid == 0) {
-        const unsigned long long target = bar.gen * (unsigned long long)bar.G;
-        __hip_atomic_fetch_add(bar.cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = 1;
-        unsigned spins = 0;
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(bar.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 255u) == 0u) {
-                if (__hip_atomic_load(bar.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
-                if (wall_clock64() - t0 > PZ_SPIN_LIMIT) {
-                    __hip_atomic_store(bar.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = 0; break;
-                }
-            }
-        }
-        *lds_ok = ok;
-    }
-    __syncthreads();
-    return *lds_ok != 0;
+    const pz_v4u q = {(unsigned)__double2loint(v), tag, (unsigned)__double2hiint(v), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, granule * 16, 0, 16);
 }
 
-// the K leading entries of acc.v, summed (EP_GMAX: maximum) over the workgroup: red [PZ_WAVES * K] scratch, out[K]
-template <int K>
-__device__ __forceinline__ void pz_block_reduce_ev(const ThreadAcc &acc, double *red, double *out, int tid)
+// poll the granule pair until both halves carry `tag`; false: the launch is being abandoned
+__device__ __forceinline__ bool pz_poll(__amdgpu_buffer_rsrc_t r, int granule, unsigned tag, int *abort_flag, double &v)
 {
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const double v = (k == EP_GMAX) ? wave_max(acc.v[k]) : wave_sum(acc.v[k]);
-        if (lane == 0) red[wave * K + k] = v;
+    for (unsigned tries = 0;; ++tries) {
+        const pz_v4u q = __builtin_amdgcn_raw_buffer_load_b128(r, granule * 16, 0, 16);
+        if (q.y == tag && q.w == tag) { v = __hiloint2double((int)q.z, (int)q.x); return true; }
+        asm volatile("" ::: "memory");                          // (the next load is a new load)
+        __builtin_amdgcn_s_sleep(1);
+        if ((tries & 1023u) == 1023u) {
+            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (tries > PZ_POLL_LIMIT) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+        }
     }
-    __syncthreads();
-    if (tid < K) {
-        double v = red[tid];
-#pragma unroll
-        for (int ww = 1; ww < PZ_WAVES; ++ww) v = (tid == EP_GMAX) ? fmax(v, red[ww * K + tid]) : v + red[ww * K + tid];
-        out[tid] = v;
-    }
-    __syncthreads();
 }
 
 // Gram update + compact-form direction coefficients by ONE wave, everything in LDS (the twin of coeffs_wave in
 // va_kernels.hip; serial form: va_core.h direction_coeffs_view).  sSY / sYY: m x m, physical-slot indexed, persistent.
-__device__ __forceinline__ void pz_coeffs(SeedHot &s, const double *up, double *sSY, double *sYY, double *sp,
+// up[]: the update totals in k_update's layout, the old pairs indexed as they were ordered BEFORE the line-search step:
+// joff = 1 when that step evicted the oldest pair (new position j = old position j + 1).
+__device__ __forceinline__ void pz_coeffs(SeedHot &s, const double *up, int joff, double *sSY, double *sYY, double *sp,
                                           double *cYs, double *cSs, int m, int lane)
 {
     const int nold = s.nold, col = s.col, sn = s.slot;
@@ -138,10 +129,11 @@ __device__ __forceinline__ void pz_coeffs(SeedHot &s, const double *up, double *
     const double dr = s.dr;
     double theta = s.theta;
     const int myslot = lane < col ? s.order[lane] : 0;
+    const double *upo = up + UP_OLD + 4 * ((lane < nold ? lane : 0) + joff);
     if (lane < MAX_M) { cYs[lane] = 0.0; cSs[lane] = 0.0; }
     if (hist) {
         if (lane < nold) {
-            const double sjy = up[UP_OLD + 4 * lane + 2], yjy = up[UP_OLD + 4 * lane + 3];
+            const double sjy = upo[2], yjy = upo[3];
             sSY[myslot * m + sn] = sjy; sYY[myslot * m + sn] = yjy; sYY[sn * m + myslot] = yjy;
         }
         if (lane == 0) { sSY[sn * m + sn] = dr; sYY[sn * m + sn] = up[UP_YY]; }   // s.y as the line search saw it
@@ -149,36 +141,84 @@ __device__ __forceinline__ void pz_coeffs(SeedHot &s, const double *up, double *
     }
     wave_sync_lds();
     double aj = 0.0, bj = 0.0;
-    if (lane < nold) { aj = up[UP_OLD + 4 * lane + 0]; bj = up[UP_OLD + 4 * lane + 1]; }
+    if (lane < nold) { aj = upo[0]; bj = upo[1]; }
     if (hist && lane == col - 1) { aj = up[UP_SGT]; bj = up[UP_YGT]; }
     const double gamma = 1.0 / theta;
     const double rjj = lane < col ? sSY[myslot * m + myslot] : 1.0;
     const double rinv = 1.0 / rjj;
-    double pj = 0.0;                                                   // p = R^-1 a  (R_ji = S_j . Y_i for j <= i)
-    for (int i = col - 1; i >= 0; --i) {
-        const int si = __builtin_amdgcn_readlane(myslot, i);
-        const double pi = lane_scalar(aj * rinv, i);
-        if (lane == i) pj = pi;
-        if (lane < i) aj -= sSY[myslot * m + si] * pi;
-    }
-    if (lane < MAX_M) sp[lane] = pj;
-    wave_sync_lds();
-    double qj = 0.0;                                                   // q = (D + gamma Y'Y) p - gamma b
-    if (lane < col) {
-        double acc = 0.0;
-        for (int k = 0; k < col; ++k) acc += sYY[myslot * m + __builtin_amdgcn_readlane(myslot, k)] * sp[k];
-        qj = rjj * pj + gamma * acc - gamma * bj;
-    }
-    double uj = 0.0;                                                   // u = R^-T q
-    for (int i = 0; i < col; ++i) {
-        const int si = __builtin_amdgcn_readlane(myslot, i);
-        const double ui = lane_scalar(qj * rinv, i);
-        if (lane == i) uj = ui;
-        if (lane > i && lane < col) qj -= sSY[si * m + myslot] * ui;
+    double pj = 0.0, qj = 0.0, uj = 0.0;
+    if (col <= PZ_MREG) {
+        // the lane's row and column of R = S'Y and its row of Y'Y in registers (position order): the two triangular
+        // solves then run on readlanes alone -- no LDS round trip inside their dependent chains
+        // (unconditional loads at in-range addresses: entries of unused slots are finite and never enter a sum)
+        double rrow[PZ_MREG], rcol[PZ_MREG], yrow[PZ_MREG];
+        const int myrow = myslot * m;
+#pragma unroll
+        for (int i = 0; i < PZ_MREG; ++i) {
+            const int si = s.order[i];                                  // (one LDS word, broadcast; always a slot number < m)
+            rrow[i] = sSY[myrow + si];
+            rcol[i] = sSY[si * m + myslot];
+            yrow[i] = sYY[myrow + si];
+        }
+#pragma unroll
+        for (int i = PZ_MREG - 1; i >= 0; --i) {                        // p = R^-1 a  (R_ji = S_j . Y_i for j <= i)
+            if (i < col) {
+                const double pi = lane_scalar(aj * rinv, i);
+                if (lane == i) pj = pi;
+                if (lane < i) aj -= rrow[i] * pi;
+            }
+        }
+        double acc = 0.0;                                               // q = (D + gamma Y'Y) p - gamma b
+#pragma unroll
+        for (int k = 0; k < PZ_MREG; ++k)
+            if (k < col) acc += yrow[k] * lane_scalar(pj, k);
+        if (lane < col) qj = rjj * pj + gamma * acc - gamma * bj;
+#pragma unroll
+        for (int i = 0; i < PZ_MREG; ++i) {                             // u = R^-T q
+            if (i < col) {
+                const double ui = lane_scalar(qj * rinv, i);
+                if (lane == i) uj = ui;
+                if (lane > i && lane < col) qj -= rcol[i] * ui;
+            }
+        }
+    } else {
+        for (int i = col - 1; i >= 0; --i) {
+            const int si = __builtin_amdgcn_readlane(myslot, i);
+            const double pi = lane_scalar(aj * rinv, i);
+            if (lane == i) pj = pi;
+            if (lane < i) aj -= sSY[myslot * m + si] * pi;
+        }
+        if (lane < MAX_M) sp[lane] = pj;
+        wave_sync_lds();
+        if (lane < col) {
+            double acc = 0.0;
+            for (int k = 0; k < col; ++k) acc += sYY[myslot * m + __builtin_amdgcn_readlane(myslot, k)] * sp[k];
+            qj = rjj * pj + gamma * acc - gamma * bj;
+        }
+        for (int i = 0; i < col; ++i) {
+            const int si = __builtin_amdgcn_readlane(myslot, i);
+            const double ui = lane_scalar(qj * rinv, i);
+            if (lane == i) uj = ui;
+            if (lane > i && lane < col) qj -= sSY[si * m + myslot] * ui;
+        }
     }
     if (lane < col) { cYs[myslot] = gamma * pj; cSs[myslot] = -uj; }
     if (lane == 0) { s.cg = -gamma; s.theta = theta; }
     wave_sync_lds();
+}
+
+// job r of the 2 col0 + 3 inner-product jobs of a trial point: which vector meets g_t and y, and where the two sums go
+// (k_update's layout).  kind 0: a stored vector V, 1: y, 2: s, 3: g_t (o1 < 0: one sum only)
+struct PzJob { const double *V; int kind, o0, o1; };
+__device__ __forceinline__ PzJob pz_job(int r, int col0, const SeedHot *hot, const double *S, const double *Y, int nvh)
+{
+    PzJob j{nullptr, 0, 0, -1};
+    if (r < col0) { j.V = S + (size_t)hot->order[r] * nvh; j.o0 = UP_OLD + 4 * r + 0; j.o1 = UP_OLD + 4 * r + 2; }
+    else if (r < 2 * col0) { j.V = Y + (size_t)hot->order[r - col0] * nvh; j.o0 = UP_OLD + 4 * (r - col0) + 1; j.o1 = UP_OLD + 4 * (r - col0) + 3; }
+    else if (r == 2 * col0) { j.kind = 1; j.o0 = UP_YGT; j.o1 = UP_YY; }
+    else if (r == 2 * col0 + 1) { j.kind = 2; j.o0 = UP_SGT; j.o1 = UP_SY; }
+    else { j.kind = 3; j.o0 = UP_GTGT; j.o1 = -1; }
+    return j;
 }
 
 template <class RHS, int DISC>
@@ -188,164 +228,255 @@ __global__ __launch_bounds__(PZ_THREADS) void k_seed(const Dev dv)
     const Dims &dm = dv.dm;                 // the persistent image: dm.T = rows per slice, dm.ntiles = G
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
     constexpr int K = EP_GP + RHS::NP;      // eval partial columns in use
+    constexpr int NT = PZ_THREADS;
     const int G = dm.ntiles, T = dm.T, D = dm.D, m = dm.m, NPe = dm.NPest;
     const int b = blockIdx.x / G, w = blockIdx.x - b * G;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n0 = w * T;
     const int rows = (dm.N - n0 < T) ? dm.N - n0 : T;
-    const int ne = rows * D;                // own path elements
-    const int TD = T * D, nv = TD + NPe;    // LDS pitch of a vector: [T rows | estimated parameters]
-    const int R = T + HL + HR, RD = R * D;
+    const int R = T + HL + HR, RD = R * D;  // staged rows: the slice and its halo
+    const int nvh = RD + NPe;               // LDS pitch of a vector: [R rows | estimated parameters]
+    const int own0 = HL * D, ne = rows * D; // own path elements: [own0, own0 + ne)
+    const bool count_p = (w == 0);          // the parameter block enters the g.d partial once
 
-    double *X = smem, *Gv = X + nv, *Dd = Gv + nv, *GT = Dd + nv;
-    double *S = GT + nv, *Y = S + (size_t)m * nv;
-    double *xs = Y + (size_t)m * nv, *fs = xs + RD, *qs = fs + RD;
-    double *red = qs + RD;                          // [PZ_WAVES * UP_N]
-    double *tot = red + PZ_WAVES * UP_N;            // [UP_N] update totals
-    double *evt = tot + UP_N;                       // [EP_N] evaluation totals
-    double *sSY = evt + EP_N, *sYY = sSY + m * m;
+    double *X = smem, *Gv = X + nvh, *Dd = Gv + nvh, *GT = Dd + nvh;
+    double *S = GT + nvh, *Y = S + (size_t)m * nvh;
+    double *xs = Y + (size_t)m * nvh, *fs = xs + RD, *qs = fs + RD;
+    double *red = qs + RD;                          // [PZ_WAVES * EP_N]
+    double *part = red + PZ_WAVES * EP_N;           // [PZ_HALO] this workgroup's sums, exchange-row layout
+    double *tot = part + PZ_HALO;                   // [PZ_HALO] the seed's totals
+    double *sSY = tot + PZ_HALO, *sYY = sSY + m * m;
     double *sp = sYY + m * m, *cYs = sp + MAX_M, *cSs = cYs + MAX_M;
     SeedHot *hot = reinterpret_cast<SeedHot *>(cSs + MAX_M);
     int *lds_ok = reinterpret_cast<int *>(reinterpret_cast<double *>(hot) + sizeof(SeedHot) / 8);
+    double *stg = reinterpret_cast<double *>(lds_ok) + 1;              // [G * pz_sum_cols] the all-gather's staging rows
+    // read-only rows the tile phases look up every cycle, copied once: the slice's observations and weight rows, the
+    // column -> data-column map, the estimated parameters' slots
+    double *ylds = stg + (size_t)G * pz_sum_cols(RHS::NP, m), *rmlds = ylds + (T + 1) * dm.L, *rflds = rmlds + (T + 1) * dm.L;
+    int *lmap_l = reinterpret_cast<int *>(rflds + RD), *pidx_l = lmap_l + D;
 
-    PzBarrier bar{dv.pz.bar + (size_t)b * 32, 0ull, dv.pz.abort_flag, G};
-    double *edge = dv.pz.edge + ((size_t)b * G + w) * (PZ_EDGE_ROWS * D);
-    double *my_evp = dv.pz.evp + ((size_t)b * G + w) * EP_N;
-    double *my_upp = dv.pz.upp + ((size_t)b * G + w) * UP_N;
-    const double *all_evp = dv.pz.evp + (size_t)b * G * EP_N, *all_upp = dv.pz.upp + (size_t)b * G * UP_N;
-    const double *all_gdp = dv.pz.gdp + (size_t)b * G;
-    const bool count_p = (w == 0);          // the parameter block enters inner products once
+    const int PD = pz_row_granules(D);
+    // the seed's exchange area: [2 buffers][G rows][PD granule pairs of 16 bytes]
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(dv.pz.xch + (size_t)b * 2 * G * PD * 2), 0, (int)(2 * G * PD * 16), 0x00020000);
 
-    // ---- the seed's state and its start point
+    // ---- the seed's state and its start point (halo rows included; rows that do not exist stay zero for good)
     {
         const double *xg = dv.x + (size_t)b * dm.ld;
-        for (int e = tid; e < nv; e += PZ_THREADS) {
+        for (int e = tid; e < nvh; e += NT) {
             double v = 0.0;
-            if (e < ne) v = xg[(size_t)n0 * D + e];
-            else if (e >= TD) v = xg[dm.ND + (e - TD)];
+            if (e < RD) {
+                const int lr = e / D, row = n0 - HL + lr;
+                if (row >= 0 && row < dm.N) v = xg[(size_t)row * D + (e - lr * D)];
+            } else v = xg[dm.ND + (e - RD)];
             X[e] = v; Gv[e] = 0.0; Dd[e] = 0.0; GT[e] = 0.0;
         }
-        for (int e = tid; e < 2 * m * nv; e += PZ_THREADS) S[e] = 0.0;        // (S and Y are adjacent)
-        for (int e = tid; e < 2 * m * m; e += PZ_THREADS) sSY[e] = 0.0;
+        for (int e = tid; e < 2 * m * nvh; e += NT) S[e] = 0.0;              // (S and Y are adjacent)
+        for (int e = tid; e < 2 * m * m; e += NT) sSY[e] = 0.0;
+        for (int e = tid; e < 2 * PZ_HALO; e += NT) part[e] = 0.0;           // (part and tot are adjacent)
         const double *gst = reinterpret_cast<const double *>(static_cast<const SeedHot *>(&dv.st[b]));
         if (tid < (int)(sizeof(SeedHot) / 8)) reinterpret_cast<double *>(hot)[tid] = gst[tid];
         if (tid == 0) *lds_ok = 1;
     }
+    ProblemPtrs ppl = dv.pp;
+    {
+        const int L = dm.L;
+        const int nd_lo = (n0 + dm.nskip - 1) / dm.nskip;                  // data rows that fall on own model rows
+        int nd_hi = (n0 + rows - 1) / dm.nskip;
+        if (nd_hi > dm.N_data - 1) nd_hi = dm.N_data - 1;
+        const int ndn = nd_hi >= nd_lo ? nd_hi - nd_lo + 1 : 0;
+        for (int e = tid; e < ndn * L; e += NT) {
+            ylds[e] = dv.pp.Y[(size_t)nd_lo * L + e];
+            if (dv.pp.rm_arr) rmlds[e] = dv.pp.rm_arr[(size_t)nd_lo * L + e];
+        }
+        const int r_lo = n0 - HL > 0 ? n0 - HL : 0, r_hi = n0 + T < dm.N - 1 ? n0 + T : dm.N - 1;      // rows of RF0: residuals (r, r + 1)
+        if (dv.pp.rf0_arr)
+            for (int e = tid; e < (r_hi - r_lo) * D; e += NT) rflds[e] = dv.pp.rf0_arr[(size_t)r_lo * D + e];
+        for (int e = tid; e < D; e += NT) lmap_l[e] = dv.pp.lmap[e];
+        for (int e = tid; e < NPe; e += NT) pidx_l[e] = dv.pp.Pidx[e];
+        ppl.Y = ylds - (long)nd_lo * L;
+        if (dv.pp.rm_arr) ppl.rm_arr = rmlds - (long)nd_lo * L;
+        if (dv.pp.rf0_arr) ppl.rf0_arr = rflds - (long)r_lo * D;
+        ppl.lmap = lmap_l; ppl.Pidx = pidx_l;
+    }
+    double pfix[RHS::NP > 0 ? RHS::NP : 1];
+#pragma unroll
+    for (int k = 0; k < RHS::NP; ++k) pfix[k] = dv.pp.Pfull[(size_t)b * dm.NP + k];
     __syncthreads();
 
     TileCtx c;
     c.n0 = n0; c.R = R; c.xs = xs; c.fs = fs; c.qs = qs;
-    c.xg = nullptr; c.dg = Dd; c.gtg = GT; c.goff = (long)n0 * D;
+    c.xg = nullptr; c.dg = Dd; c.gtg = GT; c.goff = (long)(n0 - HL) * D;
     c.tmodel = dv.pp.tmodel; c.stim = dv.pp.stim; c.nstim = dv.pp.nstim;
     c.ps = nullptr;
 
-    bool pending_gd = false;
     long long cyc = 0;
 #ifdef VA_PZ_STAMPS
-    long long pz_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pz_prev = wall_clock64();
+    long long pz_acc[PZ_NSTAMP - 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pz_prev = wall_clock64();
+    const long long pz_c0 = clock64(), pz_w0 = pz_prev;          // (shader-clock cycles against the 100 MHz wall clock: the clock the launch ran at)
 #endif
     for (;; ++cyc) {
-        PZ_MARK(11);
+        PZ_MARK(12);
         const int phase = hot->phase;
         if (phase != PH_START && phase != PH_LS) break;
         if (cyc >= dv.pz.max_cycles) {
             if (tid == 0) __hip_atomic_store(dv.pz.abort_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
+        const unsigned gen = (unsigned)cyc + 1u;
+        const int par = (int)(gen & 1u);
         const int use_d = phase == PH_LS;
         const double stp = hot->stp;
+        const int col0 = use_d ? hot->col : 0;        // pairs in the history while this point is evaluated
         c.use_d = use_d; c.stp = stp; c.c = 2.0 * hot->rf_scale * dm.cfe;
 
-        // ---- evaluation, 1: the trial point of the own rows; rows of the slice that do not exist stay zero
-        for (int e = tid; e < RD; e += PZ_THREADS) {
-            const int o = e - HL * D;
-            double v = 0.0;
-            if (o >= 0 && o < ne) {
-                v = X[o];
-                if (use_d) v = clampb(trial(v, stp, Dd[o]), dv.pp, (long)n0 * D + o);
-            }
-            xs[e] = v;
-        }
+        // ---- evaluation, 1: the trial point of the slice and its halo
+        for (int e = tid; e < RD; e += NT) xs[e] = use_d ? trial(X[e], stp, Dd[e]) : X[e];
         // (parameters of the right-hand side: fixed ones from the table, estimated ones from the trial point)
 #pragma unroll
-        for (int k = 0; k < RHS::NP; ++k) c.p[k] = dv.pp.Pfull[(size_t)b * dm.NP + k];
+        for (int k = 0; k < RHS::NP; ++k) c.p[k] = pfix[k];
         for (int k = 0; k < NPe; ++k) {
-            double v = X[TD + k];
-            if (use_d) v = clampb(trial(v, stp, Dd[TD + k]), dv.pp, dm.ND + k);
-            const int dst = dv.pp.Pidx[k];
+            double v = X[RD + k];
+            if (use_d) v = trial(v, stp, Dd[RD + k]);
+            const int dst = pidx_l[k];
 #pragma unroll
             for (int j = 0; j < RHS::NP; ++j) c.p[j] = (dst == j) ? v : c.p[j];
         }
         __syncthreads();
         PZ_MARK(0);
-        if (G > 1) {
-            // halo exchange: my last two rows / my first row, as the neighbours will stage them
-            for (int e = tid; e < PZ_EDGE_ROWS * D; e += PZ_THREADS) {
-                const int r = e / D, j = e - r * D;
-                const int lr = r < 2 ? HL + rows - 2 + r : HL;           // (every slice holds >= 2 rows)
-                st_sc1(edge + e, xs[lr * D + j]);
-            }
-            if (!pz_grid_barrier(bar, tid, lds_ok)) return;               // ---- A
-            if (w > 0) {
-                const double *le = dv.pz.edge + ((size_t)b * G + w - 1) * (PZ_EDGE_ROWS * D);
-                for (int e = tid; e < HL * D; e += PZ_THREADS) xs[e] = ld_sc1(le + (2 - HL) * D + e);
-            }
-            if (w + 1 < G) {
-                const double *re = dv.pz.edge + ((size_t)b * G + w + 1) * (PZ_EDGE_ROWS * D);
-                for (int e = tid; e < HR * D; e += PZ_THREADS) xs[(HL + T) * D + e] = ld_sc1(re + 2 * D + e);
-            }
-            if (pending_gd && tid == 0) {
-                double v = 0.0;
-                for (int t = 0; t < G; ++t) v += ld_sc1(all_gdp + t);
-                hot->gd_dir = v;
-            }
-        }
-        pending_gd = false;
-        __syncthreads();
-        PZ_MARK(1);
 
         // ---- evaluation, 2: the flat tile phases (va_core.h) on the staged rows
         ThreadAcc acc;
         acc.clear();
-        tile_f<RHS, DISC>(dm, c, tid, PZ_THREADS);
+        tile_f<RHS, DISC>(dm, c, tid, NT);
         __syncthreads();
-        tile_q<DISC>(dm, dv.pp, c, acc, tid, PZ_THREADS);
+        tile_q<DISC>(dm, ppl, c, acc, tid, NT);
         __syncthreads();
         if (dv.pp.rf0_full) {
-            tile_qfull<DISC>(dm, dv.pp, c, acc, tid, PZ_THREADS);
+            tile_qfull<DISC>(dm, ppl, c, acc, tid, NT);
             double *t = c.qs; c.qs = c.fs; c.fs = t;
             __syncthreads();
         }
-        tile_s<DISC>(dm, c, tid, PZ_THREADS);
+        tile_s<DISC>(dm, c, tid, NT);
         __syncthreads();
-        tile_g<RHS, DISC>(dm, dv.pp, c, acc, tid, PZ_THREADS);
+        tile_g<RHS, DISC>(dm, ppl, c, acc, tid, NT);
         if (dv.pp.rf0_full) { double *t = c.qs; c.qs = c.fs; c.fs = t; }
-        PZ_MARK(2);
-        pz_block_reduce_ev<K>(acc, red, evt, tid);
-        PZ_MARK(3);
-        if (G > 1) {
-            if (tid < K) st_sc1(my_evp + tid, evt[tid]);
-            if (!pz_grid_barrier(bar, tid, lds_ok)) return;               // ---- B
-            if (tid < K) evt[tid] = col_reduce<true>(all_evp + tid, G, EP_N, 0, 1, tid == EP_GMAX);
-            __syncthreads();
+        PZ_MARK(1);
+        // the workgroup's evaluation sums: wave totals
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double v = (k == EP_GMAX) ? wave_max(acc.v[k]) : wave_sum(acc.v[k]);
+            if (lane == 0) red[wave * K + k] = v;
         }
+        __syncthreads();                                  // (the slice's gradient rows are complete)
+        PZ_MARK(2);
+
+        // ---- this workgroup's row goes out in two parts.  The last wave: evaluation sums, the g.d partial of the direction
+        // in use, the slice's edge gradient rows.  The other waves meanwhile: SPECULATION -- the inner products the update
+        // will need if this point is accepted, a job per wave, its lanes striding the slice's own path elements (the
+        // parameter block joins after the all-gather, when its gradient is known), each wave publishing its own two sums.
+        const int KU = use_d ? UP_OLD + 4 * col0 : 0;
+        const int njobs = use_d ? 2 * col0 + 3 : 0;
+        const int mine = (par * G + w) * PD;
+        PzJob myjob{nullptr, 3, 0, -1};
+        if (tid < njobs) myjob = pz_job(tid, col0, hot, S, Y, nvh);           // (for the parameter block, after the step below has reordered the history)
+        if (wave == PZ_WAVES - 1) {
+            if (lane < K) {
+                double v = red[lane];
+#pragma unroll
+                for (int ww = 1; ww < PZ_WAVES; ++ww) v = (lane == EP_GMAX) ? fmax(v, red[ww * K + lane]) : v + red[ww * K + lane];
+                part[lane] = v;
+                if (G > 1) pz_put(xr, mine + lane, v, gen);
+            }
+            if (G > 1) {
+                if (lane == K) pz_put(xr, mine + PZ_GDO, part[PZ_GDO], gen);
+                for (int h = lane; h < PZ_EDGE_ROWS * D; h += 64) {
+                    const int r = h / D, j = h - r * D;
+                    const int lr = r < 2 ? HL + rows - 2 + r : HL;       // (every slice holds >= 2 rows)
+                    pz_put(xr, mine + PZ_HALO + h, GT[lr * D + j], gen);
+                }
+            }
+        }
+        {
+            for (int r = wave; r < njobs; r += PZ_WAVES) {
+                const PzJob jb = pz_job(r, col0, hot, S, Y, nvh);
+                double a0 = 0.0, a1 = 0.0;
+                const double *V = jb.kind == 0 ? jb.V : (jb.kind == 2 ? Dd : GT);      // (wave-uniform)
+                for (int i0 = lane; i0 < ne; i0 += 256) {
+                    double tv[4], gv[4], vv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {                                      // (all twelve loads before the first use)
+                        const int i = i0 + 64 * u, e = own0 + (i < ne ? i : 0);
+                        tv[u] = GT[e]; gv[u] = Gv[e]; vv[u] = V[e];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (i0 + 64 * u < ne) {
+                            const double yv = tv[u] - gv[u];
+                            const double v = jb.kind == 0 ? vv[u] : (jb.kind == 1 ? yv : (jb.kind == 2 ? stp * vv[u] : tv[u]));
+                            a0 += v * tv[u]; a1 += v * yv;
+                        }
+                    }
+                }
+                a0 = wave_sum(a0); a1 = wave_sum(a1);
+                if (lane == 0) {
+                    part[EP_N + jb.o0] = a0;
+                    if (jb.o1 >= 0) part[EP_N + jb.o1] = a1;
+                    if (G > 1) {
+                        pz_put(xr, mine + EP_N + jb.o0, a0, gen);
+                        if (jb.o1 >= 0) pz_put(xr, mine + EP_N + jb.o1, a1, gen);
+                    }
+                }
+            }
+        }
+        PZ_MARK(3);
+
+        // ---- all-gather, first part: every workgroup's evaluation sums, the neighbours' gradient rows
+        const int nev = K + 1;
+        bool ok = true;
+        if (G > 1) {
+            if (w > 0) {
+                const int src = (par * G + w - 1) * PD + PZ_HALO + (2 - HL) * D;
+                for (int e = tid; e < HL * D; e += NT) { double v = 0.0; ok = pz_poll(xr, src + e, gen, dv.pz.abort_flag, v) && ok; GT[e] = v; }
+            }
+            if (w + 1 < G) {
+                const int src = (par * G + w + 1) * PD + PZ_HALO + 2 * D;
+                for (int e = tid; e < HR * D; e += NT) { double v = 0.0; ok = pz_poll(xr, src + e, gen, dv.pz.abort_flag, v) && ok; GT[(HL + T) * D + e] = v; }
+            }
+            for (int it = tid; it < nev * G; it += NT) {
+                const int g = it / nev, ci = it - g * nev;
+                double v = 0.0;
+                ok = pz_poll(xr, (par * G + g) * PD + (ci < K ? ci : PZ_GDO), gen, dv.pz.abort_flag, v) && ok;
+                stg[it] = v;
+            }
+            if (!ok) *lds_ok = 0;
+            __syncthreads();
+            if (*lds_ok == 0) return;
+            if (tid < nev) {
+                double v = stg[tid];
+                for (int g = 1; g < G; ++g) v = (tid == EP_GMAX) ? fmax(v, stg[g * nev + tid]) : v + stg[g * nev + tid];
+                tot[tid < K ? tid : PZ_GDO] = v;
+            }
+        } else {
+            __syncthreads();
+            if (tid < nev) tot[tid < K ? tid : PZ_GDO] = part[tid < K ? tid : PZ_GDO];
+        }
+        __syncthreads();
         PZ_MARK(4);
 
-        // ---- evaluation, 3: parameter tail of the gradient, then one line-search / ladder step (every workgroup, identically)
+        // ---- decision (thread 0; every workgroup, identically): the parameter tail of the gradient, then one line-search /
+        // ladder step.  Beside it the other waves bring in the second part of the rows: the speculated inner products.
         if (tid == 0) {
+            for (int k = 0; k < NPe; ++k) {
+                const double g = tot[EP_GP + pidx_l[k]];
+                GT[RD + k] = g;
+                if (use_d) tot[EP_GTD] += g * Dd[RD + k];
+                tot[EP_GN2] += g * g;
+                tot[EP_GMAX] = fmax(tot[EP_GMAX], fabs(g));
+            }
             double ev[EP_N];
 #pragma unroll
-            for (int k = 0; k < EP_N; ++k) ev[k] = k < K ? evt[k] : 0.0;
-            for (int k = 0; k < NPe; ++k) {
-                const int idx = dv.pp.Pidx[k];
-                double g = 0.0;
-#pragma unroll
-                for (int j = 0; j < RHS::NP; ++j) g = (idx == j) ? ev[EP_GP + j] : g;
-                GT[TD + k] = g;
-                if (use_d) ev[EP_GTD] += g * Dd[TD + k];
-                ev[EP_GN2] += g * g;
-                ev[EP_GMAX] = fmax(ev[EP_GMAX], fabs(g));
-            }
+            for (int k = 0; k < EP_N; ++k) ev[k] = k < K ? tot[k] : 0.0;
             if (w == 0) atomicAdd(dv.n_evals, 1ULL);
             SeedResults r;
             r.ame = dv.ame + (size_t)b * dv.max_beta * 3;
@@ -355,140 +486,130 @@ __global__ __launch_bounds__(PZ_THREADS) void k_seed(const Dev dv)
             r.nfev = dv.nfev + (size_t)b * dv.max_beta;
             int dec = 0;
             double dirp[DP_N];
-            dirp[DP_GD] = hot->gd_dir; dirp[DP_DD] = 0.0;
+            dirp[DP_GD] = tot[PZ_GDO]; dirp[DP_DD] = 0.0;
+            hot->gd_dir = tot[PZ_GDO];
+            hot->pad0 = 0;
             ls_step(*hot, ev, dirp, dv.o, dv.rf_ladder, dv.nbeta, r, &dec, dm.cme, dm.cfe, false);
             if (dec && w == 0) atomicSub(dv.n_active, 1);
+        } else if (G > 1 && tid >= 64) {
+            double *stg2 = stg + nev * G;
+            for (int it = tid - 64; it < KU * G; it += NT - 64) {
+                const int g = it / KU, ci = it - g * KU;
+                double v = 0.0;
+                ok = pz_poll(xr, (par * G + g) * PD + EP_N + ci, gen, dv.pz.abort_flag, v) && ok;
+                stg2[it] = v;
+            }
+            if (!ok) *lds_ok = 0;
         }
         __syncthreads();
+        if (*lds_ok == 0) return;
         PZ_MARK(5);
+        if (use_d) {
+            // the seed's inner products: rows added in order, then the parameter block's share (the job's own vector
+            // against g_t's and y's parameter entries, now that the tail has formed them)
+            if (tid < KU) {
+                double v;
+                if (G > 1) {
+                    const double *stg2 = stg + nev * G;
+                    v = stg2[tid];
+                    for (int g = 1; g < G; ++g) v += stg2[g * KU + tid];
+                } else v = part[EP_N + tid];
+                tot[EP_N + tid] = v;
+            }
+            __syncthreads();
+            if (NPe > 0) {
+                if (tid < njobs) {
+                    double a0 = 0.0, a1 = 0.0;
+                    for (int k = 0; k < NPe; ++k) {
+                        const int e = RD + k;
+                        const double tv = GT[e], yv = tv - Gv[e];
+                        const double v = myjob.kind == 0 ? myjob.V[e] : (myjob.kind == 1 ? yv : (myjob.kind == 2 ? stp * Dd[e] : tv));
+                        a0 += v * tv; a1 += v * yv;
+                    }
+                    tot[EP_N + myjob.o0] += a0;
+                    if (myjob.o1 >= 0) tot[EP_N + myjob.o1] += a1;
+                }
+                __syncthreads();
+            }
+        }
+        PZ_MARK(6);
 
-        // ---- update: x += stp*d, the new pair, g <- g_t, inner products (k_update's arithmetic on the own slice)
+        // ---- update and direction
         const int upd = hot->upd, dir = hot->dir;
         if (!upd && !dir) continue;
         const bool hist = (upd & UPD_HIST) != 0;
-        const int slot = hot->slot, nold = dir ? hot->nold : 0;
-        const double stpu = hot->stp_upd;
-        double *Sn = S + (size_t)slot * nv, *Yn = Y + (size_t)slot * nv;
-        double *mp = nullptr;
-        if ((upd & UPD_STORE) && dv.minpaths) mp = dv.minpaths + ((size_t)b * dv.max_beta + hot->store_idx) * (dm.ND + dm.NP);
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
-        for (int e = tid; e < nv; e += PZ_THREADS) {
-            const double dv2 = Dd[e], gv = Gv[e], tv = GT[e];
-            double xv = X[e];
-            if (upd & UPD_X) {
-                xv = clampb(trial(xv, stpu, dv2), dv.pp, e < TD ? (long)n0 * D + e : (long)dm.ND + (e - TD));
-                X[e] = xv;
-            }
-            if (upd & UPD_STORE) {
-                if (e < ne) { if (mp) mp[(size_t)n0 * D + e] = xv; }
-                else if (e >= TD && w == 0) {
-                    const int k = e - TD;
-                    dv.pest[((size_t)b * dv.max_beta + hot->store_idx) * NPe + k] = xv;
-                    if (mp) mp[dm.ND + dv.pp.Pidx[k]] = xv;
-                }
-            }
-            double sv = 0.0, yv = 0.0;
-            if (hist) { sv = stpu * dv2; yv = tv - gv; Sn[e] = sv; Yn[e] = yv; }
-            if (upd & UPD_G) Gv[e] = tv;
-            if (e < TD || count_p) {
-                a0 += yv * tv; a1 += sv * tv; a2 += yv * yv; a3 += sv * yv; a4 += tv * tv;
-            }
-        }
-        if (mp && w == 0 && tid == 0) {
-            for (int j = 0; j < dm.NP; ++j) {         // fixed (non-estimated) parameters of the stored step come from P
-                bool est = false;
-                for (int k = 0; k < NPe; ++k) est = est || (dv.pp.Pidx[k] == j);
-                if (!est) mp[dm.ND + j] = dv.pp.Pfull[(size_t)b * dm.NP + j];
-            }
-        }
-        if (!dir) {
-            if (tid == 0) hot->upd = 0;
-            __syncthreads();
-            continue;
-        }
-        {
-            double v;
-            v = wave_sum(a0); if (lane == 0) red[wave * UP_N + UP_YGT] = v;
-            v = wave_sum(a1); if (lane == 0) red[wave * UP_N + UP_SGT] = v;
-            v = wave_sum(a2); if (lane == 0) red[wave * UP_N + UP_YY] = v;
-            v = wave_sum(a3); if (lane == 0) red[wave * UP_N + UP_SY] = v;
-            v = wave_sum(a4); if (lane == 0) red[wave * UP_N + UP_GTGT] = v;
-        }
-        __syncthreads();                                  // (the new pair is in its slot)
-        // inner products with the old pairs: wave v takes pairs v, v + 4, ...; its lanes stride the slice
-        for (int j = wave; j < nold; j += PZ_WAVES) {
-            const int sj = hot->order[j];
-            const double *Sj = S + (size_t)sj * nv, *Yj = Y + (size_t)sj * nv;
-            double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-            for (int e = lane; e < nv; e += 64) {
-                if (e >= TD && !count_p) break;
-                const double sv = Sj[e], yj = Yj[e], tv = GT[e], yv = hist ? Yn[e] : 0.0;
-                b0 += sv * tv; b1 += yj * tv; b2 += sv * yv; b3 += yj * yv;
-            }
-            double v;
-            v = wave_sum(b0); if (lane == 0) tot[UP_OLD + 4 * j + 0] = v;
-            v = wave_sum(b1); if (lane == 0) tot[UP_OLD + 4 * j + 1] = v;
-            v = wave_sum(b2); if (lane == 0) tot[UP_OLD + 4 * j + 2] = v;
-            v = wave_sum(b3); if (lane == 0) tot[UP_OLD + 4 * j + 3] = v;
-        }
-        if (tid < UP_OLD) {
-            double v = red[tid];
-#pragma unroll
-            for (int ww = 1; ww < PZ_WAVES; ++ww) v += red[ww * UP_N + tid];
-            tot[tid] = v;
-        }
-        __syncthreads();
-        const int KU = UP_OLD + 4 * nold;
-        PZ_MARK(6);
-        if (G > 1) {
-            for (int k = tid; k < KU; k += PZ_THREADS) st_sc1(my_upp + k, tot[k]);
-            if (!pz_grid_barrier(bar, tid, lds_ok)) return;               // ---- C
-            for (int k = tid; k < KU; k += PZ_THREADS) tot[k] = col_reduce<true>(all_upp + k, G, UP_N, 0, 1, false);
+        const int joff = (hist && (hot->pad0 & 2)) ? 1 : 0;      // the step evicted the oldest pair: positions moved down by one
+        if (dir) {
+            if (wave == 0) pz_coeffs(*hot, tot + EP_N, joff, sSY, sYY, sp, cYs, cSs, m, lane);
             __syncthreads();
         }
         PZ_MARK(7);
-        if (wave == 0) pz_coeffs(*hot, tot, sSY, sYY, sp, cYs, cSs, m, lane);
-        __syncthreads();
-        PZ_MARK(8);
-
-        // ---- direction (k_direction's arithmetic on the own slice) and its g.d partial
         {
-            const int col = hot->col;
-            const double cg = hot->cg;
+            const int slot = hot->slot, col = hot->col;
+            const double stpu = hot->stp_upd, cg = hot->cg;
+            double *Sn = S + (size_t)slot * nvh, *Yn = Y + (size_t)slot * nvh;
+            double *mp = nullptr;
+            if ((upd & UPD_STORE) && dv.minpaths) mp = dv.minpaths + ((size_t)b * dv.max_beta + hot->store_idx) * (dm.ND + dm.NP);
             double gd = 0.0;
-            for (int e = tid; e < nv; e += PZ_THREADS) {
-                const double gv = Gv[e];
-                double a = cg * gv;
-                for (int j = 0; j < col; ++j) {
-                    const int sj = hot->order[j];
-                    a += cYs[sj] * Y[(size_t)sj * nv + e];
-                    a += cSs[sj] * S[(size_t)sj * nv + e];
+            for (int e = tid; e < nvh; e += NT) {
+                const double dv2 = Dd[e], gv = Gv[e], tv = GT[e];
+                double xv = X[e];
+                if (upd & UPD_X) { xv = trial(xv, stpu, dv2); X[e] = xv; }
+                if (upd & UPD_STORE) {
+                    if (e >= own0 && e < own0 + ne) { if (mp) mp[(size_t)n0 * D + (e - own0)] = xv; }
+                    else if (e >= RD && w == 0) {
+                        const int k = e - RD;
+                        dv.pest[((size_t)b * dv.max_beta + hot->store_idx) * NPe + k] = xv;
+                        if (mp) mp[dm.ND + dv.pp.Pidx[k]] = xv;
+                    }
                 }
-                Dd[e] = a;
-                if (e < TD || count_p) gd += gv * a;
+                if (hist) { Sn[e] = stpu * dv2; Yn[e] = tv - gv; }
+                double gn = gv;
+                if (upd & UPD_G) { gn = tv; Gv[e] = tv; }
+                if (dir) {
+                    double a = cg * gn;
+                    for (int j = 0; j < col; ++j) {
+                        const int sj = hot->order[j];
+                        a += cYs[sj] * Y[(size_t)sj * nvh + e];
+                        a += cSs[sj] * S[(size_t)sj * nvh + e];
+                    }
+                    Dd[e] = a;
+                    if ((e >= own0 && e < own0 + ne) || (e >= RD && count_p)) gd += gn * a;
+                }
             }
-            gd = wave_sum(gd);
-            if (lane == 0) red[wave] = gd;
+            if (mp && w == 0 && tid == 0) {
+                for (int j = 0; j < dm.NP; ++j) {         // fixed (non-estimated) parameters of the stored step come from P
+                    bool est = false;
+                    for (int k = 0; k < NPe; ++k) est = est || (dv.pp.Pidx[k] == j);
+                    if (!est) mp[dm.ND + j] = dv.pp.Pfull[(size_t)b * dm.NP + j];
+                }
+            }
+            if (dir) {
+                gd = wave_sum(gd);
+                if (lane == 0) red[wave] = gd;
+            }
             __syncthreads();
             if (tid == 0) {
-                const double v = ((red[0] + red[1]) + red[2]) + red[3];
-                if (G > 1) st_sc1(dv.pz.gdp + (size_t)b * G + w, v);       // (travels with barrier A of the next evaluation)
-                else hot->gd_dir = v;
+                if (dir) {
+                    double v = red[0];
+#pragma unroll
+                    for (int ww = 1; ww < PZ_WAVES; ++ww) v += red[ww];
+                    part[PZ_GDO] = v;                     // (travels with the next evaluation's row)
+                }
                 hot->upd = 0; hot->dir = 0;
             }
-            pending_gd = true;
             __syncthreads();
         }
-        PZ_MARK(9);
+        PZ_MARK(8);
     }
 
     // ---- the final iterate back to the seed's global vector; state for the host's bookkeeping
     __syncthreads();
     {
         double *xg = dv.x + (size_t)b * dm.ld;
-        for (int e = tid; e < nv; e += PZ_THREADS) {
-            if (e < ne) xg[(size_t)n0 * D + e] = X[e];
-            else if (e >= TD && w == 0) xg[dm.ND + (e - TD)] = X[e];
+        for (int e = tid; e < nvh; e += NT) {
+            if (e >= own0 && e < own0 + ne) xg[(size_t)n0 * D + (e - own0)] = X[e];
+            else if (e >= RD && w == 0) xg[dm.ND + (e - RD)] = X[e];
         }
         if (w == 0) {
             double *gst = reinterpret_cast<double *>(static_cast<SeedHot *>(&dv.st[b]));
@@ -498,8 +619,9 @@ __global__ __launch_bounds__(PZ_THREADS) void k_seed(const Dev dv)
     }
 #ifdef VA_PZ_STAMPS
     if (blockIdx.x == 0 && tid == 0) {
-        for (int i = 0; i < 12; ++i) dv.pz.upp[i] = (double)pz_acc[i];
-        dv.pz.upp[12] = (double)cyc;
+        pz_acc[9] = clock64() - pz_c0; pz_acc[10] = wall_clock64() - pz_w0;
+        for (int i = 0; i < PZ_NSTAMP - 1; ++i) dv.pz.stamps[i] = (double)pz_acc[i];
+        dv.pz.stamps[PZ_NSTAMP - 1] = (double)cyc;
     }
 #endif
 }
@@ -518,7 +640,7 @@ inline hipError_t seed_kernel_op(const Dev &dv, bool launch, hipStream_t s)
                                (const void *)k_seed<RHS, DISC_SH>, (const void *)k_seed<RHS, DISC_FWDMAP>};
     const void *k = seed_kernel_of(ks, dv.dm.disc);
     const int HL = dv.dm.disc == DISC_SH ? 2 : 1;
-    const size_t lds = 8 * persist_lds_doubles(dv.dm.T, dv.dm.D, dv.dm.NPest, dv.dm.m, HL);
+    const size_t lds = 8 * persist_lds_doubles(dv.dm.T, dv.dm.D, dv.dm.L, RHS::NP, dv.dm.NPest, dv.dm.m, HL, dv.dm.ntiles);
     if (!launch) return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     void *args[1] = {(void *)&dv};
     return hipLaunchCooperativeKernel(k, dim3(dv.dm.B * dv.dm.ntiles), dim3(PZ_THREADS), args, (unsigned)lds, s);
