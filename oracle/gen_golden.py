@@ -139,6 +139,8 @@ def ladder_case(va, name, Y, t, Lidx, N, disc, nbeta, seed_index, D=20):
                params=a.minpaths[:, ND:].copy(), final_path=a.minpaths[-1, :ND].copy(),
                path_mid=a.minpaths[nbeta // 2, :ND].copy(),
                nit=np.array(nit), exitflag=np.array(flags), nfev_total=nev[0])
+    # the reference's minimiser at EVERY rung (va_ode.py:776), for rung-local parity: kept in a fixture file of its own
+    rec["_minpaths"] = a.minpaths.copy()
     print("%-24s evals=%d  A_final=%.10e  k: %.4f -> %.6f  nit=%s" %
           (name, nev[0], a.A_array[-1], P0[0], a.minpaths[-1, ND], nit))
     return rec
@@ -346,9 +348,44 @@ def rffull_cases(va):
     return out
 
 
+def ladder_cases(va):
+    lad = {}
+    t, Y, _, Lidx = twin.make_twin(20, 200)
+    lad["g4_c1_trapezoid_N200"] = ladder_case(va, "g4_c1_trapezoid_N200", Y, t, Lidx, 200,
+                                              "trapezoid", 30, 0)
+    data = np.load(SHIPPED)
+    lad["g4_shipped_SH_N161"] = ladder_case(va, "g4_shipped_SH_N161", data[:, 1:][:, EX_LIDX],
+                                            data[:, 0], EX_LIDX, 161, "SimpsonHermite", 30, 1)
+    return lad
+
+
+def save_ladders(lad, summary=True):
+    """ladders.npz: the per-rung tables; ladder_paths.npz: the reference's minimising path at every rung"""
+    flat, paths = {}, {}
+    for cname, rec in lad.items():
+        for k, v in rec.items():
+            if k == "_minpaths":
+                paths["%s/minpaths" % cname] = v
+            else:
+                flat["%s/%s" % (cname, k)] = v
+    if summary:
+        np.savez_compressed(os.path.join(GOLD, "ladders.npz"), **flat)
+    np.savez_compressed(os.path.join(GOLD, "ladder_paths.npz"), **paths)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     va = _refload.load_reference("va_ode")
+    if "--only-ladder-paths" in sys.argv:
+        # the same two ladders again (deterministic): only the new file is written, after checking that the run
+        # reproduces the per-rung tables already committed
+        lad = ladder_cases(va)
+        old = np.load(os.path.join(GOLD, "ladders.npz"))
+        for cname, rec in lad.items():
+            assert np.array_equal(old["%s/A_array" % cname], rec["A_array"]), cname
+            assert np.array_equal(old["%s/params" % cname], rec["params"]), cname
+        save_ladders(lad, summary=False)
+        return
     if "--only-rffull" in sys.argv:
         flat = {}
         for cname, rec in rffull_cases(va).items():
@@ -364,18 +401,7 @@ def main():
             flat["%s/%s" % (cname, k)] = v
     np.savez_compressed(os.path.join(GOLD, "single_eval.npz"), **flat)
 
-    lad = {}
-    t, Y, _, Lidx = twin.make_twin(20, 200)
-    lad["g4_c1_trapezoid_N200"] = ladder_case(va, "g4_c1_trapezoid_N200", Y, t, Lidx, 200,
-                                              "trapezoid", 30, 0)
-    data = np.load(SHIPPED)
-    lad["g4_shipped_SH_N161"] = ladder_case(va, "g4_shipped_SH_N161", data[:, 1:][:, EX_LIDX],
-                                            data[:, 0], EX_LIDX, 161, "SimpsonHermite", 30, 1)
-    flat = {}
-    for cname, rec in lad.items():
-        for k, v in rec.items():
-            flat["%s/%s" % (cname, k)] = v
-    np.savez_compressed(os.path.join(GOLD, "ladders.npz"), **flat)
+    save_ladders(ladder_cases(va))
 
     flat = {}
     for cname, rec in nakl_cases(va).items():

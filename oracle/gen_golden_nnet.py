@@ -175,18 +175,35 @@ def ladder_case(vn, name, structure, M, act, alpha, betas, seed=0):
                alpha=alpha, beta=np.asarray(betas), RM=RM, RF0=RF0, A_array=a.A_array, me_array=a.me_array,
                fe_array=a.fe_array, minpaths_last=a.minpaths[-1], nit=np.array([n[0] for n in nits]),
                nfev=np.array([n[1] for n in nits]), status=np.array([n[2] for n in nits]))
+    rec["_minpaths"] = np.array(a.minpaths)     # the reference's minimiser at every rung (va_nnet.py:510): its own fixture file
     print("%-30s evals=%d A=%s nit=%s" % (name, counts["g"], a.A_array[[0, -1]], rec["nit"]))
     return rec
 
 
 def main():
     vn = _refload.load_reference("va_nnet")
-    if "--only-extra" in sys.argv:
-        flat = {}
-        for c, rec in extra_cases(vn).items():
-            for k, v in rec.items():
-                flat["%s/%s" % (c, k)] = v
-        np.savez_compressed(os.path.join(GOLD, "nnet_extra.npz"), **flat)
+    if "--only-ladder-paths" in sys.argv:
+        # The two ladders again, with the reference's minimiser at EVERY rung (va_nnet.py:510), for rung-local parity:
+        # a self-contained record (tables + paths of ONE run) in nnet_ladder_paths.npz.  BLAS is held to one thread: with
+        # several, two runs of the reference's own twin ladder agree on rungs 0-7 only (rung 8 to 8e-15, then
+        # 398 against 576 iterations at rung 9 and actions up to 49 % apart mid-ladder, 5e-6 at the top) -- the
+        # long minimisations amplify the last bit of np.dot's summation order.
+        from threadpoolctl import threadpool_limits
+        old = np.load(os.path.join(GOLD, "nnet.npz"))
+        out = {}
+        with threadpool_limits(limits=1):
+            for name, args, kw in (("g7_twin_ladder", (twin.nnet_structure(20, 10, 10, 10), 2, "sigmoid", 1.1, np.arange(0, 436, 15)), {}),
+                                   ("g7_small_tanh_ladder", ([5, 8, 3], 6, "tanh", 1.5, np.arange(0, 40, 2)), {"seed": 1})):
+                rec = ladder_case(vn, name, *args, **kw)
+                again = ladder_case(vn, name, *args, **kw)
+                assert np.array_equal(rec["A_array"], again["A_array"]) and np.array_equal(rec["_minpaths"], again["_minpaths"]), name
+                same = int(np.argmin(np.append(old[name + "/A_array"] == rec["A_array"], False)))
+                print("%s: rungs 0..%d bit-equal to the run committed in nnet.npz" % (name, same - 1))
+                assert abs(old[name + "/A_array"][0] - rec["A_array"][0]) <= 1e-10 * rec["A_array"][0], name      # (rung 0 at least, to rounding)
+                for k in ("A_array", "me_array", "fe_array", "nit", "nfev", "status"):
+                    out["%s/%s" % (name, k)] = rec[k]
+                out[name + "/minpaths"] = rec["_minpaths"]
+        np.savez_compressed(os.path.join(GOLD, "nnet_ladder_paths.npz"), **out)
         return
     cases = single_cases(vn)
     # the example's ladder is alpha=1.1, beta=0..435; every 15th rung keeps the run short
@@ -197,7 +214,8 @@ def main():
     flat = {}
     for c, rec in cases.items():
         for k, v in rec.items():
-            flat["%s/%s" % (c, k)] = v
+            if not k.startswith("_"):
+                flat["%s/%s" % (c, k)] = v
     path = os.path.join(GOLD, "nnet.npz")
     np.savez_compressed(path, **flat)
     print("wrote", path, os.path.getsize(path))

@@ -121,7 +121,10 @@ def test_twin_ladder_on_device(gold):
     assert abs(a.A_array[0] - c["A_array"][0]) <= 1e-3 * c["A_array"][0]
     rel = np.abs(a.A_array - c["A_array"]) / c["A_array"]
     print("twin ladder vs reference goldens: rel. deviation per rung", np.array2string(rel, precision=2))
-    assert np.all(rel[:8] <= 1e-2) and rel[-1] <= 1e-1
+    # (the top of the ladder is pinned rung by rung against the reference itself, from the reference's own start points:
+    # test_twin_ladder_every_rung_from_the_references_own_start_point -- 29 of 30 rungs within 1e-3; two runs of the
+    # REFERENCE on this machine with different BLAS thread counts agree on rungs 0-7 only, oracle/gen_golden_nnet.py)
+    assert np.all(rel[:8] <= 1e-2)
     # What the twin experiment is for (nnet_twin_anneal.py:101-138): the weights that produced the data.  With M = 2
     # examples 1900 weights are not identifiable -- the reference's own run ends 9.18 (rms) away from the true weights
     # having started 0.08 away, the device's 23.9 away (measured) -- so recovered weights cannot arbitrate anything here;
@@ -142,6 +145,46 @@ def test_twin_ladder_on_device(gold):
     A, g = a.A_gradA_taped(np.append(a.minpaths[-1][:400], a.P[c["Pidx"]]))
     assert abs(A - a.A_array[-1]) <= 1e-12 * A
     a.close()
+
+
+def test_twin_ladder_every_rung_from_the_references_own_start_point(gold):
+    """Rung-local parity against the REFERENCE (tests/golden/nnet_ladder_paths.npz: tables and per-rung minimisers of one
+    single-BLAS-thread run of its own anneal() + SciPy, oracle/gen_golden_nnet.py --only-ladder-paths).  Rung k starts
+    from the reference's minimiser of rung k-1 (va_nnet.py:455-472) and is compared with the reference's rung k:
+    (A, me, fe) within 1e-3.  Rungs that end elsewhere are listed with both minima."""
+    c = gold["g7_twin_ladder"]
+    ref = load_npz_cases("nnet_ladder_paths.npz")["g7_twin_ladder"]
+    s, Pidx = c["structure"], np.asarray(c["Pidx"])
+    NDens = int(c["M"]) * int(np.sum(s))
+    nb = len(c["beta"])
+    assert ref["minpaths"].shape == (nb, NDens + len(c["P0"]))
+    rf = float(c["alpha"]) ** np.asarray(c["beta"], dtype=float)
+    Lidx = [np.arange(s[0]), np.arange(s[-1])]
+    rows = []
+    for k in range(nb):
+        if k:
+            X, P = ref["minpaths"][k - 1, :NDens], ref["minpaths"][k - 1, NDens:]
+        else:
+            # (init_to_data, va_nnet.py:425-430: observed input / output neurons start at the data)
+            a0 = _annealer(c, twin.sigmoid)
+            a0.anneal_init(c["X0"].copy(), c["P0"].copy(), float(c["alpha"]), c["beta"][:1], float(c["RM"]), float(c["RF0"]),
+                           list(Pidx), Lidx=Lidx, method='L-BFGS-B', opt_args=OPTS, adolcID=0, verbose=False)
+            X, P = a0._xp0(0)[0][:NDens], c["P0"]
+            a0.close()
+        with _capi.NnetProblem(1, s, c["din"], c["dout"], Lidx, float(c["RM"]), float(c["RF0"]), P[None, :], Pidx) as pb:
+            r = pb.minimize_lbfgs(np.append(X, P[Pidx])[None, :], rf[k], OPTS)
+        dev = np.array([r["A"][0], r["me"][0], r["fe"][0]])
+        want = np.array([ref["A_array"][k], ref["me_array"][k], ref["fe_array"][k]])
+        rows.append((k, np.abs(dev - want) / abs(want[0]), dev, want, int(r["nit"][0]), int(ref["nit"][k]), int(r["status"][0]), int(ref["status"][k])))
+    off = [q for q in rows if q[1].max() > 1e-3]
+    for q in off:
+        print("   twin rung %2d: device A %.6e me %.3e fe %.3e (nit %d, status %d) | reference A %.6e me %.3e fe %.3e (nit %d, status %d)"
+              % (q[0], q[2][0], q[2][1], q[2][2], q[4], q[6], q[3][0], q[3][1], q[3][2], q[5], q[7]))
+    print("   statuses other than 0: device %s, reference %s" % ([(q[0], q[6]) for q in rows if q[6]], [(q[0], q[7]) for q in rows if q[7]]))
+    print("twin ladder: %d of %d rungs within 1e-3 of the reference's (A, me, fe) from the reference's start; %d with its iteration count"
+          % (nb - len(off), nb, sum(1 for q in rows if q[4] == q[5])))
+    assert nb - len(off) >= 27, [q[0] for q in off]
+    assert rows[-1][1].max() <= 1e-3
 
 
 def test_stepwise_equals_fused_and_batch_independent(gold):
