@@ -294,6 +294,62 @@ def extra_nnet(device, key, steps):
             "achieved_TFLOPs": flops / ks / 1e12, "frac_of_f64_mfma_peak": flops / ks / 1e12 / F64_MFMA_PEAK_TFLOPS}
 
 
+def mnist_shape_run(device):
+    """The one run the reference publishes a wall time for (VarAnneal_tutorial.ipynb:3413-3415,
+    3449-3450, 3469, stored output :3584-10560): va_nnet, structure 784-30-10, M = 2 training pairs, weights estimated,
+    RM = 1, RF0 by the tutorial's formula, alpha = 1.1, beta = 0..435, L-BFGS-B with gtol = ftol = 1e-12 -- through the
+    drop-in (varanneal_amd.va_nnet.Annealer, device L-BFGS).  MNIST itself is not shipped: SYNTHETIC data of that shape
+    (a seeded sigmoid twin network's input / output pairs); the start point follows the tutorial's recipe and seed.
+    Context for the published number, not a same-machine comparison."""
+    from varanneal_amd import twin, va_nnet
+    s = np.array([784, 30, 10])
+    M, D_in, D_hidden, D_out = 2, 784, 30, 10
+    din, dout, _ = twin.make_nnet_twin(s, M)
+    Lidx = [np.arange(D_in), np.arange(D_out)]
+    RM = 1.0
+    RF0 = 1.0e-8 * RM * float(np.sum(s) - s[0]) / float(s[0] + s[-1])
+    alpha, beta = 1.1, np.linspace(0, 435, 436)
+    rng = np.random.RandomState(27509436)                 # (the tutorial seeds numpy's global generator with this)
+    X0 = np.array([])
+    for m in range(M):
+        xin = rng.randn(D_in)
+        X0 = np.append(X0, (xin - np.average(xin)) / np.std(xin))
+        X0 = np.append(X0, 0.2 * rng.rand(D_hidden) + 0.4)
+        X0 = np.append(X0, 0.2 * rng.rand(D_out) + 0.4)
+    P0, Pidx, off = np.array([]), [], 0
+    for n in range(len(s) - 1):
+        nw = int(s[n] * s[n + 1])
+        Pidx += list(range(off, off + nw))
+        P0 = np.append(P0, (2.0 * rng.rand(nw) - 1.0) / (D_in if n == 0 else D_hidden))
+        P0 = np.append(P0, np.zeros(s[n + 1]))
+        off += nw + int(s[n + 1])
+    opts = {'gtol': 1.0e-12, 'ftol': 1.0e-12, 'maxfun': 1000000, 'maxiter': 1000000}
+
+    def run(b):
+        a = va_nnet.Annealer()
+        a.set_structure(s); a.set_activation(twin.sigmoid)
+        a.set_input_data(din); a.set_output_data(dout)
+        t0 = time.perf_counter()
+        a.anneal(X0.copy(), P0.copy(), alpha, b, RM, RF0, Pidx, Lidx=Lidx, method='L-BFGS-B', opt_args=opts, adolcID=0,
+                 device=device, verbose=False)
+        dt = time.perf_counter() - t0
+        out = (dt, np.array(a.nit_array), np.array(a.nfev_array), np.array(a.A_array), np.array(a.exitflags))
+        a.close()
+        return out
+    run(beta[:3])                                         # warm-up: code load, allocations
+    dt, nit, nfev, A, flags = run(beta)
+    hist = np.bincount(np.minimum(nit, 10), minlength=11)
+    return {"workload": "va_nnet_784_30_10_M2_alpha1.1_beta0..435 (the tutorial's MNIST run, synthetic data of that shape)",
+            "seconds": dt, "rungs": int(len(beta)), "lbfgs_iterations": int(nit.sum()), "evaluations": int(nfev.sum()),
+            "rungs_with_one_iteration": int((nit == 1).sum()), "iterations_per_rung_histogram_0_to_10plus": hist.tolist(),
+            "max_iterations_in_a_rung": int(nit.max()), "exitflag_counts": np.bincount(flags, minlength=3).tolist(),
+            "A_first_last": [float(A[0]), float(A[-1])], "n_var": int(X0.size + len(Pidx)),
+            "reference_published": {"seconds": 101.516544, "lbfgs_iterations": 1313, "rungs_with_one_iteration": 330,
+                                    "taping_seconds": 75.3, "optimisation_seconds": 22.4,
+                                    "source": "examples/jupyter-tutorial/VarAnneal_tutorial.ipynb:10560 (author's machine, "
+                                              "real MNIST pairs, ADOL-C + SciPy; BASELINE.md section 1)"}}
+
+
 def extra_ladder(device, D, N, B, Y, Lidx, XP, P, nbeta=30):
     """The C3 ladder end to end (alpha = 1.5, beta = 0..nbeta-1, SciPy-equal stopping rules): every
     kernel of the three-launch L-BFGS cycle counted; then the two vector kernels alone with full
@@ -331,7 +387,7 @@ def extra_ladder(device, D, N, B, Y, Lidx, XP, P, nbeta=30):
                     "seed batch sit in the 256 MiB Infinity Cache, so rates above the HBM figure are possible"}
 
 
-def timed_steps(pb, rf, steps, warmup, A, dist, world, torch, barrier):
+def timed_steps(pb, rf, steps, warmup, A, dist, world, torch, barrier, graph_fixed=None):
     """EXACTLY `steps` batched evaluations between two (barrier + synchronize) brackets; returns
     (wall seconds, kernel ms by HIP events, gather ms, ramp launches), the times the MAX over ranks.  Before the
     clock starts: the graph of the timed call's chunk of launches is captured, instantiated and uploaded
@@ -347,8 +403,27 @@ def timed_steps(pb, rf, steps, warmup, A, dist, world, torch, barrier):
         mine = torch.from_numpy(np.ascontiguousarray(A)).to(cdev)
         recv = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
         dist.all_gather_into_tensor(recv, mine)          # warm-up: communicator, RCCL kernels
+    # how the K launches are issued is the caller's choice (va_problem_tune graph=: one hipGraph replay per chunk, or plain
+    # launches): a graph replay starts ~15-20 us after the call and then runs back to back, plain launches start at once
+    # and stay device-bound above ~4 us per kernel -- for a handful of steps the plain form ends first.  Both are tried
+    # untimed and the faster one is timed; either way every launch is the same kernel.
+    ramp, ramp_ms, best = 0, 0.0, {}
+    for mode in ((1, 0) if graph_fixed is None else (int(graph_fixed),)):
+        pb.tune(graph=mode)
+        pb.eval_timed_prepare(rf, steps)
+        pb.eval_timed(rf, steps); ramp += steps
+        w = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ramp_ms += pb.eval_timed(rf, steps)
+            torch.cuda.synchronize()
+            w.append(time.perf_counter() - t0)
+            ramp += steps
+        best[mode] = min(w)
+    mode = min(best, key=best.get)
+    pb.tune(graph=mode)
     pb.eval_timed_prepare(rf, steps)
-    ramp, ramp_ms = 0, 0.0
     while ramp < max(warmup, 1) or ramp_ms < RAMP_MS:
         ramp_ms += pb.eval_timed(rf, steps)              # (same chunk as the timed call: its graph is replayed, not rebuilt)
         ramp += steps
@@ -366,7 +441,7 @@ def timed_steps(pb, rf, steps, warmup, A, dist, world, torch, barrier):
         tmax = torch.tensor([wall, kernel_ms, gather_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall, kernel_ms, gather_ms = (float(v) for v in tmax)
-    return wall, kernel_ms, gather_ms, ramp
+    return wall, kernel_ms, gather_ms, ramp, ("hipGraph replay" if mode else "plain launches")
 
 
 def nnet_main(args, rank, local_rank, world, dist, torch):
@@ -391,7 +466,7 @@ def nnet_main(args, rank, local_rank, world, dist, torch):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-    wall, kernel_ms, gather_ms, ramp = timed_steps(pb, rf, args.steps, args.warmup, A, dist, world, torch, barrier)
+    wall, kernel_ms, gather_ms, ramp, launch_mode = timed_steps(pb, rf, args.steps, args.warmup, A, dist, world, torch, barrier)
     if rank != 0:
         return
     # three products per layer transition: Z = X W^T, dX = delta W, dW = delta^T X
@@ -407,7 +482,7 @@ def nnet_main(args, rank, local_rank, world, dist, torch):
         "config": {"workload": w["name"], "seeds_per_gpu": B, "structure": [int(v) for v in s], "M": M,
                    "n_var": int(XP.shape[1]), "parallelism": "seeds sharded, %d per GPU" % B,
                    "final_gather_ms": gather_ms, "rccl_ranks": dist.get_world_size() if dist is not None else 1,
-                   "ramp_launches": ramp, "env": bench_env()},
+                   "ramp_launches": ramp, "launch_mode": launch_mode, "env": bench_env()},
         "roofline": {"bound": "mfma", "achieved": flops / ks / 1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": flops / ks / 1e12 / F64_MFMA_PEAK_TFLOPS,
                      "frac_wall": flops * args.steps / wall / 1e12 / F64_MFMA_PEAK_TFLOPS, "traffic": None,
@@ -511,7 +586,7 @@ def dry_run(args, rank, world, env_set):
         assert ranks == dist.get_world_size() == args.gpus
         dist.destroy_process_group()
     if rank == 0:
-        w = WORKLOADS.get(args.workload) or NNET_WORKLOADS[args.workload]
+        w = WORKLOADS.get(args.workload) or NNET_WORKLOADS.get(args.workload) or dict(name="mnist_shape", B=1)
         print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "scaling": "weak", "config": {"workload": w["name"], "seeds_per_gpu": w["B"],
                                                         "rccl_ranks": ranks, "env": env_set}}), flush=True)
@@ -522,7 +597,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=None, help="ranks of the job, one per GPU (default: WORLD_SIZE if the job was launched already, else 1)")
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS) + sorted(NNET_WORKLOADS))
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS) + sorted(NNET_WORKLOADS) + ["mnist_shape"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra sub-records (C4 shape, C3 ladder)")
     ap.add_argument("--tile-rows", type=int, default=0)
@@ -588,6 +663,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
 
+    if args.workload == "mnist_shape":
+        if rank == 0:
+            print(json.dumps(dict(mode="mnist_shape", **mnist_shape_run(local_rank))), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.workload in NNET_WORKLOADS:
         nnet_main(args, rank, local_rank, world, dist, torch)
         if dist is not None:
@@ -621,7 +702,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    wall, kernel_ms, gather_ms, ramp = timed_steps(pb, RF_SCALE, args.steps, args.warmup, A, dist, world, torch, barrier)
+    wall, kernel_ms, gather_ms, ramp, launch_mode = timed_steps(pb, RF_SCALE, args.steps, args.warmup, A, dist, world, torch, barrier, tune.get("graph"))
 
     if rank == 0:
         balg = bytes_alg(B, N, D, 1, N, len(Lidx))
@@ -636,7 +717,7 @@ def main():
             "config": {"workload": w["name"], "seeds_per_gpu": B, "D": D, "N": N, "L": len(Lidx),
                        "disc": "trapezoid", "tile_rows": info["tile_rows"], "ntiles": info["ntiles"],
                        "parallelism": "seeds sharded, %d per GPU" % B, "final_gather_ms": gather_ms,
-                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "ramp_launches": ramp, "env": env_set, "tune": tune,
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "ramp_launches": ramp, "launch_mode": launch_mode, "env": env_set, "tune": tune,
                        "rehearsal": ("%d ranks share one GPU, collectives over gloo" % world) if args.share_gpu else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "step": "complete S1 evaluation: A, me, fe formed in the same launch (va_epilogue.h)",
@@ -660,7 +741,8 @@ def main():
                             "c4_sh": extra_variant(local_rank, steps=30, D=200, disc="SimpsonHermite", N=5001),
                             "c4_rf": extra_variant(local_rank, steps=30, D=200, N=5000, rf_vec=True),
                             "lin_d20": extra_linear(local_rank),
-                            "c5": extra_nnet(local_rank, "c5", 2000), "c5x": extra_nnet(local_rank, "c5x", 40)}
+                            "c5": extra_nnet(local_rank, "c5", 2000), "c5x": extra_nnet(local_rank, "c5x", 40),
+                            "mnist_shape": mnist_shape_run(local_rank)}
         print(json.dumps(out), flush=True)
     pb.close()
     if dist is not None:

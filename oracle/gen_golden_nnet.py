@@ -45,7 +45,7 @@ def twin_rf0(structure, RM):
     return 1.0e-8 * RM * float(np.sum(s) - s[0]) / float(s[0] + s[-1])
 
 
-def single_cases(vn):
+def single_cases(vn, mnist_only=False):
     out = {}
 
     def run(name, structure, M, act, RM, rf_scale, weights_only, init_to_data, Lidx=None, seed=0, rf0=None):
@@ -70,6 +70,12 @@ def single_cases(vn):
                          Pidx=np.asarray(Pidx, dtype=int), XP=XP, A=A, me=me, fe=fe, grad=grad)
         print("%-40s A=%.16e me=%.3e fe=%.3e |g|max=%.3e" % (name, A, me, fe, np.abs(grad).max()))
 
+    if mnist_only:
+        # the tutorial's MNIST network in full (VarAnneal_tutorial.ipynb:3413-3415, 3449-3450: 784-30-10, M = 2, weights
+        # estimated, RM = 1, RF0 by the tutorial's formula), a third of the way up its ladder (alpha = 1.1, beta = 145);
+        # synthetic twin data of that shape (the MNIST files are not shipped); complex-step gradient over all 25,468 unknowns
+        run("g6_mnist_784_30_10", [784, 30, 10], 2, "sigmoid", 1.0, 1.1 ** 145, True, True, seed=6)
+        return out
     tw = twin.nnet_structure(20, 10, 10, 10)
     # BASELINE C5 shape: structure [10]*20, M=2, weights estimated, biases fixed at 0
     run("g6_twin_rf1", tw, 2, "sigmoid", 1.0 / 0.005 ** 2, 1.0, True, True)
@@ -182,6 +188,13 @@ def ladder_case(vn, name, structure, M, act, alpha, betas, seed=0):
 
 def main():
     vn = _refload.load_reference("va_nnet")
+    if "--only-mnist" in sys.argv:
+        flat = {}
+        for c, rec in single_cases(vn, mnist_only=True).items():
+            for k, v in rec.items():
+                flat["%s/%s" % (c, k)] = v
+        np.savez_compressed(os.path.join(GOLD, "nnet_mnist.npz"), **flat)
+        return
     if "--only-ladder-paths" in sys.argv:
         # The two ladders again, with the reference's minimiser at EVERY rung (va_nnet.py:510), for rung-local parity:
         # a self-contained record (tables + paths of ONE run) in nnet_ladder_paths.npz.  BLAS is held to one thread: with

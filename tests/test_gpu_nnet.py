@@ -45,6 +45,16 @@ def test_single_eval_matches_reference(gold, name):
     pr.close()
 
 
+def test_mnist_shape_single_eval_matches_reference():
+    """the tutorial's 784-30-10 network with M = 2 against the reference's own value and complex-step gradient"""
+    c = load_npz_cases("nnet_mnist.npz")["g6_mnist_784_30_10"]
+    with _capi.NnetProblem(1, c["structure"], c["din"], c["dout"], [c["Lin"], c["Lout"]], _rm(c), float(c["RF0"]),
+                           c["P"][None, :], c["Pidx"], act=str(c["act"])) as pr:
+        A, me, fe, g = pr.action_grad(c["XP"][None, :], float(c["rf_scale"]))
+    assert abs(A[0] - c["A"]) <= 1e-12 * abs(c["A"]) and abs(fe[0] - c["fe"]) <= 1e-12 * abs(c["A"])
+    assert np.abs(g[0] - c["grad"]).max() <= 1e-10 * np.abs(c["grad"]).max()
+
+
 @pytest.mark.parametrize("structure,M,act,weights_only", [
     ([64, 64, 64, 64], 256, "sigmoid", False),      # tiles exactly full
     ([70, 33, 129, 5], 300, "tanh", True),          # ragged in every dimension, 2 example chunks

@@ -35,6 +35,16 @@ def test_single_eval_matches_reference(gold, name):
     assert abs(A2 - A) <= 1e-14 * abs(A)
 
 
+def test_mnist_shape_single_eval_matches_reference():
+    """the tutorial's network in full, 784-30-10 with M = 2 (VarAnneal_tutorial.ipynb:3413-3415; synthetic data of that
+    shape), value and complex-step gradient through the reference's own A (tests/golden/nnet_mnist.npz)"""
+    c = load_npz_cases("nnet_mnist.npz")["g6_mnist_784_30_10"]
+    assert list(c["structure"]) == [784, 30, 10] and int(c["M"]) == 2 and c["XP"].size == 2 * 824 + 784 * 30 + 30 * 10
+    A, me, fe, g = problem_for(c).action_grad(c["XP"], float(c["rf_scale"]))
+    assert abs(A - c["A"]) <= 1e-12 * abs(c["A"]) and abs(fe - c["fe"]) <= 1e-12 * abs(c["A"])
+    assert np.abs(g - c["grad"]).max() <= 1e-10 * np.abs(c["grad"]).max()
+
+
 def test_surveyors_probe_value_shape(gold):
     """SURVEY.md 8(c) G5 quotes A = fe, me = 0 at RF = RF0 = 0.0038 for the twin's seeded
     start; our seeds differ (RandomState(1000+i)), the structure of the result must not."""
