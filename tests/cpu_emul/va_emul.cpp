@@ -120,7 +120,7 @@ void eval_seed(const Emul &E, int b, const double *x, const double *d, int use_d
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
     const int R = dm.T + HL + HR;
     std::vector<double> xs(R * dm.D), fs(R * dm.D), qs(R * dm.D), ps((size_t)R * (dm.NPt > 0 ? dm.NPt : 1));
-    for (int k = 0; k < EP_N; ++k) ev[k] = 0.0;
+    for (int k = 0; k < EP_BIG; ++k) ev[k] = 0.0;        // (flat form: any number of parameters up to RHS_BIG_NP)
     for (int tile = 0; tile < dm.ntiles; ++tile) {
         TileCtx c;
         c.ps = ps.data();
@@ -129,7 +129,7 @@ void eval_seed(const Emul &E, int b, const double *x, const double *d, int use_d
         c.xg = x; c.dg = d; c.gtg = gt;
         c.tmodel = E.pp.tmodel; c.stim = E.pp.stim; c.nstim = E.pp.nstim;
         if (!dm.tdp) tile_params<RHS>(dm, E.pp, b, c);
-        std::vector<ThreadAcc> acc(NT);
+        std::vector<ThreadAccT<EP_BIG>> acc(NT);
         for (auto &a : acc) a.clear();
         for (int t = 0; t < NT; ++t) tile_load<DISC>(dm, E.pp, c, t, NT);
         if (dm.tdp) for (int t = 0; t < NT; ++t) tile_load_p<DISC>(dm, E.pp, b, c, t, NT);
@@ -143,7 +143,7 @@ void eval_seed(const Emul &E, int b, const double *x, const double *d, int use_d
         for (int t = 0; t < NT; ++t) tile_g<RHS, DISC>(dm, E.pp, c, acc[t], t, NT);
         if (dm.tdp) for (int t = 0; t < NT; ++t) tile_gp<RHS, DISC>(dm, E.pp, c, acc[t], t, NT);
         for (int t = 0; t < NT; ++t)
-            for (int k = 0; k < EP_N; ++k) {
+            for (int k = 0; k < EP_BIG; ++k) {
                 if (k == EP_GMAX) ev[k] = fmax(ev[k], acc[t].v[k]);
                 else ev[k] += acc[t].v[k];
             }
@@ -173,7 +173,7 @@ void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_
             c.xg = x; c.dg = d; c.gtg = gt;
             Tile2 tmp; tmp.xg = x; tmp.dg = d; tmp.use_d = use_d; tmp.stp = stp;
             tile2_params<RHS>(dm, E.pp, b, tmp);          // (only RHS::NP is used)
-            for (int k = 0; k < RHS_MAX_NP; ++k) c.p[k] = tmp.p[k];
+            for (int k = 0; k < RHS_BIG_NP; ++k) c.p[k] = tmp.p[k];
             acc[t].clear();
         }
         const bool edge = (tile * T - HL < 0) || (tile * T + T + HR > dm.N);
@@ -256,7 +256,7 @@ void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_
                 c.xs = xs.data(); c.es = r2.data(); c.gtg = gt;
                 Tile2 tmp; tmp.xg = x; tmp.dg = d; tmp.use_d = use_d; tmp.stp = stp;
                 tile2_params<RHS>(dm, E.pp, b, tmp);           // (only RHS::NP is used)
-                for (int k = 0; k < RHS_MAX_NP; ++k) c.p[k] = tmp.p[k];
+                for (int k = 0; k < RHS_BIG_NP; ++k) c.p[k] = tmp.p[k];
                 acc[l].clear();
                 tile4_obs<K, NE>(dm, E.pp, c, rg[l]);
                 for (int k = 0; k < K; ++k) {
@@ -375,7 +375,7 @@ extern "C" int emul_action_grad(const va_problem_desc *desc, int T, const double
     const int nv = dm.ND + dm.NPest;
     std::vector<double> gt(dm.ld);
     for (int b = 0; b < dm.B; ++b) {
-        double ev[EP_N];
+        double ev[EP_BIG] = {0.0};
         eval_dispatch(E, b, XP + (size_t)b * nv, nullptr, 0, 0.0, rf_scale, gt.data(), ev);
         finish_tail(E, nullptr, 0, gt.data(), ev);
         me[b] = ev[EP_ME] * dm.cme; fe[b] = ev[EP_FE] * dm.cfe * rf_scale; A[b] = me[b] + fe[b];
@@ -416,7 +416,7 @@ extern "C" int emul_anneal(const va_problem_desc *desc, int T, double *XP, const
             double *xb = &x[(size_t)b * ld], *gb = &g[(size_t)b * ld], *gtb = &gt[(size_t)b * ld],
                    *db = &d[(size_t)b * ld];
             // K1
-            double ev[EP_N];
+            double ev[EP_BIG] = {0.0};
             const int use_d = s.phase == PH_LS;
             eval_dispatch(E, b, xb, db, use_d, s.stp, s.rf_scale, gtb, ev);
             // K2

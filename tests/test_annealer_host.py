@@ -202,7 +202,7 @@ def test_scipy_route_with_bounds(fake_device, golden_ladders):
     a = _setup(c)
     bounds = [(-15.0, 15.0)] * 20 + [(6.5, 10.0)]
     a.anneal(c["X0"].copy(), c["P0"].copy(), 1.5, np.arange(20), 4.0, 4e-6, list(c["Lidx"]), [0],
-             opt_args=OPTS, bounds=bounds, verbose=False)
+             opt_args=OPTS, bounds=bounds, verbose=False, bounded_minimiser='scipy')
     assert len(a.bounds) == 200 * 20 + 1 and a.bounds[-1] == (6.5, 10.0)
     assert np.all(a.minpaths[:, -1] >= 6.5 - 1e-12) and np.all(np.abs(a.minpaths[:, :-1]) <= 15.0 + 1e-12)
     assert np.all(a.A_array > 0) and np.allclose(a.A_array, a.me_array + a.fe_array, rtol=1e-12)
@@ -257,7 +257,7 @@ def test_nakl_bounded_ladder_host_flow(monkeypatch):
     a.set_data(c["Y"], stim=c["stim"], t=c["t"])
     a.anneal(c["X0"].copy(), c["P0"].copy(), float(c["alpha"]), c["beta"], 1.0, list(c["RF0"]), [0],
              list(range(18)), dt_model=None, init_to_data=True, disc="SimpsonHermite", method='L-BFGS-B',
-             bounds=[tuple(b) for b in c["bounds"]], opt_args=OPTS, adolcID=0, verbose=False)
+             bounds=[tuple(b) for b in c["bounds"]], opt_args=OPTS, adolcID=0, verbose=False, bounded_minimiser='scipy')
     assert list(a.nit_array[:4]) == list(c["nit"][:4])
     assert np.all(np.abs(a.A_array[:7] - c["A_array"][:7]) <= 1e-5 * c["A_array"][:7])
     assert np.all(np.abs(a.A_array - c["A_array"]) <= 2e-2 * c["A_array"])
@@ -303,7 +303,7 @@ def test_time_dependent_parameters_host_flow(monkeypatch, tmp_path):
     big = [(None, None)] * (D + 1)
     a.anneal(X0, P0, float(c["alpha"]), c["beta"][:nb], 4.0, 4e-6, list(c["Lidx"]), [0], dt_model=None,
              init_to_data=True, disc="SimpsonHermite", method='L-BFGS-B', bounds=big, opt_args=OPTS, adolcID=0,
-             verbose=False)
+             verbose=False, bounded_minimiser='scipy')
     assert len(a.bounds) == N * D + N
     assert list(a.nit_array) == list(c["nit"][:nb])
     assert np.all(np.abs(a.A_array - c["A_array"][:nb]) <= 1e-6 * c["A_array"][:nb])

@@ -459,3 +459,65 @@ def test_linear_module_with_stimulus_and_explicit_time():
         A, me, fe, g = emul.action_grad(desc, 8, XP[None, :], 1.0, user_header=m["header"])
         assert abs(A[0] - fun(XP)[0]) <= 1e-12 * abs(A[0])
         assert np.abs(g[0] - g0).max() <= 1e-10 * np.abs(g0).max()
+
+
+def _relu_ring(t, x, p):
+    """a piecewise model: rectified coupling, two leak rates chosen by the state, a saturating self-term
+    (the reference tapes whatever executes, _autodiffmin.py:41-44; here np.maximum / np.where / np.clip trace to selects)"""
+    drive = np.maximum(np.roll(x, 1, 1), 0.0)
+    leak = np.where(x > 0.5, p[1], 0.5 * p[1])
+    return -leak * x + p[0] * drive + 0.3 * np.clip(np.roll(x, -1, 1), -1.0, 1.5) - 0.2 * np.minimum(x, np.roll(x, 2, 1))
+
+
+@pytest.mark.parametrize("disc", ["trapezoid", "SimpsonHermite", "euler", "forwardmap"])
+def test_piecewise_model_traces_to_selects_and_matches_complex_step(disc):
+    D, NP, N = 10, 2, 41
+    ex, sy = codegen.trace(_relu_ring, D, NP)
+    assert "Piecewise" in str(ex[0])
+    codegen.check_against(_relu_ring, ex, sy, D, NP, 0)
+    m = codegen.module_for(_relu_ring, D, NP, compile=False)
+    rng = np.random.RandomState(7)
+    Y = rng.randn(N, 4); Lidx = [0, 3, 5, 8]
+    P = np.array([1.3, 0.8]); Pidx = [0, 1]
+    XP = np.append(1.5 * rng.randn(N * D), P)
+    rf = 30.0
+    fun = lambda z: va_oracle.numpy_action_generic(_relu_ring, z, D, N, Y, Lidx, 0.05, 2.0, 0.1 * rf, NP, Pidx, P, disc)
+    A0, me0, fe0 = fun(XP)
+    g0 = va_oracle.complex_step_grad(fun, XP)          # (the derivative of the taken branch: what a tape gives)
+    desc, keep = _capi.make_desc(1, D, N, Y, Lidx, 0.05, 2.0, 0.1, P[None, :], Pidx, disc=disc, rhs=1000)
+    A, me, fe, g = emul.action_grad(desc, 8, XP[None, :], rf, user_header=m["header"])
+    assert abs(A[0] - A0) <= 1e-12 * abs(A0)
+    assert np.abs(g[0] - g0).max() <= 1e-10 * np.abs(g0).max()
+
+    def py_branch(t, x, p):                              # Python-level branching stays untraceable, and says what to write instead
+        return np.array([[v if v > 0 else 0.0 * v for v in x[0]]])
+    with pytest.raises(TypeError, match="np.where"):
+        codegen.trace(py_branch, 3, 1)
+
+
+def _many_parameters(t, x, p):
+    """40 parameters (the tuned kernels and the partial-sum rows carry 24; the reference has no cap,
+    varanneal/va_ode.py:564-578): every state has its own forcing p[i] and its own damping p[20 + i]"""
+    D = x.shape[1]
+    return np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - p[D:2 * D] * x + p[:D]
+
+
+@pytest.mark.parametrize("disc", ["trapezoid", "SimpsonHermite"])
+def test_forty_parameters_through_the_flat_kernel(disc):
+    D, NP, N = 20, 40, 31
+    m = codegen.module_for(_many_parameters, D, NP, compile=False,
+                           col_variant=lambda ne, gh: _capi.eval_plan(1, D, N, disc, ne, gh))
+    assert m["col"] is None and m["ghost"] is None            # (column forms stop at 24 parameters)
+    rng = np.random.RandomState(9)
+    Y = rng.randn(N, 6); Lidx = [0, 3, 7, 11, 14, 18]
+    P = np.append(8.0 + rng.rand(D), 0.8 + 0.4 * rng.rand(D))
+    Pidx = [0, 5, 19, 20, 23, 24, 25, 31, 39]                 # estimated ones on both sides of the 24th
+    XP = np.append(3.0 * rng.randn(N * D), P[Pidx])
+    rf = 20.0
+    fun = lambda z: va_oracle.numpy_action_generic(_many_parameters, z, D, N, Y, Lidx, 0.025, 4.0, 0.01 * rf, NP, Pidx, P, disc)
+    A0 = fun(XP)[0]
+    g0 = va_oracle.complex_step_grad(fun, XP)
+    desc, keep = _capi.make_desc(1, D, N, Y, Lidx, 0.025, 4.0, 0.01, P[None, :], Pidx, disc=disc, rhs=1000)
+    A, me, fe, g = emul.action_grad(desc, 8, XP[None, :], rf, user_header=m["header"])
+    assert abs(A[0] - A0) <= 1e-12 * abs(A0)
+    assert np.abs(g[0] - g0).max() <= 1e-10 * np.abs(g0).max()

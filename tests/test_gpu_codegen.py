@@ -574,3 +574,76 @@ def test_dense_linear_part_with_stimulus_and_time():
             assert abs(A[b] - fun(XP[b])[0]) <= 1e-12 * abs(A[b]), (disc, b)
         g0 = va_oracle.complex_step_grad(fun, XP[1])
         assert np.abs(g[1] - g0).max() <= 1e-10 * np.abs(g0).max(), disc
+
+
+def _many_parameters(t, x, p):
+    """40 parameters: every state its own forcing p[i] and damping p[20 + i] (the reference has no cap on NP,
+    varanneal/va_ode.py:564-578; the tuned kernels and the rows of partial sums carry 24)"""
+    D = x.shape[1]
+    return np.roll(x, 1, 1) * (np.roll(x, -1, 1) - np.roll(x, 2, 1)) - p[D:2 * D] * x + p[:D]
+
+
+@pytest.mark.parametrize("disc", ["trapezoid", "SimpsonHermite", "euler"])
+def test_forty_parameter_model_on_device(disc):
+    """single evaluations against complex-step derivatives of the NumPy restatement with the ORIGINAL callable, estimated
+    parameters on both sides of the 24th; then a short minimisation that must descend"""
+    D, NP, N, B = 20, 40, 201, 3
+    m = codegen.module_for(_many_parameters, D, NP)
+    rid = _capi.load_rhs_module(m["so"])
+    rng = np.random.RandomState(9)
+    Lidx = [0, 3, 7, 11, 14, 18]
+    Y = rng.randn(N, len(Lidx))
+    P = np.append(8.0 + rng.rand(D), 0.8 + 0.4 * rng.rand(D))
+    Pidx = [0, 5, 19, 20, 23, 24, 25, 31, 39]
+    XP = np.stack([np.append(3.0 * rng.randn(N * D), P[Pidx]) for _ in range(B)])
+    rf = 20.0
+    with _capi.Problem(B, D, N, Y, Lidx, 0.025, 4.0, 0.01, np.tile(P, (B, 1)), Pidx, disc=disc, rhs=rid) as pr:
+        assert pr.info()["eval_kernel"] == 1 and pr.persistent() is None
+        A, me, fe, g = pr.action_grad(XP, rf)
+        for b in range(B):
+            fun = lambda z: va_oracle.numpy_action_generic(_many_parameters, z, D, N, Y, Lidx, 0.025, 4.0, 0.01 * rf, NP, Pidx, P, disc)
+            A0 = fun(XP[b])[0]
+            assert abs(A[b] - A0) <= 1e-12 * abs(A0)
+            if b == 0:
+                g0 = va_oracle.complex_step_grad(fun, XP[b])
+                assert np.abs(g[b] - g0).max() <= 1e-10 * np.abs(g0).max()
+                assert np.abs(g[b, N * D:] - g0[N * D:]).max() <= 1e-10 * np.abs(g0[N * D:]).max()      # (the parameter block on its own scale)
+        r = pr.minimize_lbfgs(XP, rf, {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 300, 'maxiter': 200})
+        assert np.all(r["A"] < A) and np.all(np.isfinite(r["x"]))
+        A1 = pr.action_grad(r["x"], rf)[0]
+        assert np.all(np.abs(A1 - r["A"]) <= 1e-12 * A1)
+
+
+def _relu_ring(t, x, p):
+    """a piecewise model: rectified coupling, two leak rates chosen by the state, a saturating neighbour term -- what the
+    reference would tape as it executes (_autodiffmin.py:41-44); traced to selects (codegen.SymArray)"""
+    drive = np.maximum(np.roll(x, 1, 1), 0.0)
+    leak = np.where(x > 0.5, p[1], 0.5 * p[1])
+    return -leak * x + p[0] * drive + 0.3 * np.clip(np.roll(x, -1, 1), -1.0, 1.5) - 0.2 * np.minimum(x, np.roll(x, 2, 1))
+
+
+@pytest.mark.parametrize("D,N,disc", [(10, 200, "trapezoid"), (10, 201, "SimpsonHermite"), (20, 1000, "trapezoid"), (100, 300, "euler")])
+def test_piecewise_model_on_device(D, N, disc):
+    """value and gradient (the derivative of the taken branch) against complex-step through the original callable, on the
+    kernels the plan picks (column kernel for narrow states, streaming / flat beyond) and on the flat kernel"""
+    NP = 2
+    rng = np.random.RandomState(7)
+    Lidx = list(range(0, D, 3))
+    Y = rng.randn(N, len(Lidx))
+    P = np.array([1.3, 0.8]); Pidx = [0, 1]
+    XP = np.append(1.5 * rng.randn(N * D), P)[None, :]
+    rf = 30.0
+    fun = lambda z: va_oracle.numpy_action_generic(_relu_ring, z, D, N, Y, Lidx, 0.05, 2.0, 0.1 * rf, NP, Pidx, P, disc)
+    A0 = fun(XP[0])[0]
+    g0 = va_oracle.complex_step_grad(fun, XP[0])
+    kernels = set()
+    for ek in (0, 1):
+        m = codegen.module_for(_relu_ring, D, NP, col_variant=lambda ne, gh, reach: _capi.eval_plan(
+            1, D, N, disc, ne, gh, eval_kernel=ek, reach=reach, Lidx=Lidx))
+        rid = _capi.load_rhs_module(m["so"])
+        with _capi.Problem(1, D, N, Y, Lidx, 0.05, 2.0, 0.1, P[None, :], Pidx, disc=disc, rhs=rid, eval_kernel=ek) as pr:
+            kernels.add(pr.info()["eval_kernel"])
+            A, me, fe, g = pr.action_grad(XP, rf)
+        assert abs(A[0] - A0) <= 1e-12 * abs(A0), (ek, A[0], A0)
+        assert np.abs(g[0] - g0).max() <= 1e-10 * np.abs(g0).max(), ek
+    print("piecewise model D=%d N=%d %s ran eval kernels %s" % (D, N, disc, sorted(kernels)))

@@ -28,7 +28,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 CACHE = os.environ.get("VARANNEAL_AMD_RHS_CACHE", os.path.join(_HERE, "_rhs_cache"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-MAX_NP = 24
+MAX_NP = 128           # RHS_BIG_NP of csrc/va_core.h (the flat kernel); the tuned column / ghosted forms take up to MAX_NP_TUNED
+MAX_NP_TUNED = 24      # RHS_MAX_NP
 
 
 def _sympy():
@@ -65,10 +66,18 @@ class Sym(object):
     def __neg__(self): return Sym(-self.e)
     def __pos__(self): return self
 
-    def _cmp(self, *a):
-        raise TypeError("the model function branches on the value of a state/parameter; "
-                        "such right-hand sides cannot be traced")
-    __lt__ = __le__ = __gt__ = __ge__ = __bool__ = _cmp
+    # comparisons give symbolic conditions (for np.where); only USING one as a Python truth value cannot be traced
+    def __lt__(self, o): return self._bin(o, lambda a, b: _sympy().Lt(a, b))
+    def __le__(self, o): return self._bin(o, lambda a, b: _sympy().Le(a, b))
+    def __gt__(self, o): return self._bin(o, lambda a, b: _sympy().Gt(a, b))
+    def __ge__(self, o): return self._bin(o, lambda a, b: _sympy().Ge(a, b))
+
+    def __bool__(self):
+        raise TypeError("the model function branches on the value of a state/parameter (if / and / or / max() on traced "
+                        "values); write the branch as np.where / np.maximum / np.minimum / np.abs, which are traced to selects")
+
+    def __abs__(self):
+        return Sym(_pw_abs(self.e))
 
     def __getattr__(self, name):          # np.tanh(obj_array) calls elem.tanh(), etc.
         sp = _sympy()
@@ -83,6 +92,78 @@ class Sym(object):
         raise AttributeError(name)
 
 
+# ---- piecewise models (the reference tapes whatever executes, _autodiffmin.py:41-44): np.where / maximum / minimum /
+# abs / sign / clip and comparisons on traced arrays become SymPy Piecewise expressions, printed as C selects; the
+# derivative of a Piecewise is the Piecewise of its branches' derivatives -- the taken branch's, as a tape would give.
+def _pw_max(a, b):
+    sp = _sympy()
+    return sp.Piecewise((a, sp.Ge(a, b)), (b, True))
+
+
+def _pw_min(a, b):
+    sp = _sympy()
+    return sp.Piecewise((a, sp.Le(a, b)), (b, True))
+
+
+def _pw_abs(a):
+    sp = _sympy()
+    return sp.Piecewise((a, sp.Ge(a, 0)), (-a, True))
+
+
+def _pw_sign(a):
+    sp = _sympy()
+    return sp.Piecewise((1.0, sp.Gt(a, 0)), (-1.0, sp.Lt(a, 0)), (0.0, True))
+
+
+def _pw_where(c, a, b):
+    sp = _sympy()
+    if c is True or c is sp.true or (isinstance(c, (bool, np.bool_)) and c):
+        return a
+    if c is False or c is sp.false or (isinstance(c, (bool, np.bool_)) and not c):
+        return b
+    return sp.Piecewise((a, c), (b, True))
+
+
+def _elementwise(fn, *args):
+    """fn over the broadcast of object arrays / scalars of Sym or numbers -> SymArray of Sym"""
+    arrs = [np.asarray(a, dtype=object).view(np.ndarray) for a in args]
+    bc = np.broadcast(*arrs)
+    res = np.empty(bc.shape, dtype=object)
+    for i, vals in enumerate(bc):
+        res.flat[i] = Sym(fn(*[Sym._u(v) for v in vals]))
+    return res.view(SymArray)
+
+
+class SymArray(np.ndarray):
+    """object array of Sym that intercepts what NumPy would otherwise decide by truth-testing its elements"""
+    def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
+        sp = _sympy()
+        table = {np.maximum: _pw_max, np.fmax: _pw_max, np.minimum: _pw_min, np.fmin: _pw_min, np.absolute: _pw_abs,
+                 np.fabs: _pw_abs, np.sign: _pw_sign, np.greater: sp.Gt, np.greater_equal: sp.Ge, np.less: sp.Lt,
+                 np.less_equal: sp.Le,
+                 np.heaviside: lambda a, h: sp.Piecewise((1.0, sp.Gt(a, 0)), (0.0, sp.Lt(a, 0)), (h, True))}
+        if method == "__call__" and out is None and ufunc in table:
+            return _elementwise(table[ufunc], *inputs)
+        ins = [i.view(np.ndarray) if isinstance(i, SymArray) else i for i in inputs]
+        if out is not None:
+            kwargs["out"] = tuple(o.view(np.ndarray) if isinstance(o, SymArray) else o for o in out)
+        r = getattr(ufunc, method)(*ins, **kwargs)
+        return r.view(SymArray) if isinstance(r, np.ndarray) and r.dtype == object else r
+
+    def __array_function__(self, func, types, args, kwargs):
+        if func is np.where and len(args) == 3 and not kwargs:
+            return _elementwise(_pw_where, *args)
+        if func is np.clip and len(args) >= 3:
+            lo, hi = args[1], args[2]
+            r = args[0]
+            if lo is not None:
+                r = _elementwise(_pw_max, r, lo)
+            if hi is not None:
+                r = _elementwise(_pw_min, r, hi)
+            return r
+        return super().__array_function__(func, types, args, kwargs)
+
+
 def trace(f, D, NP, nstim=0, stim_ndim=1, p_rows=False):
     """Run `f` once on symbols.  Returns (exprs[D], symbols dict).  p_rows: the model takes
     time-dependent parameters, i.e. p of shape (rows, NP) indexed p[:, k] (va_ode.py:170-188)."""
@@ -91,19 +172,19 @@ def trace(f, D, NP, nstim=0, stim_ndim=1, p_rows=False):
     ps = sp.symbols("p0:%d" % max(NP, 1), real=True)[:NP]
     ss = sp.symbols("st0:%d" % max(nstim, 1), real=True)[:nstim]
     t = sp.Symbol("t", real=True)
-    X = np.empty((1, D), dtype=object)
+    X = np.empty((1, D), dtype=object).view(SymArray)
     for j in range(D):
         X[0, j] = Sym(xs[j])
-    P = np.empty((1, NP) if p_rows else NP, dtype=object)
+    P = np.empty((1, NP) if p_rows else NP, dtype=object).view(SymArray)
     for k in range(NP):
         P[(0, k) if p_rows else k] = Sym(ps[k])
-    T = np.empty(1, dtype=object)
+    T = np.empty(1, dtype=object).view(SymArray)
     T[0] = Sym(t)
     if nstim:
         if stim_ndim == 1:
-            S = np.empty(1, dtype=object); S[0] = Sym(ss[0])
+            S = np.empty(1, dtype=object).view(SymArray); S[0] = Sym(ss[0])
         else:
-            S = np.empty((1, nstim), dtype=object)
+            S = np.empty((1, nstim), dtype=object).view(SymArray)
             for k in range(nstim):
                 S[0, k] = Sym(ss[k])
         out = f(T, X, (P, S))
@@ -678,7 +759,9 @@ def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False, p_rows=False, col_
     check_against(f, exprs, syms, D, NP, nstim, stim_ndim, p_rows=p_rows)
     col = ghost = None
     variant = None
-    if col_variant is not None and not p_rows:
+    if p_rows and NP > MAX_NP_TUNED:
+        raise NotImplementedError("time-dependent parameters: at most %d of them" % MAX_NP_TUNED)
+    if col_variant is not None and not p_rows and NP <= MAX_NP_TUNED:      # (many parameters: the flat kernel only)
         uniform = _translation_invariant(exprs, list(syms["x"]), D)
         # column form: k_eval4 (D <= 64: stencils and small dense systems) or, for stencils, the streaming k_eval5
         col = column_form(exprs, syms, D, NP, nstim, uniform=uniform)          # (None when the model has no such form)
@@ -700,7 +783,7 @@ def module_for(f, D, NP, nstim=0, stim_ndim=1, verbose=False, p_rows=False, col_
         if variant is None or variant[0] != 3:
             ghost = None
     # no column-run kernel for this model: a dense constant linear part goes to the matrix cores
-    lin = linear_split(exprs, syms, D) if (linear and col is None and ghost is None and not p_rows) else None
+    lin = linear_split(exprs, syms, D) if (linear and col is None and ghost is None and not p_rows and NP <= MAX_NP_TUNED) else None
     text = generate_header(exprs, syms, D, NP, nstim, getattr(f, "__name__", "f"), col=col, ghost=ghost, lin=lin)
     so, hdr = build_module(text, verbose, variant, compile)
     return dict(so=so, header=hdr, exprs=exprs, text=text, col=col, ghost=ghost, col_variant=variant,

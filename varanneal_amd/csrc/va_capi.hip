@@ -386,6 +386,8 @@ int alloc_solver_state(va_handle h, int max_beta, int keep_paths)
     TRYA(h->alloc(&dv.S, B * m * ld)); TRYA(h->alloc(&dv.Y, B * m * ld));
     TRYA(h->alloc(&dv.st, B));
     TRYA(h->alloc(&dv.evp, B * dm.nprow * EP_N));
+    dv.npbig = (!h->is_nnet && dm.NPt > RHS_MAX_NP) ? dm.NPt - RHS_MAX_NP : 0;
+    if (dv.npbig) TRYA(h->alloc(&dv.evp_big, B * dm.nprow * dv.npbig));
     TRYA(h->alloc(&dv.upp, B * dm.nchunks * dv.ups));
     TRYA(h->alloc(&dv.dpp, B * dm.nchunks * DP_N));
     TRYA(h->alloc(&h->d_rf, (size_t)max_beta));
@@ -671,7 +673,7 @@ int va_rhs_load_module(const char *path, int32_t *rhs_id)
         dlclose(u.dl);
         return fail(VA_EINVAL, "%s was built against different headers (Dev %d vs %zu bytes): rebuild it", path, v[3], sizeof(Dev));
     }
-    if (v[0] < 0 || v[0] > RHS_MAX_NP) { dlclose(u.dl); return fail(VA_EUNSUPPORTED, "%s: NP=%d > %d", path, v[0], RHS_MAX_NP); }
+    if (v[0] < 0 || v[0] > RHS_BIG_NP) { dlclose(u.dl); return fail(VA_EUNSUPPORTED, "%s: NP=%d > %d", path, v[0], RHS_BIG_NP); }
     u.NP = v[0]; u.D = v[1]; u.NSTIM = v[2];
     if (info_fn vinfo = (info_fn)dlsym(u.dl, "va_user_variant_info")) {        // (writes 12 ints)
         vinfo(u.var);
@@ -736,8 +738,11 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     if (d->rhs == VA_RHS_LORENZ96 && (d->NP != RhsL96::NP || d->D < 4))
         return fail(VA_EINVAL, "Lorenz-96 needs NP=1 and D>=4 (NP=%d D=%d)", d->NP, d->D);
     if (d->n_stim < 0 || (d->n_stim > 0 && !d->stim)) return fail(VA_EINVAL, "n_stim=%d without a stimulus array", d->n_stim);
-    if (d->NPest < 0 || d->NPest > d->NP || d->NP > RHS_MAX_NP) return fail(VA_EINVAL, "bad NP/NPest (%d/%d)", d->NP, d->NPest);
+    if (d->NPest < 0 || d->NPest > d->NP || d->NP > RHS_BIG_NP) return fail(VA_EINVAL, "bad NP/NPest (%d/%d)", d->NP, d->NPest);
     const bool tdp = d->p_time_dependent != 0;
+    // more than RHS_MAX_NP parameters: the flat kernel carries them (their gradient partials in a table of their own)
+    const bool bigp = d->NP > RHS_MAX_NP;
+    if (bigp && tdp) return fail(VA_EUNSUPPORTED, "time-dependent parameters: at most %d of them", RHS_MAX_NP);
     if (tdp && d->disc != VA_DISC_TRAPEZOID && d->disc != VA_DISC_SIMPSON_HERMITE)
         return fail(VA_EUNSUPPORTED, "time-dependent parameters: trapezoid and SimpsonHermite only (upstream's euler/forwardmap "
                                      "branches are inconsistent, va_ode.py:345-349)");
@@ -797,7 +802,8 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
         // was generated); a problem that calls for any other geometry runs the module's flat kernel
         const int *v = user->var;
         dm.lin = v[10] ? 1 : 0;
-        pick_eval_geometry(d, dm, dv.g4, (v[0] == 4 || v[0] == 5) ? v[4] : 0, v[0] == 3 ? v[5] : 0, v[0] == 5 ? v + 6 : nullptr, &dv.g5, &ystrip_h);
+        if (bigp) pick_eval_geometry(d, dm, dv.g4, 0, 0);
+        else pick_eval_geometry(d, dm, dv.g4, (v[0] == 4 || v[0] == 5) ? v[4] : 0, v[0] == 3 ? v[5] : 0, v[0] == 5 ? v + 6 : nullptr, &dv.g5, &ystrip_h);
         const bool ws = d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1;
         const bool fits = dm.emode == v[0] && v[1] == d->disc &&
                           (dm.emode == 5 ? true : (v[2] == dm.maxr && (dm.emode == 4 ? (v[3] != 0) == ws : v[3] == dm.NT)));
@@ -940,7 +946,7 @@ int va_problem_create(const va_problem_desc *d, va_handle *out)
     // few seeds, short paths: can the whole minimisation live in LDS?  (flat tile phases: any right-hand side, any
     // discretisation, weight arrays, merr_nskip, full weight matrices; not bounds, time-dependent parameters, a dense
     // linear part, or the padded observation rows of the streaming kernel)
-    if (!dm.bounded && !tdp && !dm.lin && dm.emode != 5 && (!user || user->seed_kernel)) {
+    if (!dm.bounded && !tdp && !dm.lin && !bigp && dm.emode != 5 && (!user || user->seed_kernel)) {
         int G = 0, T = 0, ncu = 0;
         HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d->device));
         h->pz_maxG = ncu / (int)B;

@@ -43,10 +43,14 @@ enum { UPD_X = 1, UPD_G = 2, UPD_HIST = 4, UPD_STORE = 8 };
 enum { LS_START = 0, LS_FG = 1, LS_CONV = 2, LS_WARN = 3, LS_ERROR = 4 };
 
 constexpr int MAX_M = 32;        // history pairs
-constexpr int RHS_MAX_NP = 24;   // parameters a right-hand side may have (NaKL: 18)
+constexpr int RHS_MAX_NP = 24;   // parameters the tuned kernels and the rows of partial sums carry (NaKL: 18)
+constexpr int RHS_BIG_NP = 128;  // parameters a right-hand side may have on the flat kernel: the gradient partials of those
+                                 // beyond RHS_MAX_NP travel in a table of their own (Dev::evp_big); the reference has no cap
+                                 // (varanneal/va_ode.py:564-578)
 // eval partial columns
 enum { EP_ME = 0, EP_FE = 1, EP_GTD = 2, EP_GN2 = 3, EP_GMAX = 4, EP_GP = 5 };
 constexpr int EP_N = EP_GP + RHS_MAX_NP;
+constexpr int EP_BIG = EP_GP + RHS_BIG_NP;
 // update partial columns: 5 fixed + 4 per old history slot
 enum { UP_YGT = 0, UP_SGT = 1, UP_YY = 2, UP_SY = 3, UP_GTGT = 4, UP_OLD = 5 };
 constexpr int UP_N = UP_OLD + 4 * MAX_M;
@@ -170,13 +174,14 @@ struct TileCtx {
     const double *tmodel, *stim; // per-row time / stimulus (NULL / unused for autonomous RHS)
     int nstim;
     double *ps;                  // time-dependent parameters: staged rows [R*NPt] (LDS)
-    double p[RHS_MAX_NP];
+    double p[RHS_BIG_NP];        // (statically indexed: the entries a model does not have cost nothing)
 };
 
-struct ThreadAcc {
-    double v[EP_N];
-    VA_HD void clear() { for (int k = 0; k < EP_N; ++k) v[k] = 0.0; }
+template <int NV> struct ThreadAccT {
+    double v[NV];
+    VA_HD void clear() { for (int k = 0; k < NV; ++k) v[k] = 0.0; }
 };
+typedef ThreadAccT<EP_N> ThreadAcc;
 
 // trial point; the SAME expression is used by the update kernel so that the
 // accepted iterate is bit-identical to the point that was evaluated.
@@ -271,8 +276,8 @@ VA_HD void tile_f(const Dims &dm, TileCtx &c, int tid, int nt)
 }
 
 // phase 3: weighted residual adjoints q for rows [n0-HL, n0+T); model-error sum over owned rows.
-template <int DISC>
-VA_HD void tile_q(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &acc, int tid, int nt)
+template <int DISC, class ACC>
+VA_HD void tile_q(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ACC &acc, int tid, int nt)
 {
     constexpr int HL = Halo<DISC>::HL;
     const int D = dm.D, N = dm.N, tot = (dm.T + HL) * D;
@@ -322,8 +327,8 @@ VA_HD void tile_q(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &
 // residual; Simpson-Hermite: d1 of the interval at even n, d2 at odd n -- RF[2i], RF[2i+1] upstream).  Reads the
 // residuals tile_q left in c.qs and writes the adjoints q_n = (c/2) (R_n + R_n^T) r_n over c.fs (f is no
 // longer needed); the caller then swaps the two arrays.  R is not assumed symmetric.
-template <int DISC>
-VA_HD void tile_qfull(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &acc, int tid, int nt)
+template <int DISC, class ACC>
+VA_HD void tile_qfull(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ACC &acc, int tid, int nt)
 {
     constexpr int HL = Halo<DISC>::HL;
     const int D = dm.D, N = dm.N, tot = (dm.T + HL) * D;
@@ -395,8 +400,8 @@ VA_HD void tile_s(const Dims &dm, TileCtx &c, int tid, int nt)
 
 // phase 5: gradient rows of the tile + measurement term + parameter-gradient and
 // line-search partial sums.
-template <class RHS, int DISC>
-VA_HD void tile_g(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &acc, int tid, int nt)
+template <class RHS, int DISC, class ACC>
+VA_HD void tile_g(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ACC &acc, int tid, int nt)
 {
     constexpr int HL = Halo<DISC>::HL;
     const int D = dm.D, tot = dm.T * D;
@@ -456,8 +461,8 @@ VA_HD void tile_g(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &
 
 // phase 5b (time-dependent parameters): dA/dp_m = (df/dp)^T s_m row by row -- one thread per
 // owned row walks the D state components (generic path, not a tuned one).
-template <class RHS, int DISC>
-VA_HD void tile_gp(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ThreadAcc &acc, int tid, int nt)
+template <class RHS, int DISC, class ACC>
+VA_HD void tile_gp(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, ACC &acc, int tid, int nt)
 {
     constexpr int HL = Halo<DISC>::HL;
     const int D = dm.D;

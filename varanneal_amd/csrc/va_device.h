@@ -50,6 +50,8 @@ struct Dev {
     double *S, *Y;                 // [B][m][ld]
     SeedState *st;                 // [B]
     double *evp;                   // [B][ntiles][EP_N]       eval partials
+    double *evp_big;               // NULL or [B][ntiles][npbig]: parameter-gradient partials of parameters RHS_MAX_NP, RHS_MAX_NP + 1, ... (flat kernel)
+    int npbig;                     // = NP - RHS_MAX_NP when positive
     double *upp;                   // [B][nchunks][ups]       update-kernel dot partials
     double *dpp;                   // [B][nchunks][DP_N]      direction partials
     int ups;                       // = UP_OLD + 4*m

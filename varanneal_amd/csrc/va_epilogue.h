@@ -132,6 +132,12 @@ __device__ __forceinline__ void eval_tail(const Dev &dv, int b, int use_d, doubl
         double g = 0.0;
 #pragma unroll
         for (int j = 0; j < RHS_MAX_NP; ++j) g = (idx == j) ? ev[EP_GP + j] : g;
+        if (idx >= RHS_MAX_NP) {
+            // (models with many parameters, flat kernel: the tiles' partials of this parameter, added in tile order;
+            // written write-through by this launch and read around L1, like the rows)
+            const double *pb = dv.evp_big + (size_t)b * dm.nprow * dv.npbig + (idx - RHS_MAX_NP);
+            for (int t = 0; t < dm.nprow; ++t) g += ld_sc1(pb + (size_t)t * dv.npbig);
+        }
         gt[dm.ND + k] = g;
         if (use_d) ev[EP_GTD] += g * as_const(d)[dm.ND + k];
         ev[EP_GN2] += g * g;

@@ -158,7 +158,8 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
     if (phase != PH_START && phase != PH_LS) return;
 
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR;
-    constexpr int K = EP_GP + RHS::NP;            // partial columns in use
+    constexpr int K = EP_GP + RHS::NP;            // partial columns in use (beyond EP_N: parameters RHS_MAX_NP..., a table of their own)
+    constexpr int KR = K > EP_N ? K : EP_N;
     const int R = dm.T + HL + HR, RD = R * dm.D;
     TileCtx c;
     c.n0 = tile * dm.T; c.R = R; c.use_d = (phase == PH_LS);
@@ -167,14 +168,14 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
     constexpr bool LIN = rhs_linear<RHS>::value;
     if constexpr (LIN) c.js = smem + 3 * RD;
     double *red = smem + 3 * RD + (LIN ? dm.T * dm.D : 0);
-    c.ps = red + (EVAL_THREADS / 64) * EP_N;     // [R * NPt], time-dependent parameters only
+    c.ps = red + (EVAL_THREADS / 64) * KR;       // [R * NPt], time-dependent parameters only
     c.xg = dv.x + (size_t)b * dm.ld; c.dg = dv.d + (size_t)b * dm.ld;
     c.gtg = dv.gt + (size_t)b * dm.ld;
     c.tmodel = dv.pp.tmodel; c.stim = dv.pp.stim; c.nstim = dv.pp.nstim;
     if (!dm.tdp) tile_params<RHS>(dm, dv.pp, b, c);
 
     const int tid = threadIdx.x, nt = blockDim.x;
-    ThreadAcc acc;
+    ThreadAccT<KR> acc;
     acc.clear();
     tile_load<DISC>(dm, dv.pp, c, tid, nt);
     if (dm.tdp) tile_load_p<DISC>(dm, dv.pp, b, c, tid, nt);
@@ -214,7 +215,8 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
         double v = red[tid];
         for (int ww = 1; ww < nw; ++ww)
             v = (tid == EP_GMAX) ? fmax(v, red[ww * K + tid]) : v + red[ww * K + tid];
-        st_sc1(dv.evp + ((size_t)b * dm.ntiles + tile) * EP_N + tid, v);
+        if (tid < EP_N) st_sc1(dv.evp + ((size_t)b * dm.ntiles + tile) * EP_N + tid, v);
+        else st_sc1(dv.evp_big + ((size_t)b * dm.ntiles + tile) * dv.npbig + (tid - EP_N), v);
     }
     // the workgroup that completes the seed's partial rows forms A / runs the line-search step
     if (dv.epi != EPI_NONE && arrive_last(dv.cnt_eval + (size_t)b * CNT_STRIDE, (unsigned)dm.ntiles, lane))
@@ -225,7 +227,8 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
 inline size_t eval_flat_lds_bytes(const Dims &dm)
 {
     const int HL = dm.disc == DISC_SH ? 2 : 1;
-    return sizeof(double) * ((size_t)3 * (dm.T + HL + 1) * dm.D + (dm.lin ? (size_t)dm.T * dm.D : 0) + (EVAL_THREADS / 64) * EP_N
+    const int KR = EP_GP + dm.NPt > EP_N ? EP_GP + dm.NPt : EP_N;
+    return sizeof(double) * ((size_t)3 * (dm.T + HL + 1) * dm.D + (dm.lin ? (size_t)dm.T * dm.D : 0) + (EVAL_THREADS / 64) * KR
                              + (dm.tdp ? (size_t)(dm.T + HL + 1) * dm.NPt : 0));
 }
 inline int eval_flat_grid(const Dims &dm) { return ((dm.B * dm.ntiles + 7) / 8) * 8; }

@@ -310,7 +310,9 @@ class Annealer(HIPmin):
         else:
             self.bounds = None
         if bounded_minimiser is None:
-            bounded_minimiser = 'scipy' if self.B == 1 else 'device'
+            # L-BFGS-B itself on the device (csrc/va_lbfgsb.hip follows SciPy's iterates step for step:
+            # tests/test_gpu_codegen.py); 'scipy' keeps SciPy on the host around the device evaluator
+            bounded_minimiser = 'device'
         if bounded_minimiser not in ('scipy', 'device'):
             raise ValueError("bounded_minimiser must be 'scipy' or 'device'")
         self._device_bounds = bounds is not None and method == 'L-BFGS-B' and bounded_minimiser == 'device'
