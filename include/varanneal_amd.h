@@ -147,7 +147,8 @@ int va_problem_info(va_handle h, int64_t *n_var, int64_t *ld_internal, int32_t *
 #define VA_TUNE_FOLD 1       /* 1: the seed's last-arriving workgroup forms A / runs the line-search step inside the
                               * evaluation kernel (default while the grid is <= 8 workgroups per CU); 0: tail kernels */
 #define VA_TUNE_GRAD_SC1 2   /* 1: gradient stores write through (default with FOLD)                                   */
-#define VA_TUNE_PRIO 3       /* 1: later-dispatched workgroups of a CU issue at higher priority (default)            */
+#define VA_TUNE_PRIO 3       /* 1: later-dispatched workgroups of a CU issue at higher priority (default); 2: a seed's  */
+                             /* first and last tile (the edge variant of the rows phase) issue ahead; 0: no priorities */
 #define VA_TUNE_GRAPH 4      /* 1: ladder cycles and timed evaluations are replayed from a hipGraph (default)        */
 #define VA_TUNE_PERSIST 5    /* 1: ladders of few seeds on short paths run as ONE cooperative launch of the persistent
                               * per-seed kernel (csrc/va_persist.h: every vector of the minimisation resident in LDS),

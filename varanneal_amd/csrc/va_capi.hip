@@ -1383,7 +1383,7 @@ int va_problem_tune(va_handle h, int32_t what, int32_t value)
         if (h->is_nnet) return fail(VA_EUNSUPPORTED, "the network action chooses its tail by the net's size");
         h->fold = value != 0; break;
     case VA_TUNE_GRAD_SC1: h->dv.gaux = value != 0 ? 1 : 0; break;
-    case VA_TUNE_PRIO: h->dv.prio = value != 0 ? 1 : 0; break;
+    case VA_TUNE_PRIO: h->dv.prio = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case VA_TUNE_GRAPH: h->tune_graph = value != 0; break;
     case VA_TUNE_PERSIST: h->tune_persist = value != 0; break;
     case VA_TUNE_PERSIST_ROWS: {

@@ -44,8 +44,13 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
     constexpr int NV = EP_GP + RHS::NP;
 #ifdef VA_STAMPS
     // diagnostic build only (tools/timeline.py): per-wave wall-clock stamps into the update-partials table
-    unsigned long long *tl = reinterpret_cast<unsigned long long *>(dv.upp) + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+    unsigned long long *tl = reinterpret_cast<unsigned long long *>(dv.upp) + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 10;
 #define STAMP(i) do { if ((threadIdx.x & 63) == 0) tl[i] = wall_clock64(); } while (0)
+    // (where the wave runs: HW_REG_HW_ID = s_getreg id 4 [wave, simd, pipe, cu, sh, se], HW_REG_XCC_ID = id 20)
+    if ((threadIdx.x & 63) == 0) {
+        tl[8] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        tl[9] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned long long)w;
+    }
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -160,10 +165,14 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
     // ones then compete for the vector pipe with workgroups already in their gather / reduction
     // phases and finish up to 1.7 us after the first.  The kernel is as long as its last workgroup:
     // later workgroups issue at higher priority.
-    if (dv.prio) {
+    if (dv.prio == 1) {
         const int grp = (int)(blockIdx.x >> 8);
         if (grp == 1) __builtin_amdgcn_s_setprio(1);
         else if (grp >= 2) __builtin_amdgcn_s_setprio(2);
+    } else if (dv.prio == 2) {
+        // the seed's first and last tile run the edge variant of the rows phase (+0.5 us, profiles/r04_timeline_c3.txt) and
+        // are the workgroups a seed's tail waits for: they issue ahead of the CU's other workgroups
+        if (tile == 0 || tile == dm.ntiles - 1) __builtin_amdgcn_s_setprio(3);
     }
     if (use_d) {
         // trial point x + stp*d in place (the same fma as k_update's accepted iterate), then the
