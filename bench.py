@@ -271,7 +271,7 @@ def extra_linear(device, steps=200):
             "mfma_TFLOPs": flops / ks / 1e12, "frac": bytes_alg(B, N, D, 2, N, len(Lidx)) / ks / 1e9 / HBM_PEAK_GBS}
 
 
-def extra_nnet(device, key, steps):
+def extra_nnet(device, key, steps, fused=None):
     """The network action (BASELINE config 5, va_nnet) as a sub-record: `c5` = the reference's twin example
     (20 layers x 10 neurons, M = 2: one small kernel per evaluation), `c5x` = layers that fill the matrix cores
     (8 x 128 neurons, M = 2048).  Complete evaluations (A formed), HIP events."""
@@ -287,6 +287,8 @@ def extra_nnet(device, key, steps):
     XP = np.array([np.append(x[0], x[1][Pidx]) for x in g])
     rf = 1.1 ** 100
     with _capi.NnetProblem(B, s, din, dout, [np.arange(s[0]), np.arange(s[-1])], RM, RF0, P, Pidx, device=device) as pb:
+        if fused is not None:
+            pb.tune(nnet_fused=fused)
         pb.action_grad(XP, rf)
         ks = event_timed(pb, rf, steps)
     flops = B * M * float(np.sum(3 * 2 * s[1:] * s[:-1]))

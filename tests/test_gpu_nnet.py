@@ -269,3 +269,25 @@ def test_smallest_networks(structure, M, act):
     r = pr.minimize_lbfgs(XP[None, :], 4.0, {'gtol': 1e-10, 'ftol': 1e-12, 'maxfun': 500, 'maxiter': 500})
     assert r["A"][0] < A[0] and r["status"][0] in (0, 1)
     pr.close()
+
+
+@pytest.mark.parametrize("structure,M,act", [([64, 64, 64, 64], 256, "sigmoid"), ([40, 50, 20], 70, "relu"),
+                                             ([128, 100, 128, 7], 130, "tanh")])
+def test_fused_forward_backward_kernel_matches_oracle(structure, M, act):
+    """k_nnet_fb (forward and state-gradient products of every transition in one kernel; tune nnet_fused=1) against the
+    NumPy oracle and, bit for bit in A up to rounding, against the separate kernels"""
+    din, dout, _ = twin.make_nnet_twin(structure, M)
+    Lidx = [np.arange(structure[0]), np.arange(0, structure[-1], 2)]
+    dout = dout[:, Lidx[1]]
+    X, P, Pidx = twin.nnet_initial_guess(structure, M, 3)
+    XP = np.append(X, P[Pidx])[None, :]
+    with _capi.NnetProblem(1, structure, din, dout, Lidx, 3.0, 0.02, P[None, :], Pidx, act=act) as pr:
+        A0, me0, fe0, g0 = pr.action_grad(XP, 7.0)
+        pr.tune(nnet_fused=1)
+        A1, me1, fe1, g1 = pr.action_grad(XP, 7.0)
+        r = pr.minimize_lbfgs(XP, 7.0, {'gtol': 1e-10, 'ftol': 1e-10, 'maxfun': 60, 'maxiter': 40})
+    Ao, meo, feo, go = vno.NnetProblem(structure, din, dout, Lidx, 3.0, 0.02, P, Pidx, act=act).action_grad(XP[0], 7.0)
+    assert abs(A1[0] - Ao) <= 1e-12 * abs(Ao) and abs(me1[0] - meo) <= 1e-12 * abs(Ao)
+    assert np.abs(g1[0] - go).max() <= 1e-10 * np.abs(go).max()
+    assert abs(A1[0] - A0[0]) <= 1e-13 * abs(A0[0]) and np.abs(g1[0] - g0[0]).max() <= 1e-12 * np.abs(g0[0]).max()
+    assert r["A"][0] < A1[0]

@@ -358,7 +358,7 @@ class Problem(object):
         return dict(n_var=nv.value, ld=ld.value, tile_rows=T.value, ntiles=nt.value, eval_kernel=ek.value,
                     run_rows=rr.value)
 
-    TUNE = {"fold": 1, "grad_sc1": 2, "prio": 3, "graph": 4, "persist": 5, "persist_rows": 6}      # VA_TUNE_* of include/varanneal_amd.h
+    TUNE = {"fold": 1, "grad_sc1": 2, "prio": 3, "graph": 4, "persist": 5, "persist_rows": 6, "nnet_fused": 7}      # VA_TUNE_* of include/varanneal_amd.h
 
     def debug_read_persist(self, n):
         out = np.empty(n)

@@ -1118,6 +1118,19 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
         nn.small = (widest <= NN_SMALL && NL <= NN_ROWS_DIRECT) ? (widest <= 16 ? 16 : 32) : 0;
     }
     if (nn.small) nn.nraw = NL;
+    // layers up to NN_FB_W wide with scalar measurement weights: forward and state-gradient products in one kernel
+    // (k_nnet_fb); its workgroups write the first nfb of the n1 + n2 rows, k_nnet_wfrag zeroes the others
+    std::vector<int> wfoff(NL - 1, 0);
+    bool fb_ok = false;
+    {
+        int widest = 0, wfsz = 0;
+        for (int n = 0; n < NL; ++n) widest = s[n] > widest ? s[n] : widest;
+        for (int n = 0; n < NL - 1; ++n) { wfoff[n] = wfsz; wfsz += ((s[n + 1] + 15) / 16) * ((s[n] + 3) / 4) * 64; }
+        nn.nfb = (d->M + NN_FB_R - 1) / NN_FB_R;
+        nn.wfsz = wfsz;
+        fb_ok = !nn.small && widest <= NN_FB_W && !d->rm_in_matrix && nn.nfb <= nn.n1 + nn.n2;
+        nn.fused = 0;                  // (available through va_problem_tune; slower than the two kernels as measured)
+    }
     const bool fold_rows = nn.nraw > NN_ROWS_DIRECT;      // k_ls sums the rows with one wave: keep them few
     dm.nprow = fold_rows ? NN_RED_ROWS : nn.nraw;
     dm.ntiles = dm.nprow; dm.T = NN_TILE; dm.emode = 0;
@@ -1138,6 +1151,11 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
     TRY(h->alloc(&nn.Xw, B * dm.ld));
     if (fold_rows) TRY(h->alloc(&nn.raw, B * nn.nraw * EP_GP));
     TRY(h->alloc(&nn.gpart, B * nn.nmch * (size_t)d->NP));
+    int *wfoff_d = nullptr;
+    if (fb_ok) {
+        TRY(h->alloc(&nn.Wf, B * (size_t)nn.wfsz));
+        TRY(h->alloc(&wfoff_d, NL - 1));
+    }
     TRY(h->alloc(&t1_d, t1.size())); TRY(h->alloc(&t2_d, t2.size())); TRY(h->alloc(&t3_d, t3.size()));
     TRY(alloc_solver_state(h, max_beta, d->keep_paths));
     H2D(s_d, s.data(), NL, int); H2D(off_d, off.data(), NL + 1, int);
@@ -1146,6 +1164,7 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
     if (d->L_in) H2D(din_d, d->data_in, (size_t)d->M * d->L_in, double);
     if (d->L_out) H2D(dout_d, d->data_out, (size_t)d->M * d->L_out, double);
     H2D(P_d, d->P, B * d->NP, double);
+    if (fb_ok) { H2D(wfoff_d, wfoff.data(), NL - 1, int); nn.wfoff = wfoff_d; }
     H2D(t1_d, t1.data(), t1.size(), NnetTile); H2D(t2_d, t2.data(), t2.size(), NnetTile);
     if (!t3.empty()) H2D(t3_d, t3.data(), t3.size(), NnetTile);
     nn.s = s_d; nn.off = off_d; nn.woff = woff_d; nn.boff = boff_d; nn.lmap_in = lin_d; nn.lmap_out = lout_d;
@@ -1158,6 +1177,10 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
         if (d->L_in) { H2D(ri, d->rm_in_matrix, (size_t)d->L_in * d->L_in, double); H2D(li, d->Lidx_in, d->L_in, int); }
         if (d->L_out) { H2D(ro, d->rm_out_matrix, (size_t)d->L_out * d->L_out, double); H2D(lo, d->Lidx_out, d->L_out, int); }
         nn.rmm_in = ri; nn.rmm_out = ro; nn.lidx_in = li; nn.lidx_out = lo;
+    }
+    if (fb_ok) {
+        const hipError_t e = prepare_nnet_fb(nn, user_act);
+        if (e != hipSuccess) { (void)hipGetLastError(); nn.Wf = nullptr; }      // (the tune knob then refuses)
     }
     TRY(finish_create(h));
 #undef TRY
@@ -1385,6 +1408,9 @@ int va_problem_tune(va_handle h, int32_t what, int32_t value)
     case VA_TUNE_GRAD_SC1: h->dv.gaux = value != 0 ? 1 : 0; break;
     case VA_TUNE_PRIO: h->dv.prio = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case VA_TUNE_GRAPH: h->tune_graph = value != 0; break;
+    case VA_TUNE_NNET_FUSED:
+        if (!h->is_nnet || !h->nn.Wf) return fail(VA_ESTATE, "not a network handle whose layers fit the fused kernel");
+        h->nn.fused = value != 0 ? 1 : 0; break;
     case VA_TUNE_PERSIST: h->tune_persist = value != 0; break;
     case VA_TUNE_PERSIST_ROWS: {
         if (!h->persist) return fail(VA_ESTATE, "the handle does not run the persistent kernel");

@@ -16,6 +16,13 @@ constexpr int NN_KC = 32;        // K elements staged in LDS per step
 constexpr int NN_THREADS = 256;
 constexpr int NN_PACK = 8;       // elements per thread of the trial-point kernel (k_nnet_pack)
 
+// layers up to NN_FB_W wide: the forward product and the state-gradient product of every transition in ONE kernel
+// (k_nnet_fb, va_nnet_kernels.h): a workgroup marches a block of NN_FB_R examples through the layers
+#ifndef NN_FB_ROWS
+#define NN_FB_ROWS 64
+#endif
+constexpr int NN_FB_R = NN_FB_ROWS, NN_FB_W = 128, NN_FB_THREADS = 512, NN_FB_PITCH = NN_FB_W + 2;
+
 constexpr int NN_SMALL = 32;         // widest layer / most examples the single-kernel path handles
 constexpr int NN_ROWS_DIRECT = 64;   // partial rows per seed the line-search kernel reduces itself
 constexpr int NN_RED_ROWS = 32;      // rows left by k_nnet_rows when there are more
@@ -47,10 +54,17 @@ struct NnetDev {
     int n0;                        // workgroups per seed of the pack kernel
     int nraw;                      // partial rows per seed written by the kernels (n1 + n2 + n4)
     double *raw;                   // NULL (rows go straight to Dev::evp) or [B][nraw][EP_GP]
+    int fused;                     // 1: k_nnet_fb in place of k_nnet_fwd + k_nnet_bwd_x (every layer <= NN_FB_W wide, scalar RM); off unless
+                                   // asked for (va_problem_tune): measured SLOWER than the two kernels at c5x (profiles/r04_nnet_fused.txt)
+    int nfb;                       // its workgroups per seed: blocks of NN_FB_R examples
+    double *Wf;                    // [B][wfsz] the weights in MFMA B-fragment order (k_nnet_wfrag, per evaluation)
+    const int *wfoff;              // [NL-1] offset of layer n's fragments in Wf
+    int wfsz;
 };
 
-// launches k_nnet_small (small != 0) or k_nnet_fwd of a generated activation module (va_user_act.hip)
-typedef void (*NnetActLaunch)(const Dev *, const NnetDev *, void *stream, int small);
+// launches k_nnet_small (which = 1), k_nnet_fwd (0) or k_nnet_fb (2) of a generated activation module (va_user_act.hip)
+typedef void (*NnetActLaunch)(const Dev *, const NnetDev *, void *stream, int which);
+hipError_t prepare_nnet_fb(const NnetDev &nn, NnetActLaunch user);
 
 void launch_nnet_eval(const Dev &dv, const NnetDev &nn, hipStream_t s, NnetActLaunch user);
 

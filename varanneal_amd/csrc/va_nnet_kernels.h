@@ -227,6 +227,28 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_pack(const Dev dv, const Nn
     }
 }
 
+// the weights in the fragment order k_nnet_fb's first product reads them: for layer n, column block cb, k-step kk, lane l
+//     Wf[wfoff[n] + (cb * nk + kk) * 64 + l] = W_n[16 cb + (l & 15)][4 kk + (l >> 4)]   (zero outside the matrix)
+// and the partial rows no workgroup of the fused evaluation writes (those of the separate kernels) zeroed
+__global__ __launch_bounds__(NN_THREADS) void k_nnet_wfrag(const Dev dv, const NnetDev nn)
+{
+    const int b = blockIdx.y;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    const double *Pw = nn.Pw + (size_t)b * nn.NP;
+    double *Wf = nn.Wf + (size_t)b * nn.wfsz;
+    for (int e = blockIdx.x * NN_THREADS + threadIdx.x; e < nn.wfsz; e += gridDim.x * NN_THREADS) {
+        int n = 0;
+        while (n + 1 < nn.NL - 1 && e >= nn.wfoff[n + 1]) ++n;
+        const int sn = nn.s[n], sn1 = nn.s[n + 1], nk = (sn + 3) >> 2;
+        const int f = e - nn.wfoff[n], l = f & 63, blk = f >> 6, cb = blk / nk, kk = blk - cb * nk;
+        const int c = cb * 16 + (l & 15), k = 4 * kk + (l >> 4);
+        Wf[e] = (c < sn1 && k < sn) ? Pw[nn.woff[n] + (size_t)c * sn + k] : 0.0;
+    }
+    if (blockIdx.x == 0)
+        for (int r = nn.nfb + threadIdx.x; r < nn.n1 + nn.n2; r += NN_THREADS) put_row(dv, nn, b, r, 0.0, 0.0, 0.0, 0.0, 0.0);
+}
+
 #endif  // VA_NNET_ACT_ONLY
 
 // ------------------------------------------------------------------ K1: Z, residual, delta
@@ -300,6 +322,190 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const Nne
     wg_reduce4(v, red, tid);
     if (tid == 0) put_row(dv, nn, b, blockIdx.x, 0.0, v[1], 0.0, 0.0, 0.0);
 }
+
+// ------------------------------------------------------------------ K1 + K2 in one: forward and state-gradient products
+// Layers up to NN_FB_W = 128 wide (c5x: 8 x 128, M = 2048).  As separate kernels the two products move every delta and
+// every q through HBM twice and re-read the states (profiles/r03_nnet_c5x_ablation.txt: 78-83 % of each kernel is
+// memory time).  Here a workgroup of 8 waves owns a block of 64 EXAMPLES and marches it through the transitions:
+//   the block's states X_n sit in LDS (A operand of Z = X_n W_n^T); wave w owns the 16 output columns 16 w ... of every
+//   layer (four 16 x 16 accumulators, one per 16 examples); the B operand comes straight from L2 in fragment order
+//   (nn.Wf, written once per evaluation by k_nnet_wfrag) -- 512 contiguous bytes per matrix instruction, no LDS staging;
+//   epilogue A: residual, q, delta from Z and x_{n+1} (read ONCE from HBM: it becomes the next transition's LDS operand);
+//     delta goes to LDS (A operand of the second product) and to HBM (for k_nnet_bwd_w); q STAYS IN REGISTERS: the
+//     accumulator layout of the next transition's state gradient is the same (example, column) map;
+//   second product G_n = delta_n W_n (B operand: rows of W_n, 128 contiguous bytes per 16 lanes, from L2);
+//   epilogue B: dA/dx_n = G_n + q_{n-1} + measurement term -> gt.
+// Every state is read once and every gradient / delta entry written once: 2.79 -> 1.3 GB per evaluation at c5x.
+// MEASURED (round 4, profiles/r04_nnet_fused.txt): 563 us against 270 + 258 us for the two kernels it replaces -- with
+// one workgroup per CU the layers' memory phases (x_{n+1} in, delta and gradient out) and their matrix phases run in
+// lockstep on every CU instead of overlapping; without any operand fetch in the K loops it still takes 510 us (matrix
+// floor: 191 us).  Off unless asked for (va_problem_tune nnet_fused=1); the next step is named in DESIGN.md 8.
+template <class ACT>
+__global__ __launch_bounds__(NN_FB_THREADS, NN_FB_R == 32 ? 4 : 2) void k_nnet_fb(const Dev dv, const NnetDev nn)
+{
+    extern __shared__ __attribute__((aligned(16))) double fbs[];
+    constexpr int R = NN_FB_R, RB = NN_FB_R / 16, PX = NN_FB_PITCH, NW = NN_FB_THREADS / 64;
+    double *Xs = fbs, *DL = Xs + R * PX, *red = DL + R * PX;          // red: [NW * 5]
+    const int b = blockIdx.y, tid = threadIdx.x;
+    int use_d; double stp, rf;
+    if (!seed_live(dv, b, use_d, stp, rf)) return;
+    const int m0 = blockIdx.x * R;
+    const int nra = min(R, nn.M - m0);
+    const int lane = tid & 63, cb = __builtin_amdgcn_readfirstlane(tid >> 6), lo = lane & 15, hi = lane >> 4;
+    const size_t vo = (size_t)b * dv.dm.ld;
+    const double *Xg = (use_d ? nn.Xw : dv.x) + vo;                      // the trial point's states
+    const double *Pw = nn.Pw + (size_t)b * nn.NP;
+    const double cq = 2.0 * rf * dv.dm.cfe;
+    const int NL = nn.NL;
+    {   // the block's input-layer states; rows / columns that do not exist are zeros (they pad K)
+        const int s0 = nn.s[0];
+        for (int e = tid; e < R * NN_FB_W; e += NN_FB_THREADS) {
+            const int r = e >> 7, c = e & (NN_FB_W - 1);
+            Xs[r * PX + c] = (r < nra && c < s0) ? Xg[(size_t)(m0 + r) * nn.NDnet + c] : 0.0;
+        }
+    }
+    __syncthreads();
+    d4 qprev[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) qprev[rb] = d4{0.0, 0.0, 0.0, 0.0};
+    double v_me = 0.0, v_fe = 0.0, v_gtd = 0.0, v_gn2 = 0.0, v_gmax = 0.0;
+    const int col = cb * 16 + lo;                                         // the lane's column of every layer
+    for (int n = 0; n <= NL - 1; ++n) {
+        const int sn = nn.s[n], offn = nn.off[n];
+        const bool last = n == NL - 1;
+        const int sn1 = last ? 0 : nn.s[n + 1], offn1 = last ? 0 : nn.off[n + 1];
+        d4 q[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) q[rb] = d4{0.0, 0.0, 0.0, 0.0};
+        if (!last) {
+            // ---- product 1: Z = X_n W_n^T for the wave's 16 columns of layer n+1
+            d4 acc[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = d4{0.0, 0.0, 0.0, 0.0};
+            if (cb * 16 < sn1) {
+                const int nk = (sn + 3) >> 2;
+                const double *wf = nn.Wf + (size_t)b * nn.wfsz + nn.wfoff[n] + (size_t)cb * nk * 64 + lane;
+                // (B fragments eight k-steps ahead: an L2 round trip is about the matrix time of eight steps of the SIMD's two waves)
+                constexpr int PF = 8;
+                double bq[PF];
+#pragma unroll
+                for (int u = 0; u < PF; ++u) bq[u] = u < nk ? wf[u * 64] : 0.0;
+                for (int k0 = 0; k0 < nk; k0 += PF) {
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {
+                        const double bc = bq[u];
+                        bq[u] = k0 + PF + u < nk ? wf[(k0 + PF + u) * 64] : 0.0;
+                        if (k0 + u < nk) {
+                            const int k = 4 * (k0 + u) + hi;
+#pragma unroll
+                            for (int rb = 0; rb < RB; ++rb)
+                                acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(rb * 16 + lo) * PX + k], bc, acc[rb], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                   // every wave is done with X_n
+            // ---- epilogue A: residual, q, delta; x_{n+1} becomes the next operand (columns beyond the layer: zeros)
+            {
+                const bool on = col < sn1;
+                const double bias = on ? Pw[nn.boff[n] + col] : 0.0;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ml = rb * 16 + hi + 4 * r;
+                        double xv = 0.0, dl = 0.0;
+                        if (on && ml < nra) {
+                            const size_t idx = vo + (size_t)(m0 + ml) * nn.NDnet + offn1 + col;
+                            xv = Xg[idx - vo];
+                            const double z = acc[rb][r] + bias;
+                            const double a = ACT::f(z), da = ACT::d(z, a);
+                            const double res = xv - a, qv = cq * res;
+                            v_fe += res * res;
+                            dl = -qv * da;
+                            q[rb][r] = qv;
+                            nn.delta[idx] = dl;
+                        }
+                        DL[ml * PX + col] = dl;
+                        Xs[ml * PX + col] = xv;
+                    }
+            }
+            __syncthreads();
+        }
+        // ---- product 2 (not for the last layer: nothing leaves it) and epilogue B: dA/dx_n for the wave's 16 columns of layer n
+        // (the accumulators start from q_{n-1}: dA/dx_n = q_{n-1} + delta_n W_n, same (example, column) map)
+        d4 g[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) g[rb] = qprev[rb];
+        if (!last && cb * 16 < sn) {
+            const int nk = (sn1 + 3) >> 2;
+            const double *W = Pw + nn.woff[n];
+            const bool con = col < sn;
+            constexpr int PF = 8;
+            double bq[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) { const int k = 4 * u + hi; bq[u] = (con && k < sn1) ? W[(size_t)k * sn + col] : 0.0; }
+            for (int k0 = 0; k0 < nk; k0 += PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const double bc = bq[u];
+                    const int kn = 4 * (k0 + PF + u) + hi;
+                    bq[u] = (con && kn < sn1) ? W[(size_t)kn * sn + col] : 0.0;
+                    if (k0 + u < nk) {
+                        const int k = 4 * (k0 + u) + hi;
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb)
+                            g[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(DL[(rb * 16 + lo) * PX + k], bc, g[rb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (col < sn) {
+            int l = -1; double rm = 0.0; const double *dat = nullptr; int L = 0;
+            if (n == 0) { l = nn.lmap_in[col]; rm = nn.rm_in; dat = nn.din; L = nn.Lin; }
+            else if (last) { l = nn.lmap_out[col]; rm = nn.rm_out; dat = nn.dout; L = nn.Lout; }
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ml = rb * 16 + hi + 4 * r;
+                    if (ml >= nra) continue;
+                    const size_t idx = vo + (size_t)(m0 + ml) * nn.NDnet + offn + col;
+                    double gv = g[rb][r];
+                    if (l >= 0) {
+                        const double diff = Xg[idx - vo] - dat[(size_t)(m0 + ml) * L + l];
+                        v_me += rm * diff * diff;
+                        gv += 2.0 * dv.dm.cme * rm * diff;
+                    }
+                    dv.gt[idx] = gv;
+                    if (use_d) v_gtd += gv * dv.d[idx];
+                    v_gn2 += gv * gv;
+                    v_gmax = fmax(v_gmax, fabs(gv));
+                }
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) qprev[rb] = q[rb];
+    }
+    // the workgroup's row of partial sums
+    {
+        double w;
+        w = wave_sum(v_me); if (lane == 0) red[cb * 5 + 0] = w;
+        w = wave_sum(v_fe); if (lane == 0) red[cb * 5 + 1] = w;
+        w = wave_sum(v_gtd); if (lane == 0) red[cb * 5 + 2] = w;
+        w = wave_sum(v_gn2); if (lane == 0) red[cb * 5 + 3] = w;
+        w = wave_max(v_gmax); if (lane == 0) red[cb * 5 + 4] = w;
+        __syncthreads();
+        if (tid == 0) {
+            double t[5];
+            for (int k = 0; k < 5; ++k) {
+                t[k] = red[k];
+                for (int ww = 1; ww < NW; ++ww) t[k] = (k == 4) ? fmax(t[k], red[ww * 5 + k]) : t[k] + red[ww * 5 + k];
+            }
+            put_row(dv, nn, b, blockIdx.x, t[0], t[1], t[2], t[3], t[4]);
+        }
+    }
+}
+inline size_t nnet_fb_lds() { return sizeof(double) * ((size_t)2 * NN_FB_R * NN_FB_PITCH + 5 * (NN_FB_THREADS / 64) + 8); }
 
 #ifndef VA_NNET_ACT_ONLY
 // ------------------------------------------------------------------ K2: dA/dX
@@ -704,9 +910,22 @@ __global__ __launch_bounds__(NN_THREADS, NN_SMALL_WAVES) void k_nnet_small(const
 
 // the two launches that depend on the activation type
 template <class ACT>
-inline void launch_nnet_act(const Dev &dv, const NnetDev &nn, hipStream_t s, bool small)
+inline hipError_t prepare_nnet_fb_act()
+{
+    return hipFuncSetAttribute((const void *)k_nnet_fb<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+// which: 0 k_nnet_fwd, 1 k_nnet_small, 2 k_nnet_fb, 3 prepare k_nnet_fb (opt in to its LDS on the current device)
+template <class ACT>
+inline void launch_nnet_act(const Dev &dv, const NnetDev &nn, hipStream_t s, int which)
 {
     const int B = dv.dm.B;
+    const bool small = which == 1;
+    if (which == 3) { (void)prepare_nnet_fb_act<ACT>(); return; }
+    if (which == 2) {
+        hipLaunchKernelGGL(k_nnet_fb<ACT>, dim3(nn.nfb, B), dim3(NN_FB_THREADS), nnet_fb_lds(), s, dv, nn);
+        return;
+    }
     if (small) {
         if (nn.rmm_in) hipLaunchKernelGGL((k_nnet_small<ACT, true>), dim3(nn.NL, B), dim3(NN_THREADS), nnet_small_lds(nn.small), s, dv, nn);
         else hipLaunchKernelGGL((k_nnet_small<ACT, false>), dim3(nn.NL, B), dim3(NN_THREADS), nnet_small_lds(nn.small), s, dv, nn);

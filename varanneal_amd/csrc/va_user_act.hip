@@ -22,9 +22,10 @@ void va_user_act_info(int *out)
     out[0] = (int)sizeof(va::Dev); out[1] = (int)sizeof(va::NnetDev); out[2] = (int)sizeof(va::SeedState);
 }
 
-void va_user_act_launch(const va::Dev *dv, const va::NnetDev *nn, void *stream, int small)
+// which: 0 k_nnet_fwd, 1 k_nnet_small, 2 k_nnet_fb, 3 opt k_nnet_fb in to its LDS (va_nnet_kernels.h launch_nnet_act)
+void va_user_act_launch(const va::Dev *dv, const va::NnetDev *nn, void *stream, int which)
 {
-    va::launch_nnet_act<va::ActUser>(*dv, *nn, (hipStream_t)stream, small != 0);
+    va::launch_nnet_act<va::ActUser>(*dv, *nn, (hipStream_t)stream, which);
 }
 
 }  // extern "C"
