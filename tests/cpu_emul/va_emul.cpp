@@ -173,7 +173,7 @@ void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_
             c.xg = x; c.dg = d; c.gtg = gt;
             Tile2 tmp; tmp.xg = x; tmp.dg = d; tmp.use_d = use_d; tmp.stp = stp;
             tile2_params<RHS>(dm, E.pp, b, tmp);          // (only RHS::NP is used)
-            for (int k = 0; k < RHS_BIG_NP; ++k) c.p[k] = tmp.p[k];
+            for (int k = 0; k < RHS_MAX_NP; ++k) c.p[k] = tmp.p[k];
             acc[t].clear();
         }
         const bool edge = (tile * T - HL < 0) || (tile * T + T + HR > dm.N);
@@ -256,7 +256,7 @@ void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_
                 c.xs = xs.data(); c.es = r2.data(); c.gtg = gt;
                 Tile2 tmp; tmp.xg = x; tmp.dg = d; tmp.use_d = use_d; tmp.stp = stp;
                 tile2_params<RHS>(dm, E.pp, b, tmp);           // (only RHS::NP is used)
-                for (int k = 0; k < RHS_BIG_NP; ++k) c.p[k] = tmp.p[k];
+                for (int k = 0; k < RHS_MAX_NP; ++k) c.p[k] = tmp.p[k];
                 acc[l].clear();
                 tile4_obs<K, NE>(dm, E.pp, c, rg[l]);
                 for (int k = 0; k < K; ++k) {

@@ -24,7 +24,7 @@ pb.eval_timed(bench.RF_SCALE, 20)
 names = ["start", "issued", "landed", "rows", "gather", "sums", "barrier", "arrived"]
 for rep in range(3):
     pb.eval_timed(bench.RF_SCALE, 1)
-    raw = pb.debug_partials(nwg * 4 * 8).view(np.uint64).reshape(nwg, 4, 8).astype(np.int64)
+    raw = pb.debug_partials(nwg * 4 * 10).view(np.uint64).reshape(nwg, 4, 10)[:, :, :8].astype(np.int64)
     t0 = raw[:, :, 0].min()
     us = (raw - t0) * 1e-2
     w0 = us[:, 0, :]

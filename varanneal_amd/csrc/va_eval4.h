@@ -5,6 +5,7 @@
 // Tile arithmetic: va_tile4.h; tail of an evaluation: va_epilogue.h.
 #pragma once
 #include "va_eval_flat.h"
+#include "va_measure.h"
 
 namespace va {
 
@@ -42,22 +43,8 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
 
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, NE = RHS::NE;
     constexpr int NV = EP_GP + RHS::NP;
-#ifdef VA_STAMPS
-    // diagnostic build only (tools/timeline.py): per-wave wall-clock stamps into the update-partials table
-    unsigned long long *tl = reinterpret_cast<unsigned long long *>(dv.upp) + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 10;
-#define STAMP(i) do { if ((threadIdx.x & 63) == 0) tl[i] = wall_clock64(); } while (0)
-    // (where the wave runs: HW_REG_HW_ID = s_getreg id 4 [wave, simd, pipe, cu, sh, se], HW_REG_XCC_ID = id 20)
-    if ((threadIdx.x & 63) == 0) {
-        tl[8] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-        tl[9] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned long long)w;
-    }
-#else
-#define STAMP(i) do { } while (0)
-#endif
-    STAMP(0);
-#if defined(VA_E4_ABLATE) && VA_E4_ABLATE == 1
-    return;                                   // measurement build (profiles/r03_ablation_c3.txt): the launch alone
-#endif
+    VA_E4_STAMP_SETUP(dv, w);      // (diagnostic builds only: va_measure.h)
+    VA_E4_STAMP(0);
     // with D fixed at compile time the whole geometry (and every LDS offset) is constant
     const Geo4 g = DC > 0 ? tile4_geo<HL + HR>(DC > 0 ? DC : 4, K, NE, SUB) : dv.g4;
     constexpr int NI = DC > 0 ? (tile4_geo<HL + HR>(DC > 0 ? DC : 4, K, NE, SUB).XP + 63) / 64 : T4_NI_MAX;
@@ -121,12 +108,8 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 typedef unsigned v2u __attribute__((ext_vector_type(2)));
-#if defined(VA_E4_ABLATE) && VA_E4_ABLATE == 7
-                rg[s].yv[k] = 1.0 + k + voff * 1e-9;         // measurement build: no observation loads (wrong sums, same work)
-#else
                 const v2u v = __builtin_amdgcn_raw_buffer_load_b64(yr, voff, (s * RK + k) * dm.L * 8, 0);
                 rg[s].yv[k] = __hiloint2double((int)v.y, (int)v.x);
-#endif
             }
         }
     } else if (active) {
@@ -138,29 +121,10 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
         }
     }
 
-    STAMP(1);
+    VA_E4_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the wave's images have landed
     __builtin_amdgcn_wave_barrier();
-    STAMP(2);
-#if defined(VA_E4_ABLATE) && (VA_E4_ABLATE == 2 || VA_E4_ABLATE == 3)
-    {   // measurement builds: staging alone (2), staging + the gradient stores of a copy (3)
-#if VA_E4_ABLATE == 3
-        const __amdgpu_buffer_rsrc_t gr0 = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(dv.gt + (size_t)b * dm.ld), 0, (int)(sizeof(double) * dm.N * D), 0x00020000);
-        const bool writer0 = active && (tx & 1) == 0;
-        const int voff0 = ((n0w + a * K) * D + tx) * 8;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            typedef unsigned v4u __attribute__((ext_vector_type(4)));
-            double x0, x1;
-            ld2(xsw + a * g.PITCH + (tx & ~1) + (k + HL < K ? (k + HL) * D : g.PITCH + (k + HL - K) * D), x0, x1);
-            const v4u v = {(unsigned)__double2loint(x0), (unsigned)__double2hiint(x0), (unsigned)__double2loint(x1), (unsigned)__double2hiint(x1)};
-            if (writer0) { if (dv.gaux) __builtin_amdgcn_raw_buffer_store_b128(v, gr0, voff0, k * D * 8, 16); else __builtin_amdgcn_raw_buffer_store_b128(v, gr0, voff0, k * D * 8, 0); }
-        }
-#endif
-        return;
-    }
-#endif
+    VA_E4_STAMP(2);
     // Workgroups that share a CU start together and their data arrives in dispatch order; the later
     // ones then compete for the vector pipe with workgroups already in their gather / reduction
     // phases and finish up to 1.7 us after the first.  The kernel is as long as its last workgroup:
@@ -216,9 +180,9 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
             if (lane == 0) strip[k] = r;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        STAMP(5);
+        VA_E4_STAMP(5);
         __builtin_amdgcn_s_barrier();
-        STAMP(6);
+        VA_E4_STAMP(6);
         if (wave == 0) {
             if (lane < NV) {
                 const double r0 = strip[lane], r1 = strip[g.WAVE + lane], r2 = strip[2 * g.WAVE + lane], r3 = strip[3 * g.WAVE + lane];
@@ -244,7 +208,7 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
             else tile4_rows<RHS, DISC, K, false, DC, W_SCALAR>(dm, dv.pp, g, t, rg[s], acc);
         }
         wave_sync_lds();          // products are read by the same wave only: LDS is in order within a wave
-        if (s == SUB - 1) STAMP(3);
+        if (s == SUB - 1) VA_E4_STAMP(3);
         // A plain S1 evaluation needs A = me + fe and dA/dp from the sums: all known once the rows are
         // done.  The row goes out now, and the three dependent round trips of the tail (row
         // acknowledged, arrival counted, rows of the seed read back) run beside the gather phase and
@@ -252,12 +216,6 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
         if (!lsq && s == SUB - 1) publish();
 #pragma unroll
         for (int k = 0; k < K; ++k) gvv[s][k] = 0.0;
-#if defined(VA_E4_ABLATE) && VA_E4_ABLATE == 4
-        // measurement build: no gather phase -- the direct term goes out as the gradient
-#pragma unroll
-        for (int k = 0; k < K; ++k) gvv[s][k] = rg[s].direct[k];
-        if (false)
-#endif
         if (active) {
             if (edge) {
                 if (lsq) tile4_grad<RHS, DISC, K, true, DC, W_SCALAR, true>(dm, g, t, rg[s], acc, gvv[s]);
@@ -269,7 +227,7 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
         }
         if (s + 1 < SUB) wave_sync_lds();     // the next sub-tile overwrites the product arrays
     }
-    STAMP(4);
+    VA_E4_STAMP(4);
     // a line-search evaluation also needs g.d, g.g and max|g|: its row waits for the gradient
     if (lsq) publish();
     {
@@ -305,11 +263,6 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
             }
         }
     }
-#if defined(VA_E4_ABLATE) && (VA_E4_ABLATE == 4 || VA_E4_ABLATE == 5)
-    // measurement builds: no last-arriver tail (its arrival count is reset here instead)
-    if (wave == 0 && lane == 0 && dv.epi != EPI_NONE) __hip_atomic_store(dv.cnt_eval + (size_t)b * CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-#endif
     // The last workgroup of the seed runs the tail (and resets the counter for the next launch).
     // (Measured at C3: running it before wave 0's own gradient stores, so that its loads do not retire
     // behind seven write-through stores, is slower -- 10.2 vs 9.6 us: those stores then end the kernel.)
@@ -318,16 +271,13 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
         old = __builtin_amdgcn_readfirstlane(old);
         asm volatile("" ::: "memory");
         last = old == (unsigned)dm.ntiles - 1u;
-        STAMP(7);
+        VA_E4_STAMP(7);
         if (last) {
             if (lane == 0) __hip_atomic_store(dv.cnt_eval + (size_t)b * CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             eval_epilogue<true>(dv, b, lane, reinterpret_cast<SeedHot *>(xsw), dv.epi);
         }
     }
-#ifdef VA_STAMPS
-    if (last) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tl[1] = wall_clock64(); }    // (wave 0 re-uses slot 1)
-#endif
-#undef STAMP
+    VA_E4_STAMP_TAIL(last);        // (wave 0 re-uses slot 1)
 }
 
 

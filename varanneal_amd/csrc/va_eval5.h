@@ -173,18 +173,7 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
         }
         const unsigned ycol = (unsigned)(l_start + 2 * ypc) * 8u;
         auto issue = [&](int k, int pos) {
-#if defined(VA_E5_ABLATE) && VA_E5_ABLATE == 3
-            // measurement build: the same ring, but every wave streams ONE contiguous run (1 KiB per request, lane-linear)
-            // instead of two 496-byte runs a row apart -- what a wave that owned whole rows would ask the memory for
-            {
-                const size_t span = (size_t)dm.B * dm.ld * 8 - 4096;
-                const size_t wv = ((size_t)w * 4 + wave) * (size_t)nslots + k;
-                const char *src = reinterpret_cast<const char *>(dv.x) + ((wv << 10) % (span & ~(size_t)1023)) + lane * 16;
-                if (dma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(xring + pos * SLOTX), 16, 0, 0);
-            }
-#else
             if (dma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(xrow + k * xstep + xoff), (lds_void_t *)(xring + pos * SLOTX), 16, 0, 0);
-#endif
             if (LSRUN && use_d) {
                 if (dma_on) __builtin_amdgcn_global_load_lds((glb_void_t *)(drow + k * xstep + xoff), (lds_void_t *)(dring + pos * SLOTX), 16, 0, 0);
             }
@@ -262,9 +251,6 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
         };
         // rows m0, m0 + 1 (or m0 alone) of the gradient: LDS -> 16-byte stores
         auto flush = [&](int m0, int voff) {
-#if defined(VA_E5_ABLATE) && (VA_E5_ABLATE == 1 || VA_E5_ABLATE == 3)
-            return;
-#endif
             wave_sync_lds();
             double a0, a1;
             ld2(outrd, a0, a1);
@@ -295,16 +281,6 @@ __global__ __launch_bounds__(64 * T5_WPG_MAX, 4) void k_eval5(const Dev dv)
         // row j enters: f_j, the residual of the interval (j-1, j), and row j-1 is finished; FIRST: only
         // load the state registers
         auto step = [&](const Row &t, bool first, int orow) {
-#if defined(VA_E5_ABLATE) && (VA_E5_ABLATE == 1 || VA_E5_ABLATE == 3)
-            // measurement build: the staging ring alone (no arithmetic, no stores)
-            fe += t.x0; return;
-#elif defined(VA_E5_ABLATE) && VA_E5_ABLATE == 2
-            // measurement build: staging ring + the gradient stores (a copy)
-            {
-                if (!first) outb[orow * 64 + lane] = t.x0;
-                return;
-            }
-#endif
             const double f = RHS::f(col, t.x0, t.xn, p, 0.0, nullptr);
             if (!first) {
                 double r;

@@ -35,13 +35,6 @@ namespace va {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-// measurement builds (tools/nnabl.sh, profiles/r03_nnet_c5x_ablation.txt): -DVA_NN_ABLATE=1 no matrix instructions,
-// 2 the activation replaced by the identity, 3 no operand loads inside the K loop, 4 no memory traffic in the epilogues
-#if defined(VA_NN_ABLATE) && VA_NN_ABLATE == 3
-#define VA_NN_LOOP_LOADS 0
-#else
-#define VA_NN_LOOP_LOADS 1
-#endif
 
 constexpr int PRK = NN_KC + 4;     // [row][k] pitch: 36 = 4 (mod 32)
 constexpr int PKR = NN_TILE + 16;  // [k][row] pitch: 80 = 16 (mod 32)
@@ -110,9 +103,6 @@ __device__ __forceinline__ void mma_step(const double *As, const double *Bs, int
 {
     const int lo = lane & 15, hi = lane >> 4;
     if (!live) return;
-#if defined(VA_NN_ABLATE) && VA_NN_ABLATE == 1
-    acc[0][0][0] += As[lane] + Bs[lane]; return;               // measurement build: no matrix instructions
-#endif
 #pragma unroll
     for (int kk = 0; kk < NN_KC / 4; ++kk) {
         const int k = 4 * kk + hi;
@@ -277,7 +267,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const Nne
     for (int k0 = 0; k0 < K; k0 += NN_KC) {
         store_rk(As, tid, va); store_rk(Bs, tid, vb);
         __syncthreads();
-        if (VA_NN_LOOP_LOADS && k0 + NN_KC < K) {
+        if (k0 + NN_KC < K) {
             load_rk(X + k0 + NN_KC, nn.NDnet, nra, K - k0 - NN_KC, tid, va);
             load_rk(W + k0 + NN_KC, sn, nrb, K - k0 - NN_KC, tid, vb);
         }
@@ -301,22 +291,12 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const Nne
                 if (m >= nn.M) continue;
                 const size_t idx = vo + (size_t)m * nn.NDnet + tl.offn1 + i;
                 const double z = acc[bi][bj][r] + bias;
-#if defined(VA_NN_ABLATE) && VA_NN_ABLATE == 2
-                const double a = z, da = 1.0;
-#else
                 const double a = ACT::f(z), da = ACT::d(z, a);
-#endif
-#if defined(VA_NN_ABLATE) && VA_NN_ABLATE == 4
-                const double res = 1.0 - a;
-                v[1] += res * res * da;
-                (void)idx;
-#else
                 const double res = Xs[idx] - a;
                 const double q = cq * res;
                 v[1] += res * res;
                 nn.delta[idx] = -q * da;
                 dv.gt[idx] = q;
-#endif
             }
     }
     wg_reduce4(v, red, tid);
@@ -537,11 +517,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_x(const Dev dv, const N
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wr * 32 + bi * 16 + (lane >> 4) + 4 * r;
-#if defined(VA_NN_ABLATE) && VA_NN_ABLATE == 4
-                q0[bi][bj][r] = 0.0;
-#else
                 q0[bi][bj][r] = (n > 0 && j < sn && m < nn.M) ? dv.gt[vo + (size_t)m * nn.NDnet + tl.offn + j] : 0.0;
-#endif
             }
     }
     if (K > 0) {
@@ -553,7 +529,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_x(const Dev dv, const N
         for (int k0 = 0; k0 < K; k0 += NN_KC) {
             store_rk(As, tid, va); store_kr(Bs, tid, vb);
             __syncthreads();
-            if (VA_NN_LOOP_LOADS && k0 + NN_KC < K) {
+            if (k0 + NN_KC < K) {
                 load_rk(Dl + k0 + NN_KC, nn.NDnet, nra, K - k0 - NN_KC, tid, va);
                 load_kr(W + (size_t)(k0 + NN_KC) * sn, sn, nrb, K - k0 - NN_KC, tid, vb);
             }
@@ -591,9 +567,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_x(const Dev dv, const N
                         g += 2.0 * dv.dm.cme * rm * diff;
                     }
                 }
-#if !(defined(VA_NN_ABLATE) && VA_NN_ABLATE == 4)
                 dv.gt[idx] = g;
-#endif
                 if (use_d) v[1] += g * dv.d[idx];
                 v[2] += g * g;
                 v[3] = fmax(v[3], fabs(g));
@@ -629,7 +603,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_bwd_w(const Dev dv, const N
     for (int k0 = 0; k0 < K; k0 += NN_KC) {
         store_kr(As, tid, va); store_kr(Bs, tid, vb);
         __syncthreads();
-        if (VA_NN_LOOP_LOADS && k0 + NN_KC < K) {
+        if (k0 + NN_KC < K) {
             const size_t sh = (size_t)(k0 + NN_KC) * nn.NDnet;
             load_kr(Dl + sh, nn.NDnet, nra, K - k0 - NN_KC, tid, va);
             load_kr(X + sh, nn.NDnet, nrb, K - k0 - NN_KC, tid, vb);

@@ -30,16 +30,9 @@
 // Compiled into libvaranneal_amd.so for the built-in Lorenz-96 and into every generated right-hand-side module.
 #pragma once
 #include "va_eval_flat.h"
+#include "va_measure.h"
 
 namespace va {
-
-// measurement build (-DVA_PZ_STAMPS, never the product): thread 0 of workgroup 0 of seed 0 accumulates the wall-clock
-// ticks (100 MHz) between consecutive marks of the cycle and leaves the sums in pz.stamps
-#ifdef VA_PZ_STAMPS
-#define PZ_MARK(i) do { if (tid == 0) { const long long t_ = wall_clock64(); pz_acc[i] += t_ - pz_prev; pz_prev = t_; } } while (0)
-#else
-#define PZ_MARK(i) do {} while (0)
-#endif
 
 #ifndef PZ_THREADS_N
 #define PZ_THREADS_N 1024
@@ -311,10 +304,7 @@ __global__ __launch_bounds__(PZ_THREADS) void k_seed(const Dev dv)
     c.ps = nullptr;
 
     long long cyc = 0;
-#ifdef VA_PZ_STAMPS
-    long long pz_acc[PZ_NSTAMP - 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pz_prev = wall_clock64();
-    const long long pz_c0 = clock64(), pz_w0 = pz_prev;          // (shader-clock cycles against the 100 MHz wall clock: the clock the launch ran at)
-#endif
+    PZ_MARK_SETUP();               // (measurement builds only: va_measure.h)
     for (;; ++cyc) {
         PZ_MARK(12);
         const int phase = hot->phase;
@@ -617,13 +607,7 @@ __global__ __launch_bounds__(PZ_THREADS) void k_seed(const Dev dv)
             if (tid == 0) atomicAdd(dv.pz.cycles, (unsigned long long)cyc);
         }
     }
-#ifdef VA_PZ_STAMPS
-    if (blockIdx.x == 0 && tid == 0) {
-        pz_acc[9] = clock64() - pz_c0; pz_acc[10] = wall_clock64() - pz_w0;
-        for (int i = 0; i < PZ_NSTAMP - 1; ++i) dv.pz.stamps[i] = (double)pz_acc[i];
-        dv.pz.stamps[PZ_NSTAMP - 1] = (double)cyc;
-    }
-#endif
+    PZ_MARK_FLUSH(dv.pz.stamps, cyc);
 }
 
 inline const void *seed_kernel_of(const void *const k[4], int disc)
