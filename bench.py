@@ -389,6 +389,34 @@ def extra_ladder(device, D, N, B, Y, Lidx, XP, P, nbeta=30):
                     "seed batch sit in the 256 MiB Infinity Cache, so rates above the HBM figure are possible"}
 
 
+def extra_ladder_small(device, N, nbeta=30):
+    """BASELINE configs 1 (N = 200) and 2 (N = 1000): ONE seed, the whole 30-rung ladder.  Few seeds on a short path run
+    the persistent per-seed kernel (csrc/va_persist.h: one cooperative launch, every vector of the minimisation in LDS);
+    the same handle with `tune persist=0` runs the three-launch cycle for comparison."""
+    from varanneal_amd import _capi, twin
+    D, B = 20, 1
+    Y, Lidx, XP, P = make_inputs(D, N, B, 0)
+    rf = 1.5 ** np.arange(nbeta)
+    opts = {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000000, 'maxiter': 1000000}
+    out = {"workload": "lorenz96_D%d_N%d_B1_trapezoid_ladder%d" % (D, N, nbeta)}
+    with _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", device=device, max_beta=nbeta) as pb:
+        geo = pb.persistent()
+        out["persistent_workgroups_rows"] = list(geo) if geo else None
+        for tag, on in (("persistent", 1), ("three_launch", 0)):
+            if on and not geo:
+                continue
+            pb.tune(persist=on)
+            pb.anneal(XP, rf[:2], opts)                               # warm-up
+            c0 = pb.counters()["cycles"]
+            t0 = time.perf_counter()
+            r = pb.anneal(XP, rf, opts)
+            dt = time.perf_counter() - t0
+            cyc = pb.counters()["cycles"] - c0
+            out[tag] = {"seconds": dt, "cycles": int(cyc), "us_per_cycle": dt * 1e6 / max(1, cyc), "seed_evals": int(r["nfev"].sum()),
+                        "seed_evals_per_s": int(r["nfev"].sum()) / dt, "A_final": float(r["A"][0, -1]), "k_final": float(r["pest"][0, -1, 0])}
+    return out
+
+
 def timed_steps(pb, rf, steps, warmup, A, dist, world, torch, barrier, graph_fixed=None):
     """EXACTLY `steps` batched evaluations between two (barrier + synchronize) brackets; returns
     (wall seconds, kernel ms by HIP events, gather ms, ramp launches), the times the MAX over ranks.  Before the
@@ -738,6 +766,7 @@ def main():
         if world == 1 and args.workload == "c3" and not args.no_extra:
             pb.close()
             out["extra"] = {"ladder": extra_ladder(local_rank, D, N, B, Y, Lidx, XP, P),
+                            "ladder_c1": extra_ladder_small(local_rank, 200), "ladder_c2": extra_ladder_small(local_rank, 1000),
                             "c4": extra_c4(local_rank),
                             "c3_sh": extra_variant(local_rank, disc="SimpsonHermite", N=1001),      # (what Lorenz96_anneal.py:85 runs)
                             "c4_sh": extra_variant(local_rank, steps=30, D=200, disc="SimpsonHermite", N=5001),

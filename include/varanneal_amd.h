@@ -150,7 +150,7 @@ int va_problem_info(va_handle h, int64_t *n_var, int64_t *ld_internal, int32_t *
 #define VA_TUNE_PRIO 3       /* 1: later-dispatched workgroups of a CU issue at higher priority (default); 2: a seed's  */
                              /* first and last tile (the edge variant of the rows phase) issue ahead; 0: no priorities */
 #define VA_TUNE_GRAPH 4      /* 1: ladder cycles and timed evaluations are replayed from a hipGraph (default)        */
-#define VA_TUNE_PERSIST 5    /* 1: ladders of few seeds on short paths run as ONE cooperative launch of the persistent
+#define VA_TUNE_PERSIST 5    /* 1: ladders of few seeds on short paths run as ONE launch of the persistent
                               * per-seed kernel (csrc/va_persist.h: every vector of the minimisation resident in LDS),
                               * when the problem is eligible (default); 0: always the three-launch cycle.  Same
                               * arithmetic, different order of the partial sums: results agree to rounding, not bit for bit */

@@ -1,4 +1,4 @@
-"""GPU tests of the persistent per-seed ladder kernel (csrc/va_persist.h): ONE cooperative launch runs the whole RF
+"""GPU tests of the persistent per-seed ladder kernel (csrc/va_persist.h): ONE launch runs the whole RF
 ladder of a seed, every vector of the minimisation resident in the LDS of its workgroups -- the path the drop-in takes
 for the reference's default use (examples/Lorenz96_D20/Lorenz96_anneal.py:84-86: one seed, N = 161).
 

@@ -80,7 +80,7 @@ struct va_problem_s {
     int (*user_prepare)(const Dev *) = nullptr;
     int (*user_seed)(const Dev *, int, void *) = nullptr;
     NnetActLaunch user_act = nullptr;  // generated activation module's launcher (nn.act >= NNET_USER)
-    // few seeds, short paths: the whole ladder in ONE cooperative launch, every vector of the minimisation resident in
+    // few seeds, short paths: the whole ladder in ONE launch, every vector of the minimisation resident in
     // the LDS of pz_G workgroups per seed (va_persist.h); chosen at create when the slices fit and all are co-resident
     bool persist = false, tune_persist = true;
     int pz_G = 0, pz_T = 0, pz_maxG = 0;
@@ -558,8 +558,8 @@ int run_ladder(va_handle h, const double *rf_scale, int nbeta)
     return VA_OK;
 }
 
-// The same ladder as ONE cooperative launch of the persistent per-seed kernel.  *fell_back: the launch was refused (the
-// workgroups cannot all be resident, e.g. another process holds CUs): nothing has run, take the three-launch cycle.
+// The same ladder as ONE launch of the persistent per-seed kernel.  *fell_back: the launch was refused, or its workgroups
+// turned out not to be all resident (e.g. another process holds CUs): nothing was kept, take the three-launch cycle.
 int run_ladder_persist(va_handle h, const double *rf_scale, int nbeta, bool *fell_back)
 {
     Dev &dv = h->dv;
@@ -594,7 +594,13 @@ int run_ladder_persist(va_handle h, const double *rf_scale, int nbeta, bool *fel
     const long long cyc = (long long)(misc.cycles / (unsigned long long)(dv.dm.B > 0 ? 1 : 1));
     h->n_cycles += cyc; h->n_eval_launch += cyc;
     h->n_seed_evals = h->n_seed_evals_direct + (int64_t)*(unsigned long long *)(h->h_nactive + 2);
-    if (misc.abort_flag == 1) return fail(VA_ESTATE, "persistent ladder: a grid barrier timed out (the seed's %d workgroups were not all resident)", h->pz_G);
+    if (misc.abort_flag == 1) {
+        // a poll timed out: the seed's workgroups were not all resident.  Nothing was written back (x still holds the start
+        // point, the result tables are rewritten from rung 0): this handle takes the three-launch cycle from now on
+        h->persist = false;
+        *fell_back = true;
+        return VA_OK;
+    }
     if (misc.abort_flag == 2) return fail(VA_ESTATE, "ladder did not finish within %lld cycles", max_cycles);
     if (*h->h_nactive > 0) return fail(VA_ESTATE, "persistent ladder ended with %d live seeds", *h->h_nactive);
     return VA_OK;

@@ -93,7 +93,7 @@ int eval_grid(const Dims &dm);
 void launch_lbfgsb_dir(const Dev &dv, hipStream_t s);
 hipError_t prepare_lbfgsb(const Dev &dv);
 // the persistent per-seed ladder kernel for the built-in right-hand side (va_persist.h): launch == false opts the
-// instantiation in to its LDS on the current device, launch == true is a cooperative launch of B * ntiles workgroups
+// instantiation in to its LDS on the current device, launch == true launches B * ntiles workgroups, one per CU
 hipError_t seed_kernel_builtin(const Dev &dv, bool launch, hipStream_t s);
 // streaming column strips (va_eval5.hip)
 void launch_eval5(const Dev &dv, hipStream_t s);

@@ -3,7 +3,7 @@
 // BASELINE configs 1-2).  There the three-launch L-BFGS cycle (va_kernels.hip) is pure latency: each kernel costs a
 // dependent graph node (~1.6 us) plus 4-8 us of round trips for a few kilobytes of work.
 //
-// Here a seed is owned by G co-resident 1024-thread workgroups (cooperative launch), workgroup w keeping ITS slice of T
+// Here a seed is owned by G co-resident 1024-thread workgroups (one per CU), workgroup w keeping ITS slice of T
 // time rows of every vector of the minimisation ON CHIP for the whole ladder: x, g, the trial gradient, the direction
 // and all 2m history vectors live in LDS (C2: 29-32 workgroups, ~150 KB each) -- each with the slice's halo rows, which
 // every workgroup keeps up to date itself (all vector operations of L-BFGS are element-wise), so that the trial point
@@ -616,7 +616,12 @@ inline const void *seed_kernel_of(const void *const k[4], int disc)
 }
 
 // launch == false: opt the instantiation in to the LDS it needs on the current device (once per handle);
-// launch == true: cooperative launch of dv.dm.B * dv.dm.ntiles workgroups (all resident, or the launch fails)
+// launch == true: dv.dm.B * dv.dm.ntiles workgroups, one per CU (each takes more than half of a CU's LDS, and the host
+// never asks for more workgroups than the device has CUs).  A PLAIN launch: it has the residency of a cooperative one
+// (MI355X_MICROARCH.md, "Residency and cooperative launch"), costs 15-19 us less on the host, and -- measured in round 4 --
+// a process that made a cooperative launch under rocprofv3 --kernel-trace dies in the tool's exit handler.  Should the
+// workgroups not all be resident after all (another process holding CUs), the bounded polls end the launch with
+// abort_flag = 1 and the host falls back to the three-launch cycle.
 template <class RHS>
 inline hipError_t seed_kernel_op(const Dev &dv, bool launch, hipStream_t s)
 {
@@ -627,7 +632,7 @@ inline hipError_t seed_kernel_op(const Dev &dv, bool launch, hipStream_t s)
     const size_t lds = 8 * persist_lds_doubles(dv.dm.T, dv.dm.D, dv.dm.L, RHS::NP, dv.dm.NPest, dv.dm.m, HL, dv.dm.ntiles);
     if (!launch) return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     void *args[1] = {(void *)&dv};
-    return hipLaunchCooperativeKernel(k, dim3(dv.dm.B * dv.dm.ntiles), dim3(PZ_THREADS), args, (unsigned)lds, s);
+    return hipLaunchKernel(k, dim3(dv.dm.B * dv.dm.ntiles), dim3(PZ_THREADS), args, lds, s);
 }
 
 }  // namespace va
