@@ -72,7 +72,7 @@ def run(q, persist):
         r = pb.anneal(q["XP"].copy(), rf, OPTS, want_paths=True)
         dt = time.time() - t0
         cyc = pb.counters()["cycles"] - c0
-        if persist and os.environ.get("VARANNEAL_AMD_LIB", "").endswith("_pzst.so"):
+        if persist and "_pzs" in os.environ.get("VARANNEAL_AMD_LIB", ""):
             st = pb.debug_read_persist(14)
             names = ["trial", "tile phases", "wave sums", "publish+dots", "gather ev", "ls_step|gather dots", "dot sums+params", "coeffs", "update+direction", "-", "-", "-", "loop top"]
             n = max(st[13], 1.0)

@@ -102,10 +102,11 @@ struct Opts {
 
 // Everything the line-search / ladder step touches: <= 512 bytes so that one wave
 // can stage it in LDS with a single coalesced 8-byte load per lane (k_ls).
-struct SeedHot {
+// (the scalar part: what ls_step reads and writes besides the slot order -- the persistent ladder kernel runs the step on a
+// REGISTER copy of this part, va_persist.h; an array member would put the copy in scratch memory)
+struct SeedScal {
     int phase, beta_idx, iter, col, head, ifun, iback, ls_task;
     int upd, slot, dir, store_idx, nold, pad0;      // pad0: bounded problems -- bit 0 a pair waits to enter S'Y / S'S (k_lbfgsb_dir), bit 1 the oldest pair was evicted
-    int order[MAX_M];       // history slots, oldest -> newest (after the pending update)
     long long nfev;
     double f, fold, me, fe, theta, stp, gd, gdold, rf_scale, gn2, dr;
     double stp_upd;         // accepted step the update kernel applies (stp is the NEXT trial step)
@@ -113,6 +114,9 @@ struct SeedHot {
     double cg;
     double gd_dir;          // g.d of the direction in use (left by k_direction's last arriver)
     double stpmx;           // bounded problems: the largest step along d that stays inside the box
+};
+struct SeedHot : SeedScal {
+    int order[MAX_M];       // history slots, oldest -> newest (after the pending update)
 };
 static_assert(sizeof(SeedHot) <= 512 && sizeof(SeedHot) % 8 == 0, "SeedHot must fit one wave-wide 8-byte load");
 
@@ -618,7 +622,7 @@ struct SeedResults {
 
 // close the current beta step (va_ode.py:773-782): record, then move to the next RF
 // or finish.  `accepted`: the trial point becomes the stored minimiser.
-VA_HD_FLAT void finish_step(SeedHot &s, int status, bool accepted, const double *rf_ladder, int nbeta,
+VA_HD_FLAT void finish_step(SeedScal &s, int status, bool accepted, const double *rf_ladder, int nbeta,
                        const SeedResults &r, int *n_active_dec)
 {
     const int k = s.beta_idx;
@@ -633,7 +637,7 @@ VA_HD_FLAT void finish_step(SeedHot &s, int status, bool accepted, const double 
     }
 }
 
-VA_HD_FLAT void begin_linesearch(SeedHot &s)
+VA_HD_FLAT void begin_linesearch(SeedScal &s)
 {
     const double big = 1e10;
     s.ifun = 0; s.iback = 0; s.ls_task = LS_START;
@@ -641,11 +645,14 @@ VA_HD_FLAT void begin_linesearch(SeedHot &s)
     s.dir = 1;
 }
 
-VA_HD_FLAT void reset_memory(SeedHot &s) { s.col = 0; s.head = 0; s.theta = 1.0; s.nold = 0; s.pad0 = 0; }
+VA_HD_FLAT void reset_memory(SeedScal &s) { s.col = 0; s.head = 0; s.theta = 1.0; s.nold = 0; s.pad0 = 0; }
 
 // K2: consume one evaluation.  ev[] = eval partial sums INCLUDING the parameter tail
 // contributions; dirp[] = (g.d, d.d) of the direction in use.
-VA_HD_FLAT void ls_step(SeedHot &s, const double *ev, const double *dirp, const Opts &o,
+// (`ls`: the More'-Thuente state of the step -- s.ls itself, or a register copy of it that the caller writes back: the
+// persistent ladder kernel keeps the seed's state in LDS, where every field access of dcsrch / dcstep would be a dependent
+// round trip)
+VA_HD_FLAT void ls_step(SeedScal &s, LsState &ls, int *order, const double *ev, const double *dirp, const Opts &o,
                    const double *rf_ladder, int nbeta, const SeedResults &r, int *n_active_dec,
                    double cme, double cfe, bool bounded = false)
 {
@@ -670,7 +677,7 @@ VA_HD_FLAT void ls_step(SeedHot &s, const double *ev, const double *dirp, const 
         s.gdold = dirp[DP_GD]; s.fold = s.f;
         if (s.gdold >= 0.0) fail = true;
         else {
-            s.ls_task = dcsrch(s.f, s.gdold, s.stp, 1e-3, 0.9, 0.1, 0.0, stpmax, LS_START, s.ls);
+            s.ls_task = dcsrch(s.f, s.gdold, s.stp, 1e-3, 0.9, 0.1, 0.0, stpmax, LS_START, ls);
             if (s.ls_task == LS_ERROR) fail = true;
             else { s.ifun = 1; s.iback = 0; s.nfev += 1; }    // the evaluation we are consuming
         }
@@ -678,7 +685,7 @@ VA_HD_FLAT void ls_step(SeedHot &s, const double *ev, const double *dirp, const 
     double stp_eval = s.stp;
     if (!fail) {
         s.gd = ev[EP_GTD];
-        s.ls_task = dcsrch(ft, s.gd, s.stp, 1e-3, 0.9, 0.1, 0.0, stpmax, LS_FG, s.ls);
+        s.ls_task = dcsrch(ft, s.gd, s.stp, 1e-3, 0.9, 0.1, 0.0, stpmax, LS_FG, ls);
         if (s.ls_task == LS_FG) {
             s.ifun += 1; s.iback = s.ifun - 1;
             if (s.iback >= o.maxls) fail = true;
@@ -716,15 +723,22 @@ VA_HD_FLAT void ls_step(SeedHot &s, const double *ev, const double *dirp, const 
             // the oldest pair is evicted: order[] shifts left
             evicted = true;
             slot = s.head; s.head = (s.head + 1) % o.m;
-            for (int j = 0; j + 1 < s.col; ++j) s.order[j] = s.order[j + 1];
+            for (int j = 0; j + 1 < s.col; ++j) order[j] = order[j + 1];
             s.nold = s.col - 1;
         }
-        s.order[s.col - 1] = slot;
+        order[s.col - 1] = slot;
         s.slot = slot; s.dr = dr; s.upd |= UPD_HIST;
         // (bounded problems, k_lbfgsb_dir: a pair to enter S'Y / S'S; bit 1: the oldest pair was evicted)
         s.pad0 = 1 | (evicted ? 2 : 0);
     }
     begin_linesearch(s);
+}
+
+VA_HD_FLAT void ls_step(SeedHot &s, const double *ev, const double *dirp, const Opts &o,
+                   const double *rf_ladder, int nbeta, const SeedResults &r, int *n_active_dec,
+                   double cme, double cfe, bool bounded = false)
+{
+    ls_step(static_cast<SeedScal &>(s), s.ls, s.order, ev, dirp, o, rf_ladder, nbeta, r, n_active_dec, cme, cfe, bounded);
 }
 
 // K4: Gram update + L-BFGS direction in coefficient space (compact two-loop).

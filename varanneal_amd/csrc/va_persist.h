@@ -102,7 +102,10 @@ __device__ __forceinline__ bool pz_poll(__amdgpu_buffer_rsrc_t r, int granule, u
         const pz_v4u q = __builtin_amdgcn_raw_buffer_load_b128(r, granule * 16, 0, 16);
         if (q.y == tag && q.w == tag) { v = __hiloint2double((int)q.z, (int)q.x); return true; }
         asm volatile("" ::: "memory");                          // (the next load is a new load)
-        __builtin_amdgcn_s_sleep(1);
+#ifndef PZ_POLL_SLEEP
+#define PZ_POLL_SLEEP 1
+#endif
+        __builtin_amdgcn_s_sleep(PZ_POLL_SLEEP);
         if ((tries & 1023u) == 1023u) {
             if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
             if (tries > PZ_POLL_LIMIT) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
@@ -198,6 +201,20 @@ __device__ __forceinline__ void pz_coeffs(SeedHot &s, const double *up, int joff
     if (lane < col) { cYs[myslot] = gamma * pj; cSs[myslot] = -uj; }
     if (lane == 0) { s.cg = -gamma; s.theta = theta; }
     wave_sync_lds();
+}
+
+// rows 0 .. G-1 of one staged column, added in row order (EP_GMAX: the maximum); eight LDS loads in flight at a time
+__device__ __forceinline__ double pz_col_sum(const double *col, int G, int stride, bool is_max)
+{
+    double v = is_max ? 0.0 : 0.0;
+    for (int g0 = 0; g0 < G; g0 += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = g0 + u < G ? col[(g0 + u) * stride] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v = is_max ? fmax(v, t[u]) : v + t[u];
+    }
+    return v;
 }
 
 // job r of the 2 col0 + 3 inner-product jobs of a trial point: which vector meets g_t and y, and where the two sums go
@@ -352,12 +369,15 @@ __global__ __launch_bounds__(PZ_THREADS) void k_seed(const Dev dv)
         tile_g<RHS, DISC>(dm, ppl, c, acc, tid, NT);
         if (dv.pp.rf0_full) { double *t = c.qs; c.qs = c.fs; c.fs = t; }
         PZ_MARK(1);
-        // the workgroup's evaluation sums: wave totals
+        // the workgroup's evaluation sums: wave totals -- of the waves that held elements (thread t works on element t of the
+        // staged rows: the waves beyond them have nothing to add, and a wave reduction costs the same with or without data)
+        if (wave * 64 < RD) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const double v = (k == EP_GMAX) ? wave_max(acc.v[k]) : wave_sum(acc.v[k]);
-            if (lane == 0) red[wave * K + k] = v;
-        }
+            for (int k = 0; k < K; ++k) {
+                const double v = (k == EP_GMAX) ? wave_max(acc.v[k]) : wave_sum(acc.v[k]);
+                if (lane == 0) red[wave * K + k] = v;
+            }
+        } else if (lane < K) red[wave * K + lane] = 0.0;
         __syncthreads();                                  // (the slice's gradient rows are complete)
         PZ_MARK(2);
 
@@ -442,11 +462,7 @@ __global__ __launch_bounds__(PZ_THREADS) void k_seed(const Dev dv)
             if (!ok) *lds_ok = 0;
             __syncthreads();
             if (*lds_ok == 0) return;
-            if (tid < nev) {
-                double v = stg[tid];
-                for (int g = 1; g < G; ++g) v = (tid == EP_GMAX) ? fmax(v, stg[g * nev + tid]) : v + stg[g * nev + tid];
-                tot[tid < K ? tid : PZ_GDO] = v;
-            }
+            if (tid < nev) tot[tid < K ? tid : PZ_GDO] = pz_col_sum(stg + tid, G, nev, tid == EP_GMAX);
         } else {
             __syncthreads();
             if (tid < nev) tot[tid < K ? tid : PZ_GDO] = part[tid < K ? tid : PZ_GDO];
@@ -499,11 +515,8 @@ __global__ __launch_bounds__(PZ_THREADS) void k_seed(const Dev dv)
             // against g_t's and y's parameter entries, now that the tail has formed them)
             if (tid < KU) {
                 double v;
-                if (G > 1) {
-                    const double *stg2 = stg + nev * G;
-                    v = stg2[tid];
-                    for (int g = 1; g < G; ++g) v += stg2[g * KU + tid];
-                } else v = part[EP_N + tid];
+                if (G > 1) v = pz_col_sum(stg + nev * G + tid, G, KU, false);
+                else v = part[EP_N + tid];
                 tot[EP_N + tid] = v;
             }
             __syncthreads();
@@ -558,10 +571,19 @@ __global__ __launch_bounds__(PZ_THREADS) void k_seed(const Dev dv)
                 if (upd & UPD_G) { gn = tv; Gv[e] = tv; }
                 if (dir) {
                     double a = cg * gn;
-                    for (int j = 0; j < col; ++j) {
-                        const int sj = hot->order[j];
-                        a += cYs[sj] * Y[(size_t)sj * nvh + e];
-                        a += cSs[sj] * S[(size_t)sj * nvh + e];
+                    // (five pairs at a time: their slots and coefficients first, then the ten vector entries -- two levels of LDS
+                    // latency per batch instead of two per pair)
+                    for (int j0 = 0; j0 < col; j0 += 5) {
+                        int off[5]; double cy[5], cs[5], yv[5], sv[5];
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) {
+                            const int sj = hot->order[j0 + u < col ? j0 + u : 0];
+                            off[u] = sj * nvh + e; cy[u] = j0 + u < col ? cYs[sj] : 0.0; cs[u] = j0 + u < col ? cSs[sj] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) { yv[u] = Y[off[u]]; sv[u] = S[off[u]]; }
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) { a += cy[u] * yv[u]; a += cs[u] * sv[u]; }
                     }
                     Dd[e] = a;
                     if ((e >= own0 && e < own0 + ne) || (e >= RD && count_p)) gd += gn * a;
