@@ -647,3 +647,32 @@ def test_piecewise_model_on_device(D, N, disc):
         assert abs(A[0] - A0) <= 1e-12 * abs(A0), (ek, A[0], A0)
         assert np.abs(g[0] - g0).max() <= 1e-10 * np.abs(g0).max(), ek
     print("piecewise model D=%d N=%d %s ran eval kernels %s" % (D, N, disc, sorted(kernels)))
+
+
+def test_bounded_step_one_lands_exactly_on_the_bound():
+    """L-BFGS-B's `if (stp == 1) x = z`: with a bound far from the start point relative to its own size,
+    x + (z - x) would land a few ulp inside it; the device takes z itself at step 1, so a variable the Cauchy point puts on a
+    bound SITS on it, bit for bit, and the iteration counts follow the oracle's restatement of L-BFGS-B"""
+    from varanneal_amd import twin
+    D, N, B = 20, 200, 2
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    XP = np.empty((B, N * D + 1)); P = np.empty((B, 1))
+    for b in range(B):
+        X0, P0 = twin.initial_guess(N, D, b, Y, Lidx)
+        XP[b, :-1] = X0.ravel(); XP[b, -1] = P0[0]; P[b] = P0
+    # tiny upper bounds on a third of the states (|u| << |x0 - u|), a binding box on the parameter
+    bnds = [(-15.0, 1e-3 * (1 + (i % 7))) if i % 3 == 0 else (-15.0, 15.0) for i in range(N * D)] + [(6.5, 7.0)]
+    lo = np.array([q[0] for q in bnds]); hi = np.array([q[1] for q in bnds])
+    o = {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 400, 'maxiter': 25}
+    with _capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc="trapezoid", bounds=bnds) as pb:
+        r = pb.minimize_lbfgs(XP, 50.0, o)
+    for b in range(B):
+        x = r["x"][b]
+        assert np.all(x >= lo) and np.all(x <= hi)
+        on_hi = np.isclose(x, hi, rtol=0, atol=1e-9 * np.maximum(1.0, np.abs(hi)))
+        assert on_hi.sum() > 100 and np.array_equal(x[on_hi], hi[on_hi])      # exactly on the bound, not a few ulp inside
+        opb = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[b], [0], disc="trapezoid")
+        xo, Ao, sto, nito, nfevo = opb.minimize_lbfgs(XP[b], 50.0, o, bounds=bnds, exact=True)
+        assert (r["nit"][b], r["nfev"][b], r["status"][b]) == (nito, nfevo, sto)
+        assert np.array_equal(x == hi, xo == hi) and np.array_equal(x == lo, xo == lo)      # the same variables on their bounds
+        assert abs(r["A"][b] - Ao) <= 1e-8 * abs(Ao)

@@ -172,6 +172,7 @@ struct TileCtx {
     double stp, c;               // c = 2 * rf0_scale * cfe   (rf0 weight applied per element)
     double *xs, *fs, *qs;        // staged rows [R*D] (LDS); fs is re-used for s
     const double *xg, *dg;       // this seed's x (and d) in global memory
+    const double *zg = nullptr;  // bounded problems: this seed's z (d = z - x), the trial point at step 1
     double *gtg;                 // this seed's gradient output
     long goff = 0;               // gtg / dg are indexed by (path index - goff): 0 for the seed's global vectors, the slice's
                                  // first element when they are a workgroup's LDS-resident slice (va_persist.h)
@@ -192,6 +193,14 @@ typedef ThreadAccT<EP_N> ThreadAcc;
 VA_HD double trial(double x, double stp, double d) { return fma(stp, d, x); }
 // ... and inside the box to the last bit when there is one (stp <= stpmx keeps it there up to rounding)
 VA_HD double clampb(double v, const ProblemPtrs &pp, long i) { return pp.lo ? fmin(fmax(v, pp.lo[i]), pp.hi[i]) : v; }
+// The trial point of a bounded problem.  At step 1 it is z ITSELF -- L-BFGS-B's `if (stp == one) x = z` (lnsrlb) -- not
+// x + (z - x): with |u - x| much larger than |u| the sum lands a few ulp inside the bound, the variable then no longer
+// counts as sitting on it, and the next Cauchy step treats it as free.  z: the seed's Cauchy / subspace point (Dev::lb_z), or
+// NULL where there are no bounds.
+VA_HD double trial_b(double x, double stp, double d, const double *z, const ProblemPtrs &pp, long i)
+{
+    return (z && stp == 1.0) ? z[i] : clampb(trial(x, stp, d), pp, i);
+}
 // L-BFGS-B's projected gradient (projgr): what the convergence test looks at when there are bounds
 VA_HD double proj_grad(double x, double g, double l, double u) { return g < 0.0 ? fmax(x - u, g) : fmin(x - l, g); }
 
@@ -202,7 +211,7 @@ VA_HD void tile_params(const Dims &dm, const ProblemPtrs &pp, int b, TileCtx &c)
     for (int k = 0; k < RHS::NP; ++k) c.p[k] = pp.Pfull[(size_t)b * dm.NP + k];
     for (int k = 0; k < dm.NPest; ++k) {
         double v = c.xg[dm.ND + k];
-        if (c.use_d) v = clampb(trial(v, c.stp, c.dg[dm.ND + k]), pp, dm.ND + k);
+        if (c.use_d) v = trial_b(v, c.stp, c.dg[dm.ND + k], c.zg, pp, dm.ND + k);
         const int dst = pp.Pidx[k];
         // select chain instead of c.p[dst]: a runtime-indexed array would live in scratch
 #pragma unroll
@@ -222,7 +231,7 @@ VA_HD void tile_load(const Dims &dm, const ProblemPtrs &pp, TileCtx &c, int tid,
         double v = 0.0;
         if (gi >= 0 && gi < NDx) {
             v = c.xg[gi];
-            if (c.use_d) v = clampb(trial(v, c.stp, c.dg[gi]), pp, gi);
+            if (c.use_d) v = trial_b(v, c.stp, c.dg[gi], c.zg, pp, gi);
         }
         c.xs[e] = v;
     }
@@ -245,7 +254,7 @@ VA_HD void tile_load_p(const Dims &dm, const ProblemPtrs &pp, int b, TileCtx &c,
             if (est >= 0) {
                 const long gi = NDx + (long)row * dm.NPe + est;
                 v = c.xg[gi];
-                if (c.use_d) v = clampb(trial(v, c.stp, c.dg[gi]), pp, gi);
+                if (c.use_d) v = trial_b(v, c.stp, c.dg[gi], c.zg, pp, gi);
             } else v = pp.Pfull[((size_t)b * dm.N + row) * NPt + k];
         }
         c.ps[e] = v;

@@ -144,7 +144,7 @@ __device__ __forceinline__ void eval_tail(const Dev &dv, int b, int use_d, doubl
         double pg = g;
         if (dv.pp.lo) {        // bounded: the convergence test looks at the projected gradient
             double xv = as_const(x)[dm.ND + k];
-            if (use_d) xv = clampb(trial(xv, stp, as_const(d)[dm.ND + k]), dv.pp, dm.ND + k);
+            if (use_d) xv = trial_b(xv, stp, as_const(d)[dm.ND + k], dv.lb_z ? dv.lb_z + (size_t)b * dm.ld : nullptr, dv.pp, dm.ND + k);
             pg = proj_grad(xv, g, dv.pp.lo[dm.ND + k], dv.pp.hi[dm.ND + k]);
         }
         ev[EP_GMAX] = fmax(ev[EP_GMAX], fabs(pg));

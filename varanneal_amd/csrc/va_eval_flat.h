@@ -171,6 +171,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_eval(const Dev dv)
     c.ps = red + (EVAL_THREADS / 64) * KR;       // [R * NPt], time-dependent parameters only
     c.xg = dv.x + (size_t)b * dm.ld; c.dg = dv.d + (size_t)b * dm.ld;
     c.gtg = dv.gt + (size_t)b * dm.ld;
+    c.zg = dv.lb_z ? dv.lb_z + (size_t)b * dm.ld : nullptr;
     c.tmodel = dv.pp.tmodel; c.stim = dv.pp.stim; c.nstim = dv.pp.nstim;
     if (!dm.tdp) tile_params<RHS>(dm, dv.pp, b, c);
 

@@ -408,7 +408,8 @@ __global__ __launch_bounds__(VEC_THREADS) void k_update(const Dev dv)
         gtv[e] = tv;
         if (upd & UPD_X) {
             // (the same expression as the evaluated trial point, clamp into the box included)
-            xv.x = clampb(trial(xv.x, stp, dv2.x), dv.pp, i); xv.y = clampb(trial(xv.y, stp, dv2.y), dv.pp, i + 1);
+            const double *zb = dv.lb_z ? dv.lb_z + vo : nullptr;            // (bounded: step 1 lands on z itself, as the evaluation did)
+            xv.x = trial_b(xv.x, stp, dv2.x, zb, dv.pp, i); xv.y = trial_b(xv.y, stp, dv2.y, zb, dv.pp, i + 1);
             *reinterpret_cast<double2 *>(x + i) = xv;
         }
         if (upd & UPD_STORE) {
