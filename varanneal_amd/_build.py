@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvaranneal_amd.so")
 SOURCES = ["va_capi.hip", "va_kernels.hip", "va_eval5.hip", "va_lbfgsb.hip", "va_nnet.hip"]
-HEADERS = ["va_core.h", "va_tile2.h", "va_tile3.h", "va_tile4.h", "va_tile5.h", "va_eval3.h", "va_eval4.h", "va_eval5.h", "va_eval_flat.h", "va_epilogue.h", "va_persist.h", "va_measure.h", "va_device.h", "va_nnet.h", "va_nnet_kernels.h", os.path.join("..", "..", "include", "varanneal_amd.h")]
+HEADERS = ["va_core.h", "va_tile2.h", "va_tile3.h", "va_tile4.h", "va_tile5.h", "va_eval3.h", "va_eval4.h", "va_eval5.h", "va_eval_flat.h", "va_epilogue.h", "va_persist.h", "va_persist_geo.h", "va_measure.h", "va_device.h", "va_nnet.h", "va_nnet_kernels.h", os.path.join("..", "..", "include", "varanneal_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-sched-strategy=iterative-maxocc: measured on the whole library against the default scheduler
 # (profiles/r02_ab_experiments.txt): C3 evaluation 9.67 -> 9.18 us, 4096 seeds 362 -> 353 us, everything else equal

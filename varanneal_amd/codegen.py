@@ -701,7 +701,7 @@ BUILD_TAG = "sched=iterative-maxocc"      # part of every module's cache key: a 
 def _core_fingerprint():
     h = hashlib.sha1(BUILD_TAG.encode())
     for fn in ("va_core.h", "va_device.h", "va_eval_flat.h", "va_eval3.h", "va_eval4.h", "va_epilogue.h", "va_tile2.h", "va_tile3.h",
-               "va_tile4.h", "va_tile5.h", "va_eval5.h", "va_persist.h", "va_measure.h", "va_user_rhs.hip"):
+               "va_tile4.h", "va_tile5.h", "va_eval5.h", "va_persist.h", "va_persist_geo.h", "va_measure.h", "va_user_rhs.hip"):
         with open(os.path.join(CSRC, fn), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
