@@ -1061,7 +1061,16 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
     nn.act = d->activation; nn.Lin = d->L_in; nn.Lout = d->L_out; nn.rm_in = d->rm_in; nn.rm_out = d->rm_out;
     // job tables: one entry per 32x32 output tile
     std::vector<NnetTile> t1, t2, t3;
+    // examples per chunk of the weight-gradient product: 256, doubled while the launch keeps >= 6 workgroups per CU
+    // (each chunk writes a partial of the whole parameter gradient that k_nnet_pred reads back)
     nn.mch = d->M <= 256 ? ((d->M + NN_KC - 1) / NN_KC) * NN_KC : 256;
+    {
+        long long tiles = 0;
+        int ncu = 256;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess) ncu = 256;
+        for (int n = 0; n < NL - 1; ++n) tiles += (long long)((s[n + 1] + NN_TILE - 1) / NN_TILE) * ((s[n] + NN_TILE - 1) / NN_TILE);
+        while (nn.mch * 2 <= d->M && tiles * d->batch * ((d->M + 2 * nn.mch - 1) / (2 * nn.mch)) >= 6LL * ncu) nn.mch *= 2;
+    }
     nn.nmch = (d->M + nn.mch - 1) / nn.mch;
     auto tile = [&](int n, int r0, int c0, int c) {
         NnetTile t;
