@@ -1135,16 +1135,24 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
     if (nn.small) nn.nraw = NL;
     // layers up to NN_FB_W wide with scalar measurement weights: forward and state-gradient products in one kernel
     // (k_nnet_fb); its workgroups write the first nfb of the n1 + n2 rows, k_nnet_wfrag zeroes the others
-    std::vector<int> wfoff(NL - 1, 0);
+    std::vector<int> wfoff(2 * (NL - 1), 0);
     bool fb_ok = false;
     {
         int widest = 0, wfsz = 0;
         for (int n = 0; n < NL; ++n) widest = s[n] > widest ? s[n] : widest;
-        for (int n = 0; n < NL - 1; ++n) { wfoff[n] = wfsz; wfsz += ((s[n + 1] + 15) / 16) * ((s[n] + 3) / 4) * 64; }
+        // fragment tables of the two products of every transition: NN_FB_W / 16 column blocks of nn_fb_steps(K) k-steps
+        for (int n = 0; n < NL - 1; ++n) { wfoff[n] = wfsz; wfsz += (NN_FB_W / 16) * nn_fb_steps(s[n]) * 64; }
+        for (int n = 0; n < NL - 1; ++n) { wfoff[NL - 1 + n] = wfsz; wfsz += (NN_FB_W / 16) * nn_fb_steps(s[n + 1]) * 64; }
         nn.nfb = (d->M + NN_FB_R - 1) / NN_FB_R;
         nn.wfsz = wfsz;
-        fb_ok = !nn.small && widest <= NN_FB_W && !d->rm_in_matrix && nn.nfb <= nn.n1 + nn.n2;
+        fb_ok = !nn.small && widest <= NN_FB_W && NL <= NN_FB_LAYERS && !d->rm_in_matrix && nn.nfb <= nn.n1 + nn.n2 &&
+                (long long)NDnet * d->M < (1LL << 31);
         nn.fused = 0;                  // (available through va_problem_tune; slower than the two kernels as measured)
+        {
+            int ncu = 256;
+            if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess) ncu = 256;
+            nn.fb_slots = ncu * NN_FB_WGS; nn.fb_stagger = 0;
+        }
     }
     const bool fold_rows = nn.nraw > NN_ROWS_DIRECT;      // k_ls sums the rows with one wave: keep them few
     dm.nprow = fold_rows ? NN_RED_ROWS : nn.nraw;
@@ -1169,7 +1177,9 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
     int *wfoff_d = nullptr;
     if (fb_ok) {
         TRY(h->alloc(&nn.Wf, B * (size_t)nn.wfsz));
-        TRY(h->alloc(&wfoff_d, NL - 1));
+        TRY(h->alloc(&wfoff_d, 2 * (NL - 1)));
+        TRY(h->alloc(&dv.pz.stamps, (size_t)PZ_NSTAMP));       // (measurement builds of k_nnet_fb: va_measure.h)
+        TRY(h->alloc(&nn.fb_cu, (size_t)16));
     }
     TRY(h->alloc(&t1_d, t1.size())); TRY(h->alloc(&t2_d, t2.size())); TRY(h->alloc(&t3_d, t3.size()));
     TRY(alloc_solver_state(h, max_beta, d->keep_paths));
@@ -1179,7 +1189,7 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
     if (d->L_in) H2D(din_d, d->data_in, (size_t)d->M * d->L_in, double);
     if (d->L_out) H2D(dout_d, d->data_out, (size_t)d->M * d->L_out, double);
     H2D(P_d, d->P, B * d->NP, double);
-    if (fb_ok) { H2D(wfoff_d, wfoff.data(), NL - 1, int); nn.wfoff = wfoff_d; }
+    if (fb_ok) { H2D(wfoff_d, wfoff.data(), 2 * (NL - 1), int); nn.wfoff = wfoff_d; }
     H2D(t1_d, t1.data(), t1.size(), NnetTile); H2D(t2_d, t2.data(), t2.size(), NnetTile);
     if (!t3.empty()) H2D(t3_d, t3.data(), t3.size(), NnetTile);
     nn.s = s_d; nn.off = off_d; nn.woff = woff_d; nn.boff = boff_d; nn.lmap_in = lin_d; nn.lmap_out = lout_d;
@@ -1425,7 +1435,9 @@ int va_problem_tune(va_handle h, int32_t what, int32_t value)
     case VA_TUNE_GRAPH: h->tune_graph = value != 0; break;
     case VA_TUNE_NNET_FUSED:
         if (!h->is_nnet || !h->nn.Wf) return fail(VA_ESTATE, "not a network handle whose layers fit the fused kernel");
-        h->nn.fused = value != 0 ? 1 : 0; break;
+        // value 1: fused; value 2 + t: fused, the second workgroup of each CU starting t microseconds late
+        h->nn.fused = value != 0 ? 1 : 0;
+        h->nn.fb_stagger = value >= 2 ? (value - 2) * 100 : h->nn.fb_stagger; break;
     case VA_TUNE_PERSIST: h->tune_persist = value != 0; break;
     case VA_TUNE_PERSIST_ROWS: {
         if (!h->persist) return fail(VA_ESTATE, "the handle does not run the persistent kernel");

@@ -37,3 +37,18 @@
 #define PZ_MARK(i) do { } while (0)
 #define PZ_MARK_FLUSH(stamps, cyc) do { } while (0)
 #endif
+
+// VA_FB_STAMPS   k_nnet_fb: thread 0 of one workgroup (block 1 of seed 0) sums the 100 MHz ticks of its phases over the
+//                layers -- 0 input image, 1 first product, 2 its barrier, 3 epilogue A, 4 its barrier, 5 second product,
+//                6 epilogue B, 7 the whole kernel -- into dv.pz.stamps (read back with va_debug_read_persist)
+#ifdef VA_FB_STAMPS
+#define FB_MARK_SETUP() long long fb_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fb_prev = wall_clock64(); const long long fb_w0 = fb_prev
+#define FB_MARK(i) do { if (tid == 0) { const long long t_ = wall_clock64(); fb_acc[i] += t_ - fb_prev; fb_prev = t_; } } while (0)
+#define FB_MARK_FLUSH(stamps) do { if (blockIdx.x == 1 && blockIdx.y == 0 && tid == 0 && (stamps)) {           \
+        fb_acc[7] = wall_clock64() - fb_w0;                                                                    \
+        for (int i_ = 0; i_ < 8; ++i_) (stamps)[i_] = (double)fb_acc[i_]; } } while (0)
+#else
+#define FB_MARK_SETUP() do { } while (0)
+#define FB_MARK(i) do { } while (0)
+#define FB_MARK_FLUSH(stamps) do { } while (0)
+#endif

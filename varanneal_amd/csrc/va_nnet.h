@@ -19,9 +19,19 @@ constexpr int NN_PACK = 8;       // elements per thread of the trial-point kerne
 // layers up to NN_FB_W wide: the forward product and the state-gradient product of every transition in ONE kernel
 // (k_nnet_fb, va_nnet_kernels.h): a workgroup marches a block of NN_FB_R examples through the layers
 #ifndef NN_FB_ROWS
-#define NN_FB_ROWS 64
+#define NN_FB_ROWS 32
 #endif
-constexpr int NN_FB_R = NN_FB_ROWS, NN_FB_W = 128, NN_FB_THREADS = 512, NN_FB_PITCH = NN_FB_W + 2;
+#ifndef NN_FB_THR
+#define NN_FB_THR 256
+#endif
+// NN_FB_THREADS / 64 waves share the NN_FB_W / 16 column blocks of a layer; NN_FB_WGS workgroups per CU (their LDS: two
+// operand images of NN_FB_R rows)
+constexpr int NN_FB_R = NN_FB_ROWS, NN_FB_W = 128, NN_FB_THREADS = NN_FB_THR, NN_FB_PITCH = NN_FB_W + 2;
+constexpr int NN_FB_WGS = NN_FB_R == 32 ? 2 : 1;
+constexpr int NN_FB_LAYERS = 64; // most layers its per-layer table in LDS holds
+constexpr int NN_FB_PF = 8;      // k-steps the B fragments of its products are requested ahead
+// k-steps a fragment table holds per column block for a product over K: whole groups of NN_FB_PF, one group of zeros behind
+constexpr int nn_fb_steps(int K) { return (((K + 3) / 4 + NN_FB_PF - 1) / NN_FB_PF) * NN_FB_PF + NN_FB_PF; }
 
 constexpr int NN_SMALL = 32;         // widest layer / most examples the single-kernel path handles
 constexpr int NN_ROWS_DIRECT = 64;   // partial rows per seed the line-search kernel reduces itself
@@ -56,9 +66,11 @@ struct NnetDev {
     double *raw;                   // NULL (rows go straight to Dev::evp) or [B][nraw][EP_GP]
     int fused;                     // 1: k_nnet_fb in place of k_nnet_fwd + k_nnet_bwd_x (every layer <= NN_FB_W wide, scalar RM); off unless
                                    // asked for (va_problem_tune): measured SLOWER than the two kernels at c5x (profiles/r04_nnet_fused.txt)
+    int fb_stagger, fb_slots;      // ticks of the 100 MHz clock over which the first fb_slots workgroups of k_nnet_fb spread their starts (0: none)
+    int *fb_cu;                    // [0] workgroups of k_nnet_fb arrived in this launch (zeroed by k_nnet_wfrag)
     int nfb;                       // its workgroups per seed: blocks of NN_FB_R examples
     double *Wf;                    // [B][wfsz] the weights in MFMA B-fragment order (k_nnet_wfrag, per evaluation)
-    const int *wfoff;              // [NL-1] offset of layer n's fragments in Wf
+    const int *wfoff;              // [2 (NL-1)] offset in Wf of transition n's fragments for the first product, [NL-1 + n] for the second
     int wfsz;
 };
 

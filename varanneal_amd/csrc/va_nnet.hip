@@ -1,4 +1,6 @@
 // va_nnet.hip -- launch sequence of the feed-forward-network action (kernels: va_nnet_kernels.h).
+#include <algorithm>
+
 #include "va_nnet_kernels.h"
 
 namespace va {
@@ -29,7 +31,7 @@ void launch_nnet_eval(const Dev &dv, const NnetDev &nn, hipStream_t s, NnetActLa
     if (nn.small) { launch_act(dv, nn, s, 1, user); return; }
     hipLaunchKernelGGL(k_nnet_pack, dim3(nn.n0, B), blk, 0, s, dv, nn);
     if (nn.fused) {
-        hipLaunchKernelGGL(k_nnet_wfrag, dim3(32, B), blk, 0, s, dv, nn);
+        hipLaunchKernelGGL(k_nnet_wfrag, dim3(std::min(nn.wfsz / NN_THREADS, 256), B), blk, 0, s, dv, nn);
         launch_act(dv, nn, s, 2, user);
     } else {
         launch_act(dv, nn, s, 0, user);

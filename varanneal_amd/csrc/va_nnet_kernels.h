@@ -29,6 +29,7 @@
 #pragma once
 #include "va_nnet.h"
 #include "va_eval_flat.h"
+#include "va_measure.h"
 
 namespace va {
 
@@ -217,23 +218,37 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_pack(const Dev dv, const Nn
     }
 }
 
-// the weights in the fragment order k_nnet_fb's first product reads them: for layer n, column block cb, k-step kk, lane l
-//     Wf[wfoff[n] + (cb * nk + kk) * 64 + l] = W_n[16 cb + (l & 15)][4 kk + (l >> 4)]   (zero outside the matrix)
+// the weights in the fragment order k_nnet_fb's products read them: for transition n, column block cb, k-step kk, lane l
+//     first product  Z = X_n W_n^T:   Wf[wfoff[n]        + (cb * nkp + kk) * 64 + l] = W_n[16 cb + (l & 15)][4 kk + (l >> 4)]
+//     second product G = delta W_n:   Wf[wfoff[NL-1 + n] + (cb * nkp + kk) * 64 + l] = W_n[4 kk + (l >> 4)][16 cb + (l & 15)]
+// (nkp = nn_fb_steps(K) k-steps per column block, zeros outside the matrix: the products run without a bounds test)
 // and the partial rows no workgroup of the fused evaluation writes (those of the separate kernels) zeroed
 __global__ __launch_bounds__(NN_THREADS) void k_nnet_wfrag(const Dev dv, const NnetDev nn)
 {
-    const int b = blockIdx.y;
+    __shared__ int toff[2 * NN_FB_LAYERS], ls[NN_FB_LAYERS], lw[NN_FB_LAYERS];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (blockIdx.x == 0 && b == 0 && tid == 0) nn.fb_cu[0] = 0;          // arrivals at the fused kernel (its stagger)
     int use_d; double stp, rf;
     if (!seed_live(dv, b, use_d, stp, rf)) return;
     const double *Pw = nn.Pw + (size_t)b * nn.NP;
     double *Wf = nn.Wf + (size_t)b * nn.wfsz;
-    for (int e = blockIdx.x * NN_THREADS + threadIdx.x; e < nn.wfsz; e += gridDim.x * NN_THREADS) {
-        int n = 0;
-        while (n + 1 < nn.NL - 1 && e >= nn.wfoff[n + 1]) ++n;
-        const int sn = nn.s[n], sn1 = nn.s[n + 1], nk = (sn + 3) >> 2;
-        const int f = e - nn.wfoff[n], l = f & 63, blk = f >> 6, cb = blk / nk, kk = blk - cb * nk;
+    const int NT = nn.NL - 1;
+    for (int i = tid; i < 2 * NT; i += NN_THREADS) toff[i] = nn.wfoff[i];
+    for (int i = tid; i < nn.NL; i += NN_THREADS) { ls[i] = nn.s[i]; lw[i] = i < NT ? nn.woff[i] : 0; }
+    __syncthreads();
+    // a run of NN_THREADS consecutive entries lies in one table (the tables are multiples of 4096 entries long)
+    for (int e0 = blockIdx.x * NN_THREADS; e0 < nn.wfsz; e0 += gridDim.x * NN_THREADS) {
+        int t = 0;
+        while (t + 1 < 2 * NT && e0 >= toff[t + 1]) ++t;
+        const bool second = t >= NT;
+        const int n = second ? t - NT : t;
+        const int sn = ls[n], sn1 = ls[n + 1], nkp = nn_fb_steps(second ? sn1 : sn);
+        const int f = e0 + tid - toff[t], l = f & 63, blk = f >> 6, cb = blk / nkp, kk = blk - cb * nkp;
         const int c = cb * 16 + (l & 15), k = 4 * kk + (l >> 4);
-        Wf[e] = (c < sn1 && k < sn) ? Pw[nn.woff[n] + (size_t)c * sn + k] : 0.0;
+        double w = 0.0;
+        if (!second) { if (c < sn1 && k < sn) w = Pw[lw[n] + (size_t)c * sn + k]; }
+        else if (c < sn && k < sn1) w = Pw[lw[n] + (size_t)k * sn + c];
+        Wf[e0 + tid] = w;
     }
     if (blockIdx.x == 0)
         for (int r = nn.nfb + threadIdx.x; r < nn.n1 + nn.n2; r += NN_THREADS) put_row(dv, nn, b, r, 0.0, 0.0, 0.0, 0.0, 0.0);
@@ -303,6 +318,15 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const Nne
     if (tid == 0) put_row(dv, nn, b, blockIdx.x, 0.0, v[1], 0.0, 0.0, 0.0);
 }
 
+// one B fragment of k_nnet_fb's products (a buffer load: as an intrinsic call it stays where the source puts it --
+// plain loads carried around the k loop are sunk through the loop's phi nodes by the compiler, i.e. issued where their
+// values are used, and the products then wait out an L2 round trip per group of k-steps)
+typedef unsigned fb_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double fb_frag(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+}
+
 // ------------------------------------------------------------------ K1 + K2 in one: forward and state-gradient products
 // Layers up to NN_FB_W = 128 wide (c5x: 8 x 128, M = 2048).  As separate kernels the two products move every delta and
 // every q through HBM twice and re-read the states (profiles/r03_nnet_c5x_ablation.txt: 78-83 % of each kernel is
@@ -321,159 +345,293 @@ __global__ __launch_bounds__(NN_THREADS) void k_nnet_fwd(const Dev dv, const Nne
 // lockstep on every CU instead of overlapping; without any operand fetch in the K loops it still takes 510 us (matrix
 // floor: 191 us).  Off unless asked for (va_problem_tune nnet_fused=1); the next step is named in DESIGN.md 8.
 template <class ACT>
-__global__ __launch_bounds__(NN_FB_THREADS, NN_FB_R == 32 ? 4 : 2) void k_nnet_fb(const Dev dv, const NnetDev nn)
+__global__ __launch_bounds__(NN_FB_THREADS, NN_FB_WGS) void k_nnet_fb(const Dev dv, const NnetDev nn)
 {
     extern __shared__ __attribute__((aligned(16))) double fbs[];
-    constexpr int R = NN_FB_R, RB = NN_FB_R / 16, PX = NN_FB_PITCH, NW = NN_FB_THREADS / 64;
-    double *Xs = fbs, *DL = Xs + R * PX, *red = DL + R * PX;          // red: [NW * 5]
+    constexpr int R = NN_FB_R, RB = NN_FB_R / 16, PX = NN_FB_PITCH, NW = NN_FB_THREADS / 64, CW = NN_FB_W / 16 / NW;
+    double *Xs = fbs, *DL = Xs + R * PX, *red = DL + R * PX;          // red: [NW * 5 + 8]
+    // per-layer numbers (s, off, woff, boff, the two fragment-table offsets), read once: fetched where they are used,
+    // each costs the wave a round trip to L2 per layer before the loads that depend on it can even be requested
+    int *meta = reinterpret_cast<int *>(red + NW * 5 + 8);            // [6][NN_FB_LAYERS]
     const int b = blockIdx.y, tid = threadIdx.x;
     int use_d; double stp, rf;
     if (!seed_live(dv, b, use_d, stp, rf)) return;
     const int m0 = blockIdx.x * R;
     const int nra = min(R, nn.M - m0);
-    const int lane = tid & 63, cb = __builtin_amdgcn_readfirstlane(tid >> 6), lo = lane & 15, hi = lane >> 4;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lo = lane & 15, hi = lane >> 4;
+    const int cb0 = wave * CW;                                            // the wave's first block of 16 columns (of every layer)
     const size_t vo = (size_t)b * dv.dm.ld;
     const double *Xg = (use_d ? nn.Xw : dv.x) + vo;                      // the trial point's states
     const double *Pw = nn.Pw + (size_t)b * nn.NP;
+    const double *dg = dv.d + vo;
+    double *gtg = dv.gt + vo, *dlg = nn.delta + vo;
     const double cq = 2.0 * rf * dv.dm.cfe;
     const int NL = nn.NL;
+    // the seed's fragment tables (k_nnet_wfrag)
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)(nn.Wf + (size_t)b * nn.wfsz), 0, nn.wfsz * 8, 0x00020000);
+    if (nn.fb_stagger > 0) {
+        // Left alone, every workgroup of the launch walks through the layers in step with every other: all of them store a
+        // layer's gradients (or fetch the next layer's states) in the same few microseconds -- bursts at the HBM's full
+        // rate with the matrix cores idle, then matrix phases with the memory idle.  The workgroups that start the launch
+        // are put out of step: the i-th to arrive waits (i / 8 mod 8) eighths of fb_stagger (about one layer's period)
+        // -- consecutive workgroups go to different XCDs, so every XCD gets every phase.
+        if (tid == 0) {
+            const int i = atomicAdd(nn.fb_cu, 1);
+            if (i < nn.fb_slots) {
+                const unsigned long long wait = (unsigned long long)nn.fb_stagger * ((i >> 3) & 7) / 8, t0 = wall_clock64();
+                while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+            }
+        }
+        __syncthreads();
+    }
+    FB_MARK_SETUP();
+    if (tid < NL) {
+        meta[tid] = nn.s[tid]; meta[NN_FB_LAYERS + tid] = nn.off[tid];
+        if (tid < NL - 1) {
+            meta[2 * NN_FB_LAYERS + tid] = nn.woff[tid]; meta[3 * NN_FB_LAYERS + tid] = nn.boff[tid];
+            meta[4 * NN_FB_LAYERS + tid] = nn.wfoff[tid]; meta[5 * NN_FB_LAYERS + tid] = nn.wfoff[NL - 1 + tid];
+        }
+    }
     {   // the block's input-layer states; rows / columns that do not exist are zeros (they pad K)
         const int s0 = nn.s[0];
-        for (int e = tid; e < R * NN_FB_W; e += NN_FB_THREADS) {
-            const int r = e >> 7, c = e & (NN_FB_W - 1);
-            Xs[r * PX + c] = (r < nra && c < s0) ? Xg[(size_t)(m0 + r) * nn.NDnet + c] : 0.0;
+        constexpr int NE = R * NN_FB_W / NN_FB_THREADS;
+        double xin[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + i * NN_FB_THREADS, r = e >> 7, c = e & (NN_FB_W - 1);
+            xin[i] = (r < nra && c < s0) ? Xg[(size_t)(m0 + r) * nn.NDnet + c] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + i * NN_FB_THREADS, r = e >> 7, c = e & (NN_FB_W - 1);
+            Xs[r * PX + c] = xin[i];
         }
     }
     __syncthreads();
-    d4 qprev[RB];
+    FB_MARK(0);
+    // x_{n+1} of the lane's elements (epilogue A of transition n needs them) is requested a phase early -- before the
+    // first transition here, after the second product of transition n - 1 later -- and lands under epilogue B and the
+    // first product: asked for where it is used, every element waits out an HBM round trip (its own load's and the
+    // previous element's store's)
+    d4 xn[CW][RB];
+    auto request_x = [&](int n1) {                                        // n1: the layer whose states are fetched
+        const int s1 = meta[n1], o1 = meta[NN_FB_LAYERS + n1];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) qprev[rb] = d4{0.0, 0.0, 0.0, 0.0};
-    double v_me = 0.0, v_fe = 0.0, v_gtd = 0.0, v_gn2 = 0.0, v_gmax = 0.0;
-    const int col = cb * 16 + lo;                                         // the lane's column of every layer
-    for (int n = 0; n <= NL - 1; ++n) {
-        const int sn = nn.s[n], offn = nn.off[n];
-        const bool last = n == NL - 1;
-        const int sn1 = last ? 0 : nn.s[n + 1], offn1 = last ? 0 : nn.off[n + 1];
-        d4 q[RB];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) q[rb] = d4{0.0, 0.0, 0.0, 0.0};
-        if (!last) {
-            // ---- product 1: Z = X_n W_n^T for the wave's 16 columns of layer n+1
-            d4 acc[RB];
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) acc[rb] = d4{0.0, 0.0, 0.0, 0.0};
-            if (cb * 16 < sn1) {
-                const int nk = (sn + 3) >> 2;
-                const double *wf = nn.Wf + (size_t)b * nn.wfsz + nn.wfoff[n] + (size_t)cb * nk * 64 + lane;
-                // (B fragments eight k-steps ahead: an L2 round trip is about the matrix time of eight steps of the SIMD's two waves)
-                constexpr int PF = 8;
-                double bq[PF];
-#pragma unroll
-                for (int u = 0; u < PF; ++u) bq[u] = u < nk ? wf[u * 64] : 0.0;
-                for (int k0 = 0; k0 < nk; k0 += PF) {
-#pragma unroll
-                    for (int u = 0; u < PF; ++u) {
-                        const double bc = bq[u];
-                        bq[u] = k0 + PF + u < nk ? wf[(k0 + PF + u) * 64] : 0.0;
-                        if (k0 + u < nk) {
-                            const int k = 4 * (k0 + u) + hi;
-#pragma unroll
-                            for (int rb = 0; rb < RB; ++rb)
-                                acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(rb * 16 + lo) * PX + k], bc, acc[rb], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-            __syncthreads();                                   // every wave is done with X_n
-            // ---- epilogue A: residual, q, delta; x_{n+1} becomes the next operand (columns beyond the layer: zeros)
-            {
-                const bool on = col < sn1;
-                const double bias = on ? Pw[nn.boff[n] + col] : 0.0;
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ml = rb * 16 + hi + 4 * r;
-                        double xv = 0.0, dl = 0.0;
-                        if (on && ml < nra) {
-                            const size_t idx = vo + (size_t)(m0 + ml) * nn.NDnet + offn1 + col;
-                            xv = Xg[idx - vo];
-                            const double z = acc[rb][r] + bias;
-                            const double a = ACT::f(z), da = ACT::d(z, a);
-                            const double res = xv - a, qv = cq * res;
-                            v_fe += res * res;
-                            dl = -qv * da;
-                            q[rb][r] = qv;
-                            nn.delta[idx] = dl;
-                        }
-                        DL[ml * PX + col] = dl;
-                        Xs[ml * PX + col] = xv;
-                    }
-            }
-            __syncthreads();
-        }
-        // ---- product 2 (not for the last layer: nothing leaves it) and epilogue B: dA/dx_n for the wave's 16 columns of layer n
-        // (the accumulators start from q_{n-1}: dA/dx_n = q_{n-1} + delta_n W_n, same (example, column) map)
-        d4 g[RB];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) g[rb] = qprev[rb];
-        if (!last && cb * 16 < sn) {
-            const int nk = (sn1 + 3) >> 2;
-            const double *W = Pw + nn.woff[n];
-            const bool con = col < sn;
-            constexpr int PF = 8;
-            double bq[PF];
-#pragma unroll
-            for (int u = 0; u < PF; ++u) { const int k = 4 * u + hi; bq[u] = (con && k < sn1) ? W[(size_t)k * sn + col] : 0.0; }
-            for (int k0 = 0; k0 < nk; k0 += PF) {
-#pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    const double bc = bq[u];
-                    const int kn = 4 * (k0 + PF + u) + hi;
-                    bq[u] = (con && kn < sn1) ? W[(size_t)kn * sn + col] : 0.0;
-                    if (k0 + u < nk) {
-                        const int k = 4 * (k0 + u) + hi;
-#pragma unroll
-                        for (int rb = 0; rb < RB; ++rb)
-                            g[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(DL[(rb * 16 + lo) * PX + k], bc, g[rb], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        if (col < sn) {
-            int l = -1; double rm = 0.0; const double *dat = nullptr; int L = 0;
-            if (n == 0) { l = nn.lmap_in[col]; rm = nn.rm_in; dat = nn.din; L = nn.Lin; }
-            else if (last) { l = nn.lmap_out[col]; rm = nn.rm_out; dat = nn.dout; L = nn.Lout; }
+        for (int c2 = 0; c2 < CW; ++c2) {
+            const int col = (cb0 + c2) * 16 + lo;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ml = rb * 16 + hi + 4 * r;
-                    if (ml >= nra) continue;
-                    const size_t idx = vo + (size_t)(m0 + ml) * nn.NDnet + offn + col;
-                    double gv = g[rb][r];
-                    if (l >= 0) {
-                        const double diff = Xg[idx - vo] - dat[(size_t)(m0 + ml) * L + l];
-                        v_me += rm * diff * diff;
-                        gv += 2.0 * dv.dm.cme * rm * diff;
-                    }
-                    dv.gt[idx] = gv;
-                    if (use_d) v_gtd += gv * dv.d[idx];
-                    v_gn2 += gv * gv;
-                    v_gmax = fmax(v_gmax, fabs(gv));
+                    xn[c2][rb][r] = (col < s1 && ml < nra) ? Xg[(m0 + ml) * nn.NDnet + o1 + col] : 0.0;
                 }
         }
+    };
+    if (NL > 1) request_x(1);
+    d4 qprev[CW][RB];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) qprev[rb] = q[rb];
+    for (int c2 = 0; c2 < CW; ++c2)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) qprev[c2][rb] = d4{0.0, 0.0, 0.0, 0.0};
+    double v_me = 0.0, v_fe = 0.0, v_gtd = 0.0, v_gn2 = 0.0, v_gmax = 0.0;
+    for (int n = 0; n <= NL - 1; ++n) {
+        const int sn = meta[n], offn = meta[NN_FB_LAYERS + n];
+        const bool last = n == NL - 1;
+        const int sn1 = last ? 0 : meta[n + 1], offn1 = last ? 0 : meta[NN_FB_LAYERS + n + 1];
+        d4 q[CW][RB];
+#pragma unroll
+        for (int c2 = 0; c2 < CW; ++c2)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) q[c2][rb] = d4{0.0, 0.0, 0.0, 0.0};
+        if (!last) {
+            // ---- product 1: Z = X_n W_n^T for the wave's columns of layer n+1
+            d4 acc[CW][RB];
+#pragma unroll
+            for (int c2 = 0; c2 < CW; ++c2)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[c2][rb] = d4{0.0, 0.0, 0.0, 0.0};
+            if (cb0 * 16 < sn1) {
+                // (B fragments NN_FB_PF k-steps ahead: an L2 round trip is about the matrix time of eight steps of the SIMD's two
+                // waves.  The table is padded -- whole groups of k-steps and a group of zeros behind the last -- and X_n's
+                // columns beyond the layer are zeros: no bounds test in the loop)
+                constexpr int PF = NN_FB_PF;
+                const int nkp = nn_fb_steps(sn), nkr = nkp - PF;
+                const int wf = (meta[4 * NN_FB_LAYERS + n] + cb0 * nkp * 64 + lane) * 8;          // byte offset of the lane's first fragment element
+                const double *xa = Xs + lo * PX + hi;
+                double bq[CW][PF];
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {                                      // (requested in the order the loop re-requests them:
+#pragma unroll                                                                          //  the oldest request is the first one waited for)
+                    for (int c2 = 0; c2 < CW; ++c2) bq[c2][u] = fb_frag(wr, wf + (c2 * nkp + u) * 512);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // per k-step, in this order (pinned: left alone the scheduler requests the fragments early into fresh registers
+                // and copies them into the ring behind a wait, which shortens the distance to less than one group):
+                // the next step's A elements from LDS, this step's matrix instructions, then the reload of the ring slot
+                double a[RB];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) a[rb] = xa[rb * 16 * PX];
+                for (int k0 = 0; k0 < nkr; k0 += PF) {
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {
+                        double an[RB];
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb) an[rb] = xa[rb * 16 * PX + 4 * (k0 + u + 1)];   // (the last one is not used)
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                            for (int c2 = 0; c2 < CW; ++c2)
+                                acc[c2][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb], bq[c2][u], acc[c2][rb], 0, 0, 0);
+#pragma unroll
+                        for (int c2 = 0; c2 < CW; ++c2) bq[c2][u] = fb_frag(wr, wf + (c2 * nkp + k0 + PF + u) * 512);
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb) a[rb] = an[rb];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            FB_MARK(1);
+            __syncthreads();                                   // every wave is done with X_n
+            FB_MARK(2);
+            // ---- epilogue A: residual, q, delta; x_{n+1} becomes the next operand (columns beyond the layer: zeros)
+#pragma unroll
+            for (int c2 = 0; c2 < CW; ++c2) {
+                const int col = (cb0 + c2) * 16 + lo;
+                const bool on = col < sn1;
+                const double bias = on ? Pw[meta[3 * NN_FB_LAYERS + n] + col] : 0.0;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ml = rb * 16 + hi + 4 * r;
+                        const double xv = xn[c2][rb][r];
+                        double dl = 0.0;
+                        if (on && ml < nra) {
+                            const int e = (m0 + ml) * nn.NDnet + offn1 + col;        // (the ensemble has fewer than 2^31 states: create)
+                            const double z = acc[c2][rb][r] + bias;
+                            const double a = ACT::f(z), da = ACT::d(z, a);
+                            const double res = xv - a, qv = cq * res;
+                            v_fe += res * res;
+                            dl = -qv * da;
+                            q[c2][rb][r] = qv;
+#if !defined(VA_FB_ABL) || VA_FB_ABL != 2
+                            dlg[e] = dl;
+#endif
+                        }
+                        DL[ml * PX + col] = dl;
+                        Xs[ml * PX + col] = xv;
+                    }
+            }
+            FB_MARK(3);
+            __syncthreads();
+            FB_MARK(4);
+        }
+        // ---- product 2 (not for the last layer: nothing leaves it) and epilogue B: dA/dx_n for the wave's columns of layer n
+        // (the accumulators start from q_{n-1}: dA/dx_n = q_{n-1} + delta_n W_n, same (example, column) map)
+        d4 g[CW][RB], dn[CW][RB];
+#pragma unroll
+        for (int c2 = 0; c2 < CW; ++c2)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) { g[c2][rb] = qprev[c2][rb]; dn[c2][rb] = d4{0.0, 0.0, 0.0, 0.0}; }
+        if (use_d) {                                           // the direction's entries epilogue B multiplies with (same reason)
+#pragma unroll
+            for (int c2 = 0; c2 < CW; ++c2) {
+                const int col = (cb0 + c2) * 16 + lo;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ml = rb * 16 + hi + 4 * r;
+                        if (col < sn && ml < nra) dn[c2][rb][r] = dg[(m0 + ml) * nn.NDnet + offn + col];
+                    }
+            }
+        }
+        if (!last && cb0 * 16 < sn) {
+            constexpr int PF = NN_FB_PF;
+            const int nkp = nn_fb_steps(sn1), nkr = nkp - PF;
+            const int wf = (meta[5 * NN_FB_LAYERS + n] + cb0 * nkp * 64 + lane) * 8;
+            const double *da = DL + lo * PX + hi;
+            double bq[CW][PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+#pragma unroll
+                for (int c2 = 0; c2 < CW; ++c2) bq[c2][u] = fb_frag(wr, wf + (c2 * nkp + u) * 512);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            double a[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) a[rb] = da[rb * 16 * PX];
+            for (int k0 = 0; k0 < nkr; k0 += PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    double an[RB];
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) an[rb] = da[rb * 16 * PX + 4 * (k0 + u + 1)];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                        for (int c2 = 0; c2 < CW; ++c2)
+                            g[c2][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb], bq[c2][u], g[c2][rb], 0, 0, 0);
+#pragma unroll
+                    for (int c2 = 0; c2 < CW; ++c2) bq[c2][u] = fb_frag(wr, wf + (c2 * nkp + k0 + PF + u) * 512);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) a[rb] = an[rb];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (n + 2 <= NL - 1) request_x(n + 2);                 // (transition n + 1's; its q, delta are formed two phases from here)
+        FB_MARK(5);
+        const bool measured = n == 0 || last;                   // (uniform: the layers between carry no measurement term)
+#pragma unroll
+        for (int c2 = 0; c2 < CW; ++c2) {
+            const int col = (cb0 + c2) * 16 + lo;
+            if (col < sn) {
+                int l = -1; double rm = 0.0; const double *dat = nullptr; int L = 0;
+                if (measured) {
+                    if (n == 0) { l = nn.lmap_in[col]; rm = nn.rm_in; dat = nn.din; L = nn.Lin; }
+                    else { l = nn.lmap_out[col]; rm = nn.rm_out; dat = nn.dout; L = nn.Lout; }
+                }
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ml = rb * 16 + hi + 4 * r;
+                        if (ml >= nra) continue;
+                        const int e = (m0 + ml) * nn.NDnet + offn + col;
+                        double gv = g[c2][rb][r];
+                        if (measured && l >= 0) {
+                            const double diff = Xg[e] - dat[(size_t)(m0 + ml) * L + l];
+                            v_me += rm * diff * diff;
+                            gv += 2.0 * dv.dm.cme * rm * diff;
+                        }
+#if !defined(VA_FB_ABL) || VA_FB_ABL != 1
+                        gtg[e] = gv;
+#endif
+                        v_gtd += gv * dn[c2][rb][r];
+                        v_gn2 += gv * gv;
+                        v_gmax = fmax(v_gmax, fabs(gv));
+                    }
+            }
+        }
+        FB_MARK(6);
+#pragma unroll
+        for (int c2 = 0; c2 < CW; ++c2)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) qprev[c2][rb] = q[c2][rb];
     }
+    FB_MARK_FLUSH(dv.pz.stamps);
     // the workgroup's row of partial sums
     {
         double w;
-        w = wave_sum(v_me); if (lane == 0) red[cb * 5 + 0] = w;
-        w = wave_sum(v_fe); if (lane == 0) red[cb * 5 + 1] = w;
-        w = wave_sum(v_gtd); if (lane == 0) red[cb * 5 + 2] = w;
-        w = wave_sum(v_gn2); if (lane == 0) red[cb * 5 + 3] = w;
-        w = wave_max(v_gmax); if (lane == 0) red[cb * 5 + 4] = w;
+        w = wave_sum(v_me); if (lane == 0) red[wave * 5 + 0] = w;
+        w = wave_sum(v_fe); if (lane == 0) red[wave * 5 + 1] = w;
+        w = wave_sum(v_gtd); if (lane == 0) red[wave * 5 + 2] = w;
+        w = wave_sum(v_gn2); if (lane == 0) red[wave * 5 + 3] = w;
+        w = wave_max(v_gmax); if (lane == 0) red[wave * 5 + 4] = w;
         __syncthreads();
         if (tid == 0) {
             double t[5];
@@ -485,7 +643,7 @@ __global__ __launch_bounds__(NN_FB_THREADS, NN_FB_R == 32 ? 4 : 2) void k_nnet_f
         }
     }
 }
-inline size_t nnet_fb_lds() { return sizeof(double) * ((size_t)2 * NN_FB_R * NN_FB_PITCH + 5 * (NN_FB_THREADS / 64) + 8); }
+inline size_t nnet_fb_lds() { return sizeof(double) * ((size_t)2 * NN_FB_R * NN_FB_PITCH + 5 * (NN_FB_THREADS / 64) + 8) + sizeof(int) * 6 * NN_FB_LAYERS; }
 
 #ifndef VA_NNET_ACT_ONLY
 // ------------------------------------------------------------------ K2: dA/dX
