@@ -282,6 +282,7 @@ def test_fused_forward_backward_kernel_matches_oracle(structure, M, act):
     X, P, Pidx = twin.nnet_initial_guess(structure, M, 3)
     XP = np.append(X, P[Pidx])[None, :]
     with _capi.NnetProblem(1, structure, din, dout, Lidx, 3.0, 0.02, P[None, :], Pidx, act=act) as pr:
+        pr.tune(nnet_fused=0)
         A0, me0, fe0, g0 = pr.action_grad(XP, 7.0)
         pr.tune(nnet_fused=1)
         A1, me1, fe1, g1 = pr.action_grad(XP, 7.0)
@@ -291,3 +292,36 @@ def test_fused_forward_backward_kernel_matches_oracle(structure, M, act):
     assert np.abs(g1[0] - go).max() <= 1e-10 * np.abs(go).max()
     assert abs(A1[0] - A0[0]) <= 1e-13 * abs(A0[0]) and np.abs(g1[0] - g0[0]).max() <= 1e-12 * np.abs(g0[0]).max()
     assert r["A"][0] < A1[0]
+
+
+
+@pytest.mark.parametrize("structure,M,act", [([64, 64, 64], 2048, "sigmoid"), ([70, 100, 33], 2030, "tanh")])
+def test_fused_kernel_is_the_default_when_its_blocks_fill_the_chip(structure, M, act):
+    """8 seeds x 64 blocks of 32 examples = 512 workgroups: the handle evaluates with k_nnet_fb unasked.  Action and
+    gradient against the NumPy oracle and the separate kernels; a minimisation (line-search evaluations: the direction's
+    entries are prefetched too) against the separate kernels' iterates"""
+    B = 8
+    din, dout, _ = twin.make_nnet_twin(structure, M)
+    Lidx = [np.arange(structure[0]), np.arange(structure[-1])]
+    g = [twin.nnet_initial_guess(structure, M, b) for b in range(B)]
+    Pidx = g[0][2]
+    P = np.array([x[1] for x in g])
+    XP = np.array([np.append(x[0], x[1][Pidx]) for x in g])
+    opts = {'gtol': 1e-10, 'ftol': 1e-10, 'maxfun': 40, 'maxiter': 12}
+    with _capi.NnetProblem(B, structure, din, dout, Lidx, 3.0, 0.02, P, Pidx, act=act) as pr:
+        A1, me1, fe1, g1 = pr.action_grad(XP, 7.0)
+        r1 = pr.minimize_lbfgs(XP, 7.0, opts)
+        pr.tune(nnet_fused=0)
+        A0, me0, fe0, g0 = pr.action_grad(XP, 7.0)
+        r0 = pr.minimize_lbfgs(XP, 7.0, opts)
+        pr.tune(nnet_fused=1)
+        A2, _, _, g2 = pr.action_grad(XP, 7.0)
+    assert np.array_equal(A1, A2) and np.array_equal(g1, g2)                  # the default WAS the fused kernel
+    assert not np.array_equal(g1, g0)                                          # (and the other path is another summation order)
+    assert np.all(np.abs(A1 - A0) <= 1e-13 * np.abs(A0)) and np.abs(g1 - g0).max() <= 1e-12 * np.abs(g0).max()
+    for b in (0, B - 1):
+        Ao, meo, feo, go = vno.NnetProblem(structure, din, dout, Lidx, 3.0, 0.02, P[b], Pidx, act=act).action_grad(XP[b], 7.0)
+        assert abs(A1[b] - Ao) <= 1e-12 * abs(Ao) and abs(me1[b] - meo) <= 1e-12 * abs(Ao)
+        assert np.abs(g1[b] - go).max() <= 1e-10 * np.abs(go).max()
+    assert np.array_equal(r1["nit"], r0["nit"]) and np.array_equal(r1["nfev"], r0["nfev"])
+    assert np.all(np.abs(r1["A"] - r0["A"]) <= 1e-9 * np.abs(r0["A"])) and np.all(r1["A"] < A1)

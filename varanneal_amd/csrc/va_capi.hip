@@ -1147,12 +1147,15 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
         nn.wfsz = wfsz;
         fb_ok = !nn.small && widest <= NN_FB_W && NL <= NN_FB_LAYERS && !d->rm_in_matrix && nn.nfb <= nn.n1 + nn.n2 &&
                 (long long)NDnet * d->M < (1LL << 31);
-        nn.fused = 0;                  // (available through va_problem_tune; slower than the two kernels as measured)
         {
             int ncu = 256;
             if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess) ncu = 256;
             nn.fb_slots = ncu * NN_FB_WGS; nn.fb_stagger = 0;
         }
+        // on when its blocks of NN_FB_R examples fill the chip at least once (a workgroup walks ALL layers of its block:
+        // with few blocks the separate kernels, one workgroup per layer and tile, have more in flight); va_problem_tune
+        // switches it either way (c5x, 1024 workgroups: 637 against 709 us per evaluation, profiles/r04_nnet_fused.txt)
+        nn.fused = fb_ok && (long long)nn.nfb * d->batch >= nn.fb_slots;
     }
     const bool fold_rows = nn.nraw > NN_ROWS_DIRECT;      // k_ls sums the rows with one wave: keep them few
     dm.nprow = fold_rows ? NN_RED_ROWS : nn.nraw;
@@ -1435,7 +1438,7 @@ int va_problem_tune(va_handle h, int32_t what, int32_t value)
     case VA_TUNE_GRAPH: h->tune_graph = value != 0; break;
     case VA_TUNE_NNET_FUSED:
         if (!h->is_nnet || !h->nn.Wf) return fail(VA_ESTATE, "not a network handle whose layers fit the fused kernel");
-        // value 1: fused; value 2 + t: fused, the second workgroup of each CU starting t microseconds late
+        // value 1: fused; value 2 + t: fused, the first workgroups' starts spread over t microseconds (measurement)
         h->nn.fused = value != 0 ? 1 : 0;
         h->nn.fb_stagger = value >= 2 ? (value - 2) * 100 : h->nn.fb_stagger; break;
     case VA_TUNE_PERSIST: h->tune_persist = value != 0; break;

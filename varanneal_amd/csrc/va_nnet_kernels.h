@@ -330,20 +330,25 @@ __device__ __forceinline__ double fb_frag(__amdgpu_buffer_rsrc_t r, int byte_off
 // ------------------------------------------------------------------ K1 + K2 in one: forward and state-gradient products
 // Layers up to NN_FB_W = 128 wide (c5x: 8 x 128, M = 2048).  As separate kernels the two products move every delta and
 // every q through HBM twice and re-read the states (profiles/r03_nnet_c5x_ablation.txt: 78-83 % of each kernel is
-// memory time).  Here a workgroup of 8 waves owns a block of 64 EXAMPLES and marches it through the transitions:
-//   the block's states X_n sit in LDS (A operand of Z = X_n W_n^T); wave w owns the 16 output columns 16 w ... of every
-//   layer (four 16 x 16 accumulators, one per 16 examples); the B operand comes straight from L2 in fragment order
-//   (nn.Wf, written once per evaluation by k_nnet_wfrag) -- 512 contiguous bytes per matrix instruction, no LDS staging;
+// memory time).  Here a workgroup of 4 waves owns a block of 32 EXAMPLES and marches it through the transitions (two
+// workgroups per CU, 256 registers a lane each):
+//   the block's states X_n sit in LDS (A operand of Z = X_n W_n^T); wave w owns the 32 output columns 32 w ... of every
+//   layer (2 x 2 accumulators of 16 x 16); the B operand comes straight from L2 in fragment order (nn.Wf, written once
+//   per evaluation by k_nnet_wfrag, padded so that the k loops carry no bounds test) -- 512 contiguous bytes per matrix
+//   instruction, no LDS staging, requested NN_FB_PF k-steps ahead;
 //   epilogue A: residual, q, delta from Z and x_{n+1} (read ONCE from HBM: it becomes the next transition's LDS operand);
 //     delta goes to LDS (A operand of the second product) and to HBM (for k_nnet_bwd_w); q STAYS IN REGISTERS: the
 //     accumulator layout of the next transition's state gradient is the same (example, column) map;
-//   second product G_n = delta_n W_n (B operand: rows of W_n, 128 contiguous bytes per 16 lanes, from L2);
+//   second product G_n = delta_n W_n (B operand: the second fragment table);
 //   epilogue B: dA/dx_n = G_n + q_{n-1} + measurement term -> gt.
 // Every state is read once and every gradient / delta entry written once: 2.79 -> 1.3 GB per evaluation at c5x.
-// MEASURED (round 4, profiles/r04_nnet_fused.txt): 563 us against 270 + 258 us for the two kernels it replaces -- with
-// one workgroup per CU the layers' memory phases (x_{n+1} in, delta and gradient out) and their matrix phases run in
-// lockstep on every CU instead of overlapping; without any operand fetch in the K loops it still takes 510 us (matrix
-// floor: 191 us).  Off unless asked for (va_problem_tune nnet_fused=1); the next step is named in DESIGN.md 8.
+// MEASURED (round 4, profiles/r04_nnet_fused.txt): 414 us against 270 + 258 us for the two kernels it replaces (c5x
+// evaluation 709 -> 637 us).  What the first version (563 us) lost, found with the phase marks of va_measure.h and the ISA:
+//   bounds tests in the k loops made every k-step a branch with a wait behind each LDS read; plain loads carried around
+//   the loop were sunk to their uses by the compiler (no prefetch at all); x_{n+1} / d fetched inside the epilogues made
+//   every element wait for an HBM round trip; per-layer sizes and offsets fetched from global memory put a round trip in
+//   front of each phase.  The products now run at the matrix rate of two waves per SIMD; what is left are the epilogues
+//   (f64 exp and division: ~4 us per layer on the vector ALUs; the stores of all workgroups of the launch come in bursts).
 template <class ACT>
 __global__ __launch_bounds__(NN_FB_THREADS, NN_FB_WGS) void k_nnet_fb(const Dev dv, const NnetDev nn)
 {
