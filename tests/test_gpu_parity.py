@@ -41,7 +41,7 @@ def test_all_golden_single_evals(capi, golden_single, eval_kernel):
     production for D = 20), auto and tiny tiles"""
     worstA = worstG = 0.0
     for name, c in golden_single.items():
-        for tile_rows in (0, 6):
+        for tile_rows in (0, 6, 144):            # (144: runs of 12 rows where that kernel is compiled, else 8)
             with gpu_problem(capi, c, tile_rows=tile_rows, eval_kernel=eval_kernel) as pb:
                 A, me, fe, g = pb.action_grad(c["XP"][None, :], c["rf_scale"])
             eA = abs(A[0] - c["A"]) / abs(c["A"])
@@ -312,6 +312,40 @@ def test_c3_shape_properties(capi):
     Ap_, _, _, gp_ = pb2.action_grad(XP[perm], 1000.0)
     assert np.array_equal(Ap_, A2[perm]) and np.array_equal(gp_, g2[perm])
     pb.close(); pb2.close()
+
+
+@pytest.mark.parametrize("disc,N", [("SimpsonHermite", 1001), ("trapezoid", 1000), ("euler", 871), ("forwardmap", 289)])
+def test_runs_of_twelve_rows(capi, disc, N):
+    """k_eval4 with runs of 12 rows (two workgroups per CU; D = 20, scalar weights) -- what the chooser takes for
+    Simpson-Hermite at the C3 shape (one round of resident workgroups) -- against the oracle, against runs of 4 rows, and
+    through a minimisation (line-search launches)"""
+    import va_oracle
+    from varanneal_amd import twin
+    D, B = 20, 64
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    XP = np.empty((B, N * D + 1)); P = np.empty((B, 1))
+    for b in range(B):
+        X0, P0 = twin.initial_guess(N, D, b)
+        XP[b, :-1] = X0.ravel(); XP[b, -1] = P0[0]; P[b] = P0
+    rf = 1.5 ** 14
+    opts = {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000, 'maxiter': 6}
+    with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc=disc, tile_rows=(0 if disc == "SimpsonHermite" else 144)) as pb:
+        info = pb.info()
+        assert (info["eval_kernel"], info["run_rows"]) == (4, 12), info
+        A, me, fe, g = pb.action_grad(XP, rf)
+        r = pb.minimize_lbfgs(XP, rf, opts)
+    with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc=disc, tile_rows=48) as pb4:
+        assert pb4.info()["run_rows"] == 4
+        A4, me4, fe4, g4 = pb4.action_grad(XP, rf)
+        r4 = pb4.minimize_lbfgs(XP, rf, opts)
+    assert np.all(np.abs(A - A4) <= 1e-13 * np.abs(A4)) and np.abs(g - g4).max() <= 1e-12 * np.abs(g4).max()
+    assert np.array_equal(r["nit"], r4["nit"]) and np.array_equal(r["nfev"], r4["nfev"])
+    assert np.all(np.abs(r["A"] - r4["A"]) <= 1e-10 * np.abs(r4["A"]))
+    for b in (0, 17, B - 1):
+        ob = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[b], [0], disc=disc)
+        Ao, meo, feo, go = ob.action_grad(XP[b], rf)
+        assert abs(A[b] - Ao) <= RTOL_A * abs(Ao) and abs(me[b] - meo) <= RTOL_A * abs(Ao) and abs(fe[b] - feo) <= RTOL_A * abs(feo)
+        assert np.abs(g[b] - go).max() <= RTOL_G * np.abs(go).max()
 
 
 def test_c4_shape_properties(capi):

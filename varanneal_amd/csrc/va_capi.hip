@@ -250,10 +250,15 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
                 const long cost = ((ntl(k) + per_round - 1) / per_round) * (k + 2) * 4 + (k == 6 ? 0 : 1);     // ties go to 6
                 if (best < 0 || cost < best) { best = cost; K = k; }
             }
+            // Simpson-Hermite, D = 20, scalar weights: runs of 12 rows (two workgroups per CU, no spill) when they put the whole
+            // grid in ONE round of resident workgroups -- a launch of this size is a chain of latencies, not of rows: N = 1001,
+            // 64 seeds: K = 4 -> 21 tiles, 1.75 rounds, 11.3 us; K = 12 -> 7 tiles, 448 workgroups, 9.4 us (trapezoid at K = 7: 8.6)
+            if (sh && D == 20 && d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1 && ntl(12) <= 2 * 256 && ntl(K) > 3 * 256) K = 12;
         }
         if (d->tile_rows > 0) {
             K = (d->tile_rows + rows1 - 1) / rows1;
-            K = K < 4 ? 4 : (K > 8 ? 8 : K);
+            const bool k12 = D == 20 && d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1;     // (the one longer run compiled)
+            K = K < 4 ? 4 : (K >= 12 && k12 ? 12 : (K > 8 ? 8 : K));
             if (sh && (K & 1)) ++K;
         }
         // weight arrays / data every nskip-th row: runs of 6 and 7 rows do not fit three waves per SIMD's 168 registers
@@ -276,7 +281,8 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
         // only SUB = 1 is instantiated, and the host never asks for anything else)
         const int SUB = 1;
         g4 = sh ? tile4_geo<3>(D, K, ne, SUB) : tile4_geo<2>(D, K, ne, SUB);
-        if ((g4.XP + 63) / 64 <= T4_NI_MAX && tile4_magic_ok(g4)) {
+        // (D = 20 is compiled with its geometry constant: the kernel sizes its staging loop exactly)
+        if ((D == 20 || (g4.XP + 63) / 64 <= T4_NI_MAX) && tile4_magic_ok(g4)) {
             dm.RY = 4 * RW; dm.NT = 256; dm.maxr = K; dm.T = g4.T;
             dm.ntiles = (N + dm.T - 1) / dm.T;
             return;

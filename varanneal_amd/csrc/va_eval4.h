@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
             wave_sync_lds();
             const int base = (n0w + s * RK) * D * 8;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {                     // (RW * D <= 64 columns, K <= 8 rows: at most 256 pieces)
+            for (int i = 0; i < (K * 32 + 63) / 64; ++i) {    // (RW * D <= 64 columns, K rows: at most 32 K pieces)
                 if (i * 64 >= npieces) break;
                 typedef unsigned v4u __attribute__((ext_vector_type(4)));
                 const int q = i * 64 + lane;
