@@ -124,6 +124,31 @@ def test_custom_activation_on_larger_shapes_against_oracle(structure, M):
 
 
 @pytest.mark.gpu
+def test_custom_activation_through_the_fused_kernel():
+    """the generated module's k_nnet_fb instantiation (asked for: a generated activation runs the separate kernels unasked)
+    against the NumPy oracle and the separate kernels, evaluation and minimisation"""
+    structure, M = [70, 33, 128, 5], 300
+    din, dout, _ = twin.make_nnet_twin(structure, M)
+    Lidx = [np.arange(structure[0]), np.arange(0, structure[-1], 2)]
+    dout = dout[:, Lidx[1]]
+    X0, P0, Pidx = twin.nnet_initial_guess(structure, M, 7, False)
+    XP = np.append(X0.ravel(), P0[Pidx])[None, :]
+    aid = _capi.load_act_module(codegen.activation_module_for(swish)["so"])
+    opts = {'gtol': 1e-10, 'ftol': 1e-12, 'maxiter': 10, 'maxfun': 100}
+    with _capi.NnetProblem(1, structure, din, dout, Lidx, 2.0, 0.3, P0[None, :], Pidx, act=aid) as pr:
+        A0, me0, fe0, g0 = pr.action_grad(XP, 4.0)
+        r0 = pr.minimize_lbfgs(XP, 4.0, opts)
+        pr.tune(nnet_fused=1)
+        A1, me1, fe1, g1 = pr.action_grad(XP, 4.0)
+        r1 = pr.minimize_lbfgs(XP, 4.0, opts)
+    Ao, meo, feo, go = vno.NnetProblem(structure, din, dout, Lidx, 2.0, 0.3, P0, Pidx, act=SWISH).action_grad(XP[0], 4.0)
+    assert abs(A1[0] - Ao) <= 1e-12 * abs(Ao) and abs(fe1[0] - feo) <= 1e-12 * abs(Ao)
+    assert np.abs(g1[0] - go).max() <= 1e-10 * np.abs(go).max()
+    assert not np.array_equal(g1, g0) and np.abs(g1 - g0).max() <= 1e-12 * np.abs(g0).max()
+    assert (r1["nit"][0], r1["nfev"][0]) == (r0["nit"][0], r0["nfev"][0]) and abs(r1["A"][0] - r0["A"][0]) <= 1e-9 * abs(r0["A"][0])
+
+
+@pytest.mark.gpu
 def test_annealer_takes_any_layer_map(gold):
     """through the drop-in: set_activation(callable) -> trace -> module; two rungs, actions decrease and the
     stored minimiser reproduces them"""

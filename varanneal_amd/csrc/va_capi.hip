@@ -1161,7 +1161,9 @@ int va_nnet_problem_create(const va_nnet_desc *d, va_handle *out)
         // on when its blocks of NN_FB_R examples fill the chip at least once (a workgroup walks ALL layers of its block:
         // with few blocks the separate kernels, one workgroup per layer and tile, have more in flight); va_problem_tune
         // switches it either way (c5x, 1024 workgroups: 637 against 709 us per evaluation, profiles/r04_nnet_fused.txt)
-        nn.fused = fb_ok && (long long)nn.nfb * d->batch >= nn.fb_slots;
+        // (not for softplus -- log1p / exp / expm1 spill 28 registers there: 830 against 809 us -- nor, unasked, for a generated
+        // activation, whose register needs nobody has looked at)
+        nn.fused = fb_ok && (long long)nn.nfb * d->batch >= nn.fb_slots && d->activation != NNET_SOFTPLUS && d->activation < NNET_USER;
     }
     const bool fold_rows = nn.nraw > NN_ROWS_DIRECT;      // k_ls sums the rows with one wave: keep them few
     dm.nprow = fold_rows ? NN_RED_ROWS : nn.nraw;
