@@ -265,7 +265,8 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
         // with their weight registers (18-59 spilled; measured at the C3 shape, profiles/r03_f3_variants.txt: 21 us
         // against 13 us for K = 5): those problems run K <= 5, or 8 at two waves per SIMD
         {
-            const bool ws4 = d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1;
+            // (D = 20 with scalar weights and data at every nskip-th row has a variant of its own without weight registers)
+            const bool ws4 = d->rm_kind == 0 && d->rf_kind == 0 && (d->merr_nskip == 1 || (D == 20 && d->rhs == VA_RHS_LORENZ96));
             if (!ws4 && (K == 6 || K == 7)) K = sh ? 4 : 5;
         }
         // column forms with many products per element (a ring of coupled units: 8): the product arrays grow with the run

@@ -31,10 +31,11 @@ __device__ __forceinline__ void tile4_dma(const Geo4 &g, const double *src, doub
 // all images are requested up front, the first sub-tile's gradient leaves while the next is computed
 // (co-resident waves run in lockstep: load, then compute, then store, all of them together), and
 // the wave reduces its partial sums once.
-template <class RHS, int DISC, int K, int DC, bool W_SCALAR, int SUB>
+template <class RHS, int DISC, int K, int DC, int WS, int SUB>
 __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ? 3 : 2)) void k_eval4(const Dev dv)      // (the neighbour values of the lane's K rows live in registers: K * NB of them)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr bool W_SCALAR = WS != 0;                        // WS: 0 weight arrays, 1 scalar weights, 2 scalar weights + merr_nskip
     const Dims &dm = dv.dm;
     const int nwork = dm.B * dm.ntiles;
     const int w = xcd_swizzle(blockIdx.x, nwork);
@@ -97,7 +98,29 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
     T4Regs<K, NE> rg[SUB];
     ThreadAcc acc;
     acc.clear();
-    if constexpr (W_SCALAR) {
+    if constexpr (WS == 2) {
+        // data at every nskip-th model row: the lane walks its rows once, counting data rows; rows without data read as 0
+        // (outside the buffer) and are masked out of the measurement terms by rg.has
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)dv.pp.Y, 0, (int)(sizeof(double) * dm.N_data * dm.L), 0x00020000);
+        const bool obs = active && t.l >= 0;
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) {
+            const int m0 = t.r0 + s * RK;
+            int nd = m0 / dm.nskip, rem = m0 - nd * dm.nskip;
+            unsigned has = 0u;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                const bool h = obs && rem == 0 && nd < dm.N_data && m0 + k < dm.N;
+                const v2u v = __builtin_amdgcn_raw_buffer_load_b64(yr, h ? (nd * dm.L + t.l) * 8 : 0x7ffffff0, 0, 0);
+                rg[s].yv[k] = __hiloint2double((int)v.y, (int)v.x);
+                has |= h ? (1u << k) : 0u;
+                if (++rem == dm.nskip) { rem = 0; ++nd; }
+            }
+            rg[s].has = has;
+        }
+    } else if constexpr (W_SCALAR) {
         // observations of the lane's own rows: one address per lane, the row stride rides in an SGPR;
         // rows beyond the data and unobserved columns fall outside the buffer and read as 0
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
@@ -204,8 +227,8 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
         const bool edge = (n0s - HL < 0) || (n0s + RK + HR > dm.N);          // wave-uniform
         t.r0 = n0s + a * K; t.xs = xsw + s * g.XW;
         if (active) {
-            if (edge) tile4_rows<RHS, DISC, K, true, DC, W_SCALAR>(dm, dv.pp, g, t, rg[s], acc);
-            else tile4_rows<RHS, DISC, K, false, DC, W_SCALAR>(dm, dv.pp, g, t, rg[s], acc);
+            if (edge) tile4_rows<RHS, DISC, K, true, DC, WS>(dm, dv.pp, g, t, rg[s], acc);
+            else tile4_rows<RHS, DISC, K, false, DC, WS>(dm, dv.pp, g, t, rg[s], acc);
         }
         wave_sync_lds();          // products are read by the same wave only: LDS is in order within a wave
         if (s == SUB - 1) VA_E4_STAMP(3);
@@ -218,11 +241,11 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
         for (int k = 0; k < K; ++k) gvv[s][k] = 0.0;
         if (active) {
             if (edge) {
-                if (lsq) tile4_grad<RHS, DISC, K, true, DC, W_SCALAR, true>(dm, g, t, rg[s], acc, gvv[s]);
-                else tile4_grad<RHS, DISC, K, true, DC, W_SCALAR, false>(dm, g, t, rg[s], acc, gvv[s]);
+                if (lsq) tile4_grad<RHS, DISC, K, true, DC, WS, true>(dm, g, t, rg[s], acc, gvv[s]);
+                else tile4_grad<RHS, DISC, K, true, DC, WS, false>(dm, g, t, rg[s], acc, gvv[s]);
             } else {
-                if (lsq) tile4_grad<RHS, DISC, K, false, DC, W_SCALAR, true>(dm, g, t, rg[s], acc, gvv[s]);
-                else tile4_grad<RHS, DISC, K, false, DC, W_SCALAR, false>(dm, g, t, rg[s], acc, gvv[s]);
+                if (lsq) tile4_grad<RHS, DISC, K, false, DC, WS, true>(dm, g, t, rg[s], acc, gvv[s]);
+                else tile4_grad<RHS, DISC, K, false, DC, WS, false>(dm, g, t, rg[s], acc, gvv[s]);
             }
         }
         if (s + 1 < SUB) wave_sync_lds();     // the next sub-tile overwrites the product arrays
@@ -284,16 +307,16 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
 inline size_t eval4_lds_bytes(const Dev &dv) { return sizeof(double) * (size_t)dv.g4.NW * dv.g4.WAVE; }
 
 // launch one instantiation (the caller has checked that dv.g4 / dv.dm.maxr / dv.dm.disc match it)
-template <class RHS, int DISC, int K, int DC, bool W_SCALAR>
+template <class RHS, int DISC, int K, int DC, int WS>
 inline void launch_eval4_one(const Dev &dv, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_eval4<RHS, DISC, K, DC, W_SCALAR, 1>), dim3(eval_flat_grid(dv.dm)), dim3(256), eval4_lds_bytes(dv), s, dv);
+    hipLaunchKernelGGL((k_eval4<RHS, DISC, K, DC, WS, 1>), dim3(eval_flat_grid(dv.dm)), dim3(256), eval4_lds_bytes(dv), s, dv);
 }
-template <class RHS, int DISC, int K, int DC, bool W_SCALAR>
+template <class RHS, int DISC, int K, int DC, int WS>
 inline hipError_t prepare_eval4_one(const Dev &dv)
 {
     if (eval4_lds_bytes(dv) <= 64 * 1024) return hipSuccess;
-    return hipFuncSetAttribute((const void *)k_eval4<RHS, DISC, K, DC, W_SCALAR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return hipFuncSetAttribute((const void *)k_eval4<RHS, DISC, K, DC, WS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 }  // namespace va

@@ -81,26 +81,26 @@ static void eval3_d(const Dev &dv, EvalOp &op)
     else eval3_rhs<RHS, K, 0, 1024>(dv, op);
 }
 
-template <class RHS, int K, int DC, bool W_SCALAR, int SUB>
+template <class RHS, int K, int DC, int WS, int SUB>
 static void eval4_disc(const Dev &dv, EvalOp &op)
 {
     switch (dv.dm.disc) {
-    case DISC_EULER: eval_op(k_eval4<RHS, DISC_EULER, K, DC, W_SCALAR, SUB>, dv, 256, op); break;
-    case DISC_TRAPEZOID: eval_op(k_eval4<RHS, DISC_TRAPEZOID, K, DC, W_SCALAR, SUB>, dv, 256, op); break;
-    case DISC_SH: eval_op(k_eval4<RHS, DISC_SH, K, DC, W_SCALAR, SUB>, dv, 256, op); break;
-    default: eval_op(k_eval4<RHS, DISC_FWDMAP, K, DC, W_SCALAR, SUB>, dv, 256, op); break;
+    case DISC_EULER: eval_op(k_eval4<RHS, DISC_EULER, K, DC, WS, SUB>, dv, 256, op); break;
+    case DISC_TRAPEZOID: eval_op(k_eval4<RHS, DISC_TRAPEZOID, K, DC, WS, SUB>, dv, 256, op); break;
+    case DISC_SH: eval_op(k_eval4<RHS, DISC_SH, K, DC, WS, SUB>, dv, 256, op); break;
+    default: eval_op(k_eval4<RHS, DISC_FWDMAP, K, DC, WS, SUB>, dv, 256, op); break;
     }
 }
 
 // sub-tiles per wave: 1, or 2 / 3 for grids of a few wave-tiles per SIMD (compiled for the
 // scalar-weight variant with D fixed only: that is where such grids are the BASELINE configs)
-template <class RHS, int K, int DC, bool W_SCALAR>
+template <class RHS, int K, int DC, int WS>
 static void eval4_rhs(const Dev &dv, EvalOp &op)
 {
     // (measured at C3, SUB = 3 -- one wave per SIMD, 256 workgroups -- against SUB = 1 -- three waves
     // per SIMD: 8.7 vs 8.0 us.  A lone wave has nothing to hide its LDS and matrix-pipe latencies
     // behind, so only SUB = 1 is compiled; the kernel keeps the loop.)
-    eval4_disc<RHS, K, DC, W_SCALAR, 1>(dv, op);
+    eval4_disc<RHS, K, DC, WS, 1>(dv, op);
 }
 
 // D = 20 (examples/Lorenz96_D20, BASELINE configs 1-3) is compiled with D as a constant; scalar RM /
@@ -108,9 +108,12 @@ static void eval4_rhs(const Dev &dv, EvalOp &op)
 template <class RHS, int K>
 static void eval4_d(const Dev &dv, EvalOp &op)
 {
-    const bool ws = !dv.pp.rm_arr && !dv.pp.rf0_arr && dv.dm.nskip == 1;
-    if (dv.dm.D == 20) { if (ws) eval4_rhs<RHS, K, 20, true>(dv, op); else eval4_rhs<RHS, K, 20, false>(dv, op); }
-    else { if (ws) eval4_rhs<RHS, K, 0, true>(dv, op); else eval4_rhs<RHS, K, 0, false>(dv, op); }
+    const bool sw = !dv.pp.rm_arr && !dv.pp.rf0_arr, ws = sw && dv.dm.nskip == 1;
+    if (dv.dm.D == 20) {
+        if (ws) eval4_rhs<RHS, K, 20, 1>(dv, op);
+        else if (sw) eval4_rhs<RHS, K, 20, 2>(dv, op);        // scalar weights, data at every nskip-th row
+        else eval4_rhs<RHS, K, 20, 0>(dv, op);
+    } else { if (ws) eval4_rhs<RHS, K, 0, 1>(dv, op); else eval4_rhs<RHS, K, 0, 0>(dv, op); }
 }
 
 static void eval_dispatch(const Dev &dv, int rhs, EvalOp &op)
@@ -127,7 +130,7 @@ static void eval_dispatch(const Dev &dv, int rhs, EvalOp &op)
         case 7: eval4_d<RhsL96s, 7>(dv, op); break;
         // runs of 12 rows at two workgroups per CU (D = 20, scalar weights: Simpson-Hermite at the C3 shape in ONE round of
         // resident workgroups, see the chooser in va_capi.hip)
-        case 12: eval4_rhs<RhsL96s, 12, 20, true>(dv, op); break;
+        case 12: eval4_rhs<RhsL96s, 12, 20, 1>(dv, op); break;
         default: eval4_d<RhsL96s, 8>(dv, op); break;
         }
     } else if (dv.dm.emode == 3) {

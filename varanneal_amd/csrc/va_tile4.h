@@ -110,6 +110,7 @@ VA_HD constexpr int tile4_row(const Geo4 &g, int R) { return (R / g.K) * g.PITCH
 
 template <int K, int NE> struct T4Regs {
     double direct[K], xown[K], yv[K], wv[K], dval[K];     // direct_m + the diagonal term of J^T s; wv unused when W_SCALAR
+    unsigned has;                                         // WS == 2 only: bit k set <=> the lane's row k has an observation
 };
 
 struct Tile4 {
@@ -175,11 +176,13 @@ VA_HD void tile4_obs(const Dims &dm, const ProblemPtrs &pp, const Tile4 &t, T4Re
 
 // rows + scatter: f, residuals, q, direct, s for the lane's run in registers; publishes the products.
 // W_SCALAR: scalar RM and RF0, data at every row (the reference's Lorenz-96 example and every BASELINE
-// config): the weights factor out of the sums and the loops carry no weight registers.
-template <class RHS, int DISC, int K, bool EDGE, int DC, bool W_SCALAR>
+// config): the weights factor out of the sums and the loops carry no weight registers.  WS = 0: weight arrays,
+// 1: W_SCALAR, 2: W_SCALAR with data at every merr_nskip-th row (rows without data masked by rg.has).
+template <class RHS, int DISC, int K, bool EDGE, int DC, int WS>
 VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, const Tile4 &t,
                       T4Regs<K, RHS::NE> &rg, ThreadAcc &acc)
 {
+    constexpr bool W_SCALAR = WS != 0;                   // (WS == 2: scalar weights, data every nskip-th row -- rg.has)
     constexpr int HL = Halo<DISC>::HL, HR = Halo<DISC>::HR, NR = K + HL + HR, NQ = K + HL, NB = RHS::NB, NE = RHS::NE;
     const int D = DC > 0 ? DC : g.D, N = dm.N, PITCH = g.PITCH;
     const double dt = dm.dt;
@@ -260,7 +263,8 @@ VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, cons
         double me = 0.0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const double diff = xo[k + HL] - rg.yv[k];
+            double diff = xo[k + HL] - rg.yv[k];
+            if constexpr (WS == 2) diff = ((rg.has >> k) & 1u) ? diff : 0.0;
             if constexpr (W_SCALAR) me = fma(diff, diff, me);
             else me = fma(rg.wv[k] * diff, diff, me);
         }
@@ -309,10 +313,11 @@ VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, cons
 // gather: gradient rows of the lane's run.  LSQ: also the sums the line search needs (g.d, g.g, max|g|).
 // The K gradient values of the lane's run come back in gvv[]; the caller stores them (rows >= N of an
 // edge tile hold exact zeros and must not be stored).
-template <class RHS, int DISC, int K, bool EDGE, int DC, bool W_SCALAR, bool LSQ>
+template <class RHS, int DISC, int K, bool EDGE, int DC, int WS, bool LSQ>
 VA_HD void tile4_grad(const Dims &dm, const Geo4 &g, const Tile4 &t, const T4Regs<K, RHS::NE> &rg, ThreadAcc &acc,
                       double (&gvv)[K])
 {
+    constexpr bool W_SCALAR = WS != 0;
     constexpr int NG = RHS::NG;
     const int D = DC > 0 ? DC : g.D;
     lds_cvp rp[NG];
@@ -327,7 +332,8 @@ VA_HD void tile4_grad(const Dims &dm, const Geo4 &g, const Tile4 &t, const T4Reg
 #pragma unroll
         for (int u = 0; u < NG; ++u) r[u] = rp[u][k * D];
         double gv = rg.direct[k] + RHS::gather(r);
-        const double diff = rg.xown[k] - rg.yv[k];
+        double diff = rg.xown[k] - rg.yv[k];
+        if constexpr (WS == 2) diff = ((rg.has >> k) & 1u) ? diff : 0.0;
         if constexpr (W_SCALAR) gv = fma(c2, diff, gv);
         else gv = fma(two_cme, rg.wv[k] * diff, gv);
         // rows >= N of an edge tile: every term above is an exact zero (inputs zeroed in tile4_rows,
