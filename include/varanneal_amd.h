@@ -155,8 +155,10 @@ int va_problem_info(va_handle h, int64_t *n_var, int64_t *ld_internal, int32_t *
                               * when the problem is eligible (default); 0: always the three-launch cycle.  Same
                               * arithmetic, different order of the partial sums: results agree to rounding, not bit for bit */
 #define VA_TUNE_PERSIST_ROWS 6   /* time rows per workgroup of the persistent kernel (0: the library's choice); VA_EINVAL when not admissible */
-#define VA_TUNE_NNET_FUSED 7     /* network handles whose layers are at most 128 wide: 1 forward and state-gradient products in one
-                                 * kernel (k_nnet_fb, default), 0 the separate k_nnet_fwd + k_nnet_bwd_x */
+#define VA_TUNE_NNET_FUSED 7     /* network handles whose layers are at most 128 wide (at most 64 layers, scalar RM): 1 forward and
+                                 * state-gradient products in one kernel (k_nnet_fb), 0 the separate k_nnet_fwd + k_nnet_bwd_x.
+                                 * The library's own choice: 1 when blocks of 32 examples x seeds >= 2 x CUs and the activation is a
+                                 * built-in other than softplus.  2 + t: as 1, the first workgroups' starts spread over t us (measurement) */
 int va_problem_tune(va_handle h, int32_t what, int32_t value);
 /* 1 if va_anneal / va_minimize_lbfgs on this handle run the persistent per-seed kernel, with its geometry
  * (workgroups per seed, time rows per workgroup); 0 otherwise. */
