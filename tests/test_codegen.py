@@ -242,6 +242,14 @@ def test_eval_plan_matches_the_geometry_rules():
     assert _capi.eval_plan(1, 20, 200, "trapezoid", 2, 2, p_time_dependent=True) is None
     assert _capi.eval_plan(64, 200, 5000, "trapezoid", 0, 2) == (3, 1, 8, 256)  # C4's shape: one lane per column
     assert _capi.eval_plan(64, 200, 5000, "trapezoid", 2, 0) is None
+    # instantiations that exist for the built-in right-hand side only: Simpson-Hermite at the C3 shape in runs of 12 rows (one
+    # round of resident workgroups), merr_nskip on the scalar-weight kernel's run length (row mask instead of weight registers)
+    assert _capi.eval_plan(64, 20, 1001, "SimpsonHermite", 2, 2, builtin=True) == (4, 2, 12, 1)
+    assert _capi.eval_plan(64, 20, 1001, "SimpsonHermite", 2, 2) == (4, 2, 4, 1)
+    assert _capi.eval_plan(32, 20, 1001, "SimpsonHermite", 2, 2, builtin=True) == (4, 2, 4, 1)       # already one round
+    assert _capi.eval_plan(64, 20, 1001, "trapezoid", 2, 2, merr_nskip=2, builtin=True) == (4, 1, 7, 0)
+    assert _capi.eval_plan(64, 20, 1001, "trapezoid", 2, 2, merr_nskip=2) == (4, 1, 5, 0)
+    assert _capi.eval_plan(64, 20, 1000, "trapezoid", 2, 2, rf_array=True, builtin=True) == (4, 1, 5, 0)
     assert _capi.eval_plan(64, 2000, 500, "trapezoid", 0, 2) is None            # beyond 1024 columns: flat
 
 

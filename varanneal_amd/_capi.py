@@ -238,14 +238,18 @@ def check(rc):
 
 
 def eval_plan(batch, D, N_model, disc, ne, ghost=0, rm_array=False, rm_full=False, rf_array=False, rf_full=False,
-              merr_nskip=1, tile_rows=0, eval_kernel=0, bounded=False, p_time_dependent=False, reach=None, Lidx=None):
+              merr_nskip=1, tile_rows=0, eval_kernel=0, bounded=False, p_time_dependent=False, reach=None, Lidx=None,
+              builtin=False):
     """(eval kernel 3 | 4 | 5, disc, K, w) of the column-run kernel instantiation a problem of this shape would run
     for a model with a column form of `ne` products per element and / or a ghosted form of `ghost` ghost
     columns (0 = the model has no such form), or None (flat kernel).  w: kernel 4 -- 1 for scalar weights;
     kernel 3 -- threads per workgroup.  reach = (xl, xr, gl, gr) of the column form and Lidx (the observed columns)
-    let wide states pick the streaming kernel 5.  No GPU call (va_eval_plan / va_eval_plan_reach)."""
+    let wide states pick the streaming kernel 5.  builtin: the plan of the built-in Lorenz-96 (a few instantiations exist
+    for it alone: runs of 12 rows, the row-mask variant of merr_nskip); the default is a generated model's plan -- what
+    va_ode.py asks for before it writes a module.  No GPU call (va_eval_plan / va_eval_plan_reach)."""
     d = ProblemDesc()
     d.struct_size = C.sizeof(ProblemDesc)
+    d.rhs = 0 if builtin else 1000                        # VA_RHS_LORENZ96 / VA_RHS_USER_BASE
     d.batch, d.D, d.N_model, d.merr_nskip = batch, D, N_model, merr_nskip
     d.N_data = (N_model - 1) // merr_nskip + 1
     d.rm_kind = (2 if rm_full else 1) if rm_array else 0
