@@ -266,6 +266,17 @@ void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_
             }
             // the device picks the scalar-weight variant exactly like this (va_kernels.hip: eval4_d)
             const bool ws = !E.pp.rm_arr && !E.pp.rf0_arr && dm.nskip == 1;
+            if (!ws && E.pp.rf0_arr) {
+                // RF0 arrays: every lane parks its weights in its own slots of the product arrays (k_eval4 does so after
+                // the trial point is formed)
+                if constexpr (tile4_rfw_in_lds<K, NE, HL, 0>()) {            // (the emulator runs the generic-D instantiations: never)
+                    for (int l = 0; l < NL; ++l) {
+                        double wq[K + HL];
+                        tile4_rfw_load<K, HL>(dm, E.pp, th[l], D, wq);
+                        tile4_rfw_store<K, HL>(g, th[l], D, wq);
+                    }
+                }
+            }
             for (int l = 0; l < NL; ++l) {
                 if (ws) {
                     if (edge) tile4_rows<RHS, DISC, K, true, 0, true>(dm, E.pp, g, th[l], rg[l], acc[l]);

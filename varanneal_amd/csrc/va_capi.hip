@@ -263,11 +263,12 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
             if (sh && (K & 1)) ++K;
         }
         // weight arrays / data every nskip-th row: runs of 6 and 7 rows do not fit three waves per SIMD's 168 registers
-        // with their weight registers (18-59 spilled; measured at the C3 shape, profiles/r03_f3_variants.txt: 21 us
-        // against 13 us for K = 5): those problems run K <= 5, or 8 at two waves per SIMD
+        // with their weight registers (35-58 spilled; measured at the C3 shape, profiles/r03_f3_variants.txt: 21 us
+        // against 13 us for K = 5): those problems run K <= 5, or 8 at two waves per SIMD -- except the built-in
+        // right-hand side at D = 20, whose instantiations park the RF weights in LDS, fold the RM weights into the data
+        // registers before the f evaluations (va_tile4.h) and mask merr_nskip's rows by a bit each
         {
-            // (D = 20 with scalar weights and data at every nskip-th row has a variant of its own without weight registers)
-            const bool ws4 = d->rm_kind == 0 && d->rf_kind == 0 && (d->merr_nskip == 1 || (D == 20 && d->rhs == VA_RHS_LORENZ96));
+            const bool ws4 = (d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1) || (D == 20 && d->rhs == VA_RHS_LORENZ96);
             if (!ws4 && (K == 6 || K == 7)) K = sh ? 4 : 5;
         }
         // column forms with many products per element (a ring of coupled units: 8): the product arrays grow with the run

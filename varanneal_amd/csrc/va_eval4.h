@@ -143,6 +143,20 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
             tile4_obs<K, NE>(dm, dv.pp, ts, rg[s]);
         }
     }
+    // RF0 arrays: the lane's weights, requested with everything else (parked in the product arrays below: va_tile4.h)
+    static_assert(SUB == 1 || WS != 0, "sub-tiles are compiled for the scalar-weight variants only");
+    constexpr bool RFW = WS == 0 && tile4_rfw_in_lds<K, NE, HL, DC>();
+    double wq[SUB][K + HL];
+    if constexpr (RFW) {
+        if (dv.pp.rf0_arr && active) {
+#pragma unroll
+            for (int s = 0; s < SUB; ++s) {
+                Tile4 ts = t;
+                ts.r0 = t.r0 + s * RK;
+                tile4_rfw_load<K, HL>(dm, dv.pp, ts, D, wq[s]);
+            }
+        }
+    }
 
     VA_E4_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the wave's images have landed
@@ -189,6 +203,10 @@ __global__ __launch_bounds__(256, SUB > 1 ? 1 : ((K <= 7 && K * RHS::NB <= 28) ?
             for (int k = 0; k < K; ++k) rg[s].dval[k] = 0.0;
     }
     const bool lsq = dv.epi != EPI_FINALIZE;                                  // launch-uniform
+    if constexpr (RFW) {
+        // (the d image in the second region is dead now; every lane writes and later reads its own slots only)
+        if (dv.pp.rf0_arr && active) tile4_rfw_store<K, HL>(g, t, D, wq[0]);
+    }
     unsigned old = 0;
     double gvv[SUB][K];                       // the gradient stays in registers until the partial sums are out
     // The workgroup's row of partial sums: every wave reduces through the matrix pipe (max|g| through

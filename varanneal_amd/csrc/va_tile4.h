@@ -174,6 +174,33 @@ VA_HD void tile4_obs(const Dims &dm, const ProblemPtrs &pp, const Tile4 &t, T4Re
     }
 }
 
+// Per-row, per-column model-error weights (RF0 arrays) of the lane's K + HL residual rows.  They are needed after the
+// f evaluations of tile4_rows, whose registers they must not occupy meanwhile, and fetched there they cost a round trip in
+// the middle of the phase: the lane requests them early (tile4_rfw_load, with its observations), parks them in ITS OWN
+// slots of the product arrays (tile4_rfw_store: slot (e, k) of the lane holds weight e * K + k -- nobody else touches
+// those slots before the lane itself overwrites them with its products) and reads them back where the residuals are formed.
+// (D a compile-time constant only: with D in a register the parked weights cost the generic instantiations 30+ registers)
+template <int K, int NE, int HL, int DC> constexpr bool tile4_rfw_in_lds() { return DC > 0 && NE * K >= K + HL; }
+// weight arrays, D a compile-time constant: the measurement terms are formed at the top of tile4_rows (same reason)
+template <int WS, int DC> constexpr bool tile4_me_first() { return WS == 0 && DC > 0; }
+template <int K, int HL>
+VA_HD void tile4_rfw_load(const Dims &dm, const ProblemPtrs &pp, const Tile4 &t, int D, double (&wq)[K + HL])
+{
+#pragma unroll
+    for (int j = 0; j < K + HL; ++j) {
+        const int row = t.r0 - HL + j;
+        const int rc = row < 0 ? 0 : (row > dm.N - 2 ? dm.N - 2 : row);    // clamped; the residual is 0 there anyway
+        wq[j] = pp.rf0_arr[(size_t)rc * D + t.tx];
+    }
+}
+template <int K, int HL>
+VA_HD void tile4_rfw_store(const Geo4 &g, const Tile4 &t, int D, const double (&wq)[K + HL])
+{
+    double *ep = t.es + t.a * g.PITCH + t.tx;
+#pragma unroll
+    for (int j = 0; j < K + HL; ++j) ep[(j / K) * g.EW1 + (j % K) * D] = wq[j];
+}
+
 // rows + scatter: f, residuals, q, direct, s for the lane's run in registers; publishes the products.
 // W_SCALAR: scalar RM and RF0, data at every row (the reference's Lorenz-96 example and every BASELINE
 // config): the weights factor out of the sums and the loops carry no weight registers.  WS = 0: weight arrays,
@@ -191,6 +218,21 @@ VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, cons
     lds_cvp xnp[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) xnp[k] = VA_LDS_CVP(t.xs + t.a * PITCH + wrap_col(t.tx + RHS::nb_off(k), D));
+    if constexpr (tile4_me_first<WS, DC>()) {
+        // weight arrays: the measurement terms first -- w (x - y) takes the data registers' place and the weights die
+        // before the f evaluations below (whose registers are the kernel's peak); the gather phase adds 2 cme w (x - y)
+        double me = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int j = k + HL;
+            double xk = x0p[j < K ? j * D : PITCH + (j - K) * D];
+            if (EDGE) xk = (t.r0 + k < N) ? xk : 0.0;
+            const double diff = xk - rg.yv[k], dw = rg.wv[k] * diff;
+            me = fma(dw, diff, me);
+            rg.yv[k] = dw;
+        }
+        acc.v[EP_ME] += me;
+    }
     double xo[NR], fo[NR], q[NQ];
     double xnb[K][NB];                                   // neighbour values of the own rows (for the products)
     double tm[NR];                                       // model time of the rows (non-autonomous right-hand sides only)
@@ -249,8 +291,12 @@ VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, cons
         } else {
             double w = dm.rf0;
             if (pp.rf0_arr) {
-                int rc = row < 0 ? 0 : (row > N - 2 ? N - 2 : row);    // clamped; r = 0 there anyway
-                w = pp.rf0_arr[(size_t)rc * D + t.tx];
+                // (tile4_rfw_store put it there; a volatile read: it stays below the f evaluations, where the registers are free)
+                if constexpr (tile4_rfw_in_lds<K, NE, HL, DC>()) w = VA_LDS_CVP(t.es + t.a * PITCH + t.tx)[(j / K) * g.EW1 + (j % K) * D];
+                else {
+                    int rc = row < 0 ? 0 : (row > N - 2 ? N - 2 : row);    // clamped; r = 0 there anyway
+                    w = pp.rf0_arr[(size_t)rc * D + t.tx];
+                }
             }
             const double wr = w * r;
             q[j] = t.c * wr;
@@ -258,7 +304,7 @@ VA_HD void tile4_rows(const Dims &dm, const ProblemPtrs &pp, const Geo4 &g, cons
         }
     }
     acc.v[EP_FE] += W_SCALAR ? dm.rf0 * fe : fe;
-    {   // measurement error of the own rows (A needs nothing from the gather phase: a plain S1
+    if constexpr (!tile4_me_first<WS, DC>()) {   // measurement error of the own rows (A needs nothing from the gather phase: a plain S1
         // evaluation publishes its partial sums right after this function)
         double me = 0.0;
 #pragma unroll
@@ -332,10 +378,13 @@ VA_HD void tile4_grad(const Dims &dm, const Geo4 &g, const Tile4 &t, const T4Reg
 #pragma unroll
         for (int u = 0; u < NG; ++u) r[u] = rp[u][k * D];
         double gv = rg.direct[k] + RHS::gather(r);
-        double diff = rg.xown[k] - rg.yv[k];
-        if constexpr (WS == 2) diff = ((rg.has >> k) & 1u) ? diff : 0.0;
-        if constexpr (W_SCALAR) gv = fma(c2, diff, gv);
-        else gv = fma(two_cme, rg.wv[k] * diff, gv);
+        if constexpr (tile4_me_first<WS, DC>()) gv = fma(two_cme, rg.yv[k], gv);          // (tile4_rows left w (x - y) there)
+        else {
+            double diff = rg.xown[k] - rg.yv[k];
+            if constexpr (WS == 2) diff = ((rg.has >> k) & 1u) ? diff : 0.0;
+            if constexpr (W_SCALAR) gv = fma(c2, diff, gv);
+            else gv = fma(two_cme, rg.wv[k] * diff, gv);
+        }
         // rows >= N of an edge tile: every term above is an exact zero (inputs zeroed in tile4_rows,
         // observation loads return 0 there)
         gvv[k] = gv;
