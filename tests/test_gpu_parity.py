@@ -348,6 +348,44 @@ def test_runs_of_twelve_rows(capi, disc, N):
         assert np.abs(g[b] - go).max() <= RTOL_G * np.abs(go).max()
 
 
+@pytest.mark.parametrize("disc,N,nskip", [("trapezoid", 1000, 1), ("euler", 1000, 1), ("forwardmap", 1000, 1), ("trapezoid", 1001, 2),
+                                          ("SimpsonHermite", 1001, 1)])
+def test_weight_arrays_at_the_c3_shape(capi, disc, N, nskip):
+    """RF0 and RM arrays (and data at every nskip-th row) on k_eval4 at 64 seeds: the built-in right-hand side at D = 20 parks
+    the RF weights in LDS and folds the RM weights into its data registers, which lets it run the scalar kernel's run length
+    (7 rows; Simpson-Hermite 4) -- against the oracle, and through a minimisation against runs of 4 rows"""
+    import va_oracle
+    from varanneal_amd import twin
+    D, B = 20, 64
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    Y = Y[::nskip]
+    XP = np.empty((B, N * D + 1)); P = np.empty((B, 1))
+    for b in range(B):
+        X0, P0 = twin.initial_guess(N, D, b)
+        XP[b, :-1] = X0.ravel(); XP[b, -1] = P0[0]; P[b] = P0
+    RF0 = np.resize(4e-6 * (1.0 + 0.1 * np.arange(D)), (N - 1, D)) * (1.0 + 0.001 * np.arange(N - 1))[:, None]
+    RM = np.resize(4.0 * (1.0 + 0.1 * np.arange(len(Lidx))), Y.shape) * (1.0 + 0.002 * np.arange(Y.shape[0]))[:, None]
+    rf = 1.5 ** 14
+    opts = {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000, 'maxiter': 6}
+    with capi.Problem(B, D, N, Y, Lidx, twin.DT, RM, RF0, P, [0], disc=disc, merr_nskip=nskip) as pb:
+        info = pb.info()
+        assert (info["eval_kernel"], info["run_rows"]) == (4, 4 if disc == "SimpsonHermite" else 7), info
+        A, me, fe, g = pb.action_grad(XP, rf)
+        r = pb.minimize_lbfgs(XP, rf, opts)
+    with capi.Problem(B, D, N, Y, Lidx, twin.DT, RM, RF0, P, [0], disc=disc, merr_nskip=nskip, tile_rows=48) as pb4:
+        assert pb4.info()["run_rows"] == 4
+        A4, me4, fe4, g4 = pb4.action_grad(XP, rf)
+        r4 = pb4.minimize_lbfgs(XP, rf, opts)
+    assert np.all(np.abs(A - A4) <= 1e-13 * np.abs(A4)) and np.abs(g - g4).max() <= 1e-12 * np.abs(g4).max()
+    assert np.array_equal(r["nit"], r4["nit"]) and np.array_equal(r["nfev"], r4["nfev"])
+    assert np.all(np.abs(r["A"] - r4["A"]) <= 1e-10 * np.abs(r4["A"]))
+    for b in (0, 31, B - 1):
+        ob = va_oracle.Problem(D, N, Y, Lidx, twin.DT, RM, RF0, P[b], [0], disc=disc, merr_nskip=nskip)
+        Ao, meo, feo, go = ob.action_grad(XP[b], rf)
+        assert abs(A[b] - Ao) <= RTOL_A * abs(Ao) and abs(me[b] - meo) <= RTOL_A * abs(Ao) and abs(fe[b] - feo) <= RTOL_A * abs(feo)
+        assert np.abs(g[b] - go).max() <= RTOL_G * np.abs(go).max()
+
+
 def test_c4_shape_properties(capi):
     """BASELINE config 4 per-GPU shape (D=200, N=5000, L=80, 64 seeds; n_var = 1,000,001):
     two seeds against the oracle, the rest through size-independent properties."""
