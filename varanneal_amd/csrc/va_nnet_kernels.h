@@ -591,15 +591,35 @@ __global__ __launch_bounds__(NN_FB_THREADS, NN_FB_WGS) void k_nnet_fb(const Dev 
         if (n + 2 <= NL - 1) request_x(n + 2);                 // (transition n + 1's; its q, delta are formed two phases from here)
         FB_MARK(5);
         const bool measured = n == 0 || last;                   // (uniform: the layers between carry no measurement term)
+        // the measurement terms of the input / output layer: per column block, every operand is requested before the first is
+        // used (fetched element by element they cost the two layers 16 memory round trips each: ~15 us a layer); the output
+        // layer's states are still in LDS (epilogue A of the last transition put them there)
+        const int *lm = n == 0 ? nn.lmap_in : nn.lmap_out;
+        const double *dat = n == 0 ? nn.din : nn.dout;
+        const int L = n == 0 ? nn.Lin : nn.Lout;
+        const double mrm = measured ? (n == 0 ? nn.rm_in : nn.rm_out) : 0.0, mc = 2.0 * dv.dm.cme * mrm;
 #pragma unroll
         for (int c2 = 0; c2 < CW; ++c2) {
             const int col = (cb0 + c2) * 16 + lo;
+            d4 mdiff[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) mdiff[rb] = d4{0.0, 0.0, 0.0, 0.0};
+            if (measured) {
+                const int l = col < sn ? lm[col] : -1;
+                d4 mx[RB], my[RB];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ml = rb * 16 + hi + 4 * r;
+                        const bool on = l >= 0 && ml < nra;
+                        my[rb][r] = on ? dat[(size_t)(m0 + ml) * L + l] : 0.0;
+                        mx[rb][r] = !on ? 0.0 : (last ? Xs[ml * PX + col] : Xg[(m0 + ml) * nn.NDnet + offn + col]);
+                    }
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) mdiff[rb] = mx[rb] - my[rb];
+            }
             if (col < sn) {
-                int l = -1; double rm = 0.0; const double *dat = nullptr; int L = 0;
-                if (measured) {
-                    if (n == 0) { l = nn.lmap_in[col]; rm = nn.rm_in; dat = nn.din; L = nn.Lin; }
-                    else { l = nn.lmap_out[col]; rm = nn.rm_out; dat = nn.dout; L = nn.Lout; }
-                }
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -607,12 +627,9 @@ __global__ __launch_bounds__(NN_FB_THREADS, NN_FB_WGS) void k_nnet_fb(const Dev 
                         const int ml = rb * 16 + hi + 4 * r;
                         if (ml >= nra) continue;
                         const int e = (m0 + ml) * nn.NDnet + offn + col;
-                        double gv = g[c2][rb][r];
-                        if (measured && l >= 0) {
-                            const double diff = Xg[e] - dat[(size_t)(m0 + ml) * L + l];
-                            v_me += rm * diff * diff;
-                            gv += 2.0 * dv.dm.cme * rm * diff;
-                        }
+                        const double diff = mdiff[rb][r];                 // (0 where nothing is measured)
+                        v_me += mrm * diff * diff;
+                        const double gv = g[c2][rb][r] + mc * diff;
 #if !defined(VA_FB_ABL) || VA_FB_ABL != 1
                         gtg[e] = gv;
 #endif
