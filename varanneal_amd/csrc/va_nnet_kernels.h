@@ -440,6 +440,39 @@ __global__ __launch_bounds__(NN_FB_THREADS, NN_FB_WGS) void k_nnet_fb(const Dev 
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) qprev[c2][rb] = d4{0.0, 0.0, 0.0, 0.0};
     double v_me = 0.0, v_fe = 0.0, v_gtd = 0.0, v_gn2 = 0.0, v_gmax = 0.0;
+    {
+        // the input layer's measurement term: dA/dx_0 = delta_0 W_0 + 2 cme RM (x_0 - d_in).  It rides in the accumulators the
+        // second product of the first transition starts from (q of a transition before the first: zero otherwise); x_0 is in
+        // LDS, the data are requested all at once while nothing else is live
+        const int s0 = meta[0], Lin = nn.Lin;
+        const double mc = 2.0 * dv.dm.cme * nn.rm_in;
+        int lc[CW];
+#pragma unroll
+        for (int c2 = 0; c2 < CW; ++c2) { const int col = (cb0 + c2) * 16 + lo; lc[c2] = col < s0 ? nn.lmap_in[col] : -1; }
+        d4 my[CW][RB];
+#pragma unroll
+        for (int c2 = 0; c2 < CW; ++c2)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ml = rb * 16 + hi + 4 * r;
+                    my[c2][rb][r] = (lc[c2] >= 0 && ml < nra) ? nn.din[(size_t)(m0 + ml) * Lin + lc[c2]] : 0.0;
+                }
+#pragma unroll
+        for (int c2 = 0; c2 < CW; ++c2) {
+            const int col = (cb0 + c2) * 16 + lo;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ml = rb * 16 + hi + 4 * r;
+                    const double diff = (lc[c2] >= 0 && ml < nra) ? Xs[ml * PX + col] - my[c2][rb][r] : 0.0;
+                    v_me += nn.rm_in * diff * diff;
+                    qprev[c2][rb][r] = mc * diff;
+                }
+        }
+    }
     for (int n = 0; n <= NL - 1; ++n) {
         const int sn = meta[n], offn = meta[NN_FB_LAYERS + n];
         const bool last = n == NL - 1;
@@ -590,14 +623,14 @@ __global__ __launch_bounds__(NN_FB_THREADS, NN_FB_WGS) void k_nnet_fb(const Dev 
         }
         if (n + 2 <= NL - 1) request_x(n + 2);                 // (transition n + 1's; its q, delta are formed two phases from here)
         FB_MARK(5);
-        const bool measured = n == 0 || last;                   // (uniform: the layers between carry no measurement term)
+        const bool measured = last;                             // (the input layer's term came in through qprev, the hidden layers have none)
         // the measurement terms of the input / output layer: per column block, every operand is requested before the first is
         // used (fetched element by element they cost the two layers 16 memory round trips each: ~15 us a layer); the output
         // layer's states are still in LDS (epilogue A of the last transition put them there)
-        const int *lm = n == 0 ? nn.lmap_in : nn.lmap_out;
-        const double *dat = n == 0 ? nn.din : nn.dout;
-        const int L = n == 0 ? nn.Lin : nn.Lout;
-        const double mrm = measured ? (n == 0 ? nn.rm_in : nn.rm_out) : 0.0, mc = 2.0 * dv.dm.cme * mrm;
+        const int *lm = nn.lmap_out;
+        const double *dat = nn.dout;
+        const int L = nn.Lout;
+        const double mrm = measured ? nn.rm_out : 0.0, mc = 2.0 * dv.dm.cme * mrm;
 #pragma unroll
         for (int c2 = 0; c2 < CW; ++c2) {
             const int col = (cb0 + c2) * 16 + lo;
