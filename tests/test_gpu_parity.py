@@ -386,6 +386,38 @@ def test_weight_arrays_at_the_c3_shape(capi, disc, N, nskip):
         assert np.abs(g[b] - go).max() <= RTOL_G * np.abs(go).max()
 
 
+@pytest.mark.parametrize("disc,N,nskip", [("trapezoid", 1001, 2), ("SimpsonHermite", 1001, 2), ("euler", 1000, 3)])
+def test_sparse_data_with_scalar_weights_at_the_c3_shape(capi, disc, N, nskip):
+    """data at every nskip-th row, scalar RM / RF0, 64 seeds: the scalar-weight kernel with one mask bit per row (no weight
+    registers: the scalar kernel's run length) against the oracle and against runs of 4 rows, evaluation and minimisation"""
+    import va_oracle
+    from varanneal_amd import twin
+    D, B = 20, 64
+    t, Y, _, Lidx = twin.make_twin(D, N)
+    Y = Y[::nskip]
+    XP = np.empty((B, N * D + 1)); P = np.empty((B, 1))
+    for b in range(B):
+        X0, P0 = twin.initial_guess(N, D, b)
+        XP[b, :-1] = X0.ravel(); XP[b, -1] = P0[0]; P[b] = P0
+    rf = 1.5 ** 14
+    opts = {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000, 'maxiter': 6}
+    with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc=disc, merr_nskip=nskip) as pb:
+        info = pb.info()
+        assert info["eval_kernel"] == 4 and info["run_rows"] in ((4, 6) if disc == "SimpsonHermite" else (7,)), info
+        A, me, fe, g = pb.action_grad(XP, rf)
+        r = pb.minimize_lbfgs(XP, rf, opts)
+    with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc=disc, merr_nskip=nskip, tile_rows=48) as pb4:
+        A4, me4, fe4, g4 = pb4.action_grad(XP, rf)
+        r4 = pb4.minimize_lbfgs(XP, rf, opts)
+    assert np.all(np.abs(A - A4) <= 1e-13 * np.abs(A4)) and np.abs(g - g4).max() <= 1e-12 * np.abs(g4).max()
+    assert np.array_equal(r["nit"], r4["nit"]) and np.array_equal(r["nfev"], r4["nfev"])
+    for b in (0, 40, B - 1):
+        ob = va_oracle.Problem(D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P[b], [0], disc=disc, merr_nskip=nskip)
+        Ao, meo, feo, go = ob.action_grad(XP[b], rf)
+        assert abs(A[b] - Ao) <= RTOL_A * abs(Ao) and abs(me[b] - meo) <= RTOL_A * abs(Ao) and abs(fe[b] - feo) <= RTOL_A * abs(feo)
+        assert np.abs(g[b] - go).max() <= RTOL_G * np.abs(go).max()
+
+
 def test_c4_shape_properties(capi):
     """BASELINE config 4 per-GPU shape (D=200, N=5000, L=80, 64 seeds; n_var = 1,000,001):
     two seeds against the oracle, the rest through size-independent properties."""
