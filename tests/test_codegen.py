@@ -249,6 +249,7 @@ def test_eval_plan_matches_the_geometry_rules():
     assert _capi.eval_plan(32, 20, 1001, "SimpsonHermite", 2, 2, builtin=True) == (4, 2, 4, 1)       # already one round
     assert _capi.eval_plan(64, 20, 1001, "trapezoid", 2, 2, merr_nskip=2, builtin=True) == (4, 1, 7, 0)
     assert _capi.eval_plan(64, 20, 1001, "trapezoid", 2, 2, merr_nskip=2) == (4, 1, 5, 0)
+    assert _capi.eval_plan(64, 20, 1001, "SimpsonHermite", 2, 2, merr_nskip=2, builtin=True) == (4, 2, 12, 0)
     assert _capi.eval_plan(64, 20, 1000, "trapezoid", 2, 2, rf_array=True, builtin=True) == (4, 1, 7, 0)    # (weights parked in LDS)
     assert _capi.eval_plan(64, 20, 1000, "trapezoid", 2, 2, rf_array=True) == (4, 1, 5, 0)
     assert _capi.eval_plan(64, 2000, 500, "trapezoid", 0, 2) is None            # beyond 1024 columns: flat

@@ -403,7 +403,7 @@ def test_sparse_data_with_scalar_weights_at_the_c3_shape(capi, disc, N, nskip):
     opts = {'gtol': 1e-8, 'ftol': 1e-8, 'maxfun': 1000, 'maxiter': 6}
     with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc=disc, merr_nskip=nskip) as pb:
         info = pb.info()
-        assert info["eval_kernel"] == 4 and info["run_rows"] in ((4, 6) if disc == "SimpsonHermite" else (7,)), info
+        assert info["eval_kernel"] == 4 and info["run_rows"] == (12 if disc == "SimpsonHermite" else 7), info
         A, me, fe, g = pb.action_grad(XP, rf)
         r = pb.minimize_lbfgs(XP, rf, opts)
     with capi.Problem(B, D, N, Y, Lidx, twin.DT, 4.0, 4e-6, P, [0], disc=disc, merr_nskip=nskip, tile_rows=48) as pb4:

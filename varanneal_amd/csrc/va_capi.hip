@@ -254,11 +254,11 @@ void pick_eval_geometry(const va_problem_desc *d, Dims &dm, Geo4 &g4, int ne, in
             // grid in ONE round of resident workgroups -- a launch of this size is a chain of latencies, not of rows: N = 1001,
             // 64 seeds: K = 4 -> 21 tiles, 1.75 rounds, 11.3 us; K = 12 -> 7 tiles, 448 workgroups, 9.4 us (trapezoid at K = 7: 8.6)
             // (measured for the built-in right-hand side: a generated model keeps the chooser's K unless asked)
-            if (sh && D == 20 && d->rhs == VA_RHS_LORENZ96 && d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1 && ntl(12) <= 2 * 256 && ntl(K) > 3 * 256) K = 12;
+            if (sh && D == 20 && d->rhs == VA_RHS_LORENZ96 && d->rm_kind == 0 && d->rf_kind == 0 && ntl(12) <= 2 * 256 && ntl(K) > 3 * 256) K = 12;
         }
         if (d->tile_rows > 0) {
             K = (d->tile_rows + rows1 - 1) / rows1;
-            const bool k12 = D == 20 && d->rm_kind == 0 && d->rf_kind == 0 && d->merr_nskip == 1;     // (the one longer run compiled)
+            const bool k12 = D == 20 && d->rm_kind == 0 && d->rf_kind == 0 && (d->merr_nskip == 1 || d->rhs == VA_RHS_LORENZ96);     // (the one longer run compiled)
             K = K < 4 ? 4 : (K >= 12 && k12 ? 12 : (K > 8 ? 8 : K));
             if (sh && (K & 1)) ++K;
         }

@@ -128,9 +128,9 @@ static void eval_dispatch(const Dev &dv, int rhs, EvalOp &op)
         case 5: eval4_d<RhsL96s, 5>(dv, op); break;
         case 6: eval4_d<RhsL96s, 6>(dv, op); break;
         case 7: eval4_d<RhsL96s, 7>(dv, op); break;
-        // runs of 12 rows at two workgroups per CU (D = 20, scalar weights: Simpson-Hermite at the C3 shape in ONE round of
-        // resident workgroups, see the chooser in va_capi.hip)
-        case 12: eval4_rhs<RhsL96s, 12, 20, 1>(dv, op); break;
+        // runs of 12 rows at two workgroups per CU (D = 20, scalar weights, data at every row or every nskip-th: Simpson-Hermite at
+        // the C3 shape in ONE round of resident workgroups, see the chooser in va_capi.hip)
+        case 12: if (dv.dm.nskip == 1) eval4_rhs<RhsL96s, 12, 20, 1>(dv, op); else eval4_rhs<RhsL96s, 12, 20, 2>(dv, op); break;
         default: eval4_d<RhsL96s, 8>(dv, op); break;
         }
     } else if (dv.dm.emode == 3) {
