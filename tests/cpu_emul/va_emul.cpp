@@ -213,9 +213,12 @@ void eval_seed3(const Emul &E, int b, const double *x, const double *d, int use_
 
 // K1, wave-private column runs (va_tile4.h): every wave stages its own image through the piece
 // map the direct-to-LDS loads use (bounds-checked here), then rows / scatter / gather
-template <class RHS, int DISC, int K>
-void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
-                double rf_scale, double *gt, double *ev)
+// DC, WS: the instantiation the device runs (va_kernels.hip: eval4_d) -- D = 20 as a compile-time constant (weight arrays:
+// RF weights parked in the product arrays, measurement terms formed first), WS = 0 weight arrays / 1 scalar weights /
+// 2 scalar weights with data at every nskip-th row (row mask)
+template <class RHS, int DISC, int K, int DC, int WS>
+void eval_seed4_v(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
+                  double rf_scale, double *gt, double *ev)
 {
     const Dims &dm = E.dm;
     const Geo4 &g = E.g4;
@@ -235,7 +238,7 @@ void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_
         for (int ws_ = 0; ws_ < g.NW * g.SUB; ++ws_) {    // (wave, sub-tile): a wave's sub-tiles are consecutive
             const int n0w = tile * g.T + ws_ * g.RW * K;
             const long src0 = guard + (long)(n0w - HL) * D;
-            for (int q = 0; q < T4_NI_MAX * 64; ++q) {
+            for (int q = 0; q < ((g.XP + 63) / 64) * 64; ++q) {
                 const int sp = tile4_src_piece(g, q);
                 if (sp < 0) continue;
                 const long si = src0 + 2L * sp;
@@ -259,17 +262,26 @@ void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_
                 for (int k = 0; k < RHS_MAX_NP; ++k) c.p[k] = tmp.p[k];
                 acc[l].clear();
                 tile4_obs<K, NE>(dm, E.pp, c, rg[l]);
+                if (WS == 2) {
+                    // the row-mask variant: observations as k_eval4 loads them (0 where there is none) and one bit per row with data
+                    unsigned has = 0u;
+                    for (int k = 0; k < K; ++k) {
+                        const int m = c.r0 + k, nd = m / dm.nskip;
+                        const bool h = c.l >= 0 && nd * dm.nskip == m && nd < dm.N_data && m < dm.N;
+                        rg[l].yv[k] = h ? E.pp.Y[(size_t)nd * dm.L + c.l] : 0.0;
+                        has |= h ? (1u << k) : 0u;
+                    }
+                    rg[l].has = has;
+                }
                 for (int k = 0; k < K; ++k) {
                     const long gi = (long)(c.r0 + k) * D + c.tx;
                     rg[l].dval[k] = (use_d && c.r0 + k < dm.N) ? d[gi] : 0.0;
                 }
             }
-            // the device picks the scalar-weight variant exactly like this (va_kernels.hip: eval4_d)
-            const bool ws = !E.pp.rm_arr && !E.pp.rf0_arr && dm.nskip == 1;
-            if (!ws && E.pp.rf0_arr) {
+            if (WS == 0 && E.pp.rf0_arr) {
                 // RF0 arrays: every lane parks its weights in its own slots of the product arrays (k_eval4 does so after
                 // the trial point is formed)
-                if constexpr (tile4_rfw_in_lds<K, NE, HL, 0>()) {            // (the emulator runs the generic-D instantiations: never)
+                if constexpr (tile4_rfw_in_lds<K, NE, HL, DC>()) {
                     for (int l = 0; l < NL; ++l) {
                         double wq[K + HL];
                         tile4_rfw_load<K, HL>(dm, E.pp, th[l], D, wq);
@@ -278,23 +290,13 @@ void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_
                 }
             }
             for (int l = 0; l < NL; ++l) {
-                if (ws) {
-                    if (edge) tile4_rows<RHS, DISC, K, true, 0, true>(dm, E.pp, g, th[l], rg[l], acc[l]);
-                    else tile4_rows<RHS, DISC, K, false, 0, true>(dm, E.pp, g, th[l], rg[l], acc[l]);
-                } else {
-                    if (edge) tile4_rows<RHS, DISC, K, true, 0, false>(dm, E.pp, g, th[l], rg[l], acc[l]);
-                    else tile4_rows<RHS, DISC, K, false, 0, false>(dm, E.pp, g, th[l], rg[l], acc[l]);
-                }
+                if (edge) tile4_rows<RHS, DISC, K, true, DC, WS>(dm, E.pp, g, th[l], rg[l], acc[l]);
+                else tile4_rows<RHS, DISC, K, false, DC, WS>(dm, E.pp, g, th[l], rg[l], acc[l]);
             }
             for (int l = 0; l < NL; ++l) {
                 double gvv[K];
-                if (ws) {
-                    if (edge) tile4_grad<RHS, DISC, K, true, 0, true, true>(dm, g, th[l], rg[l], acc[l], gvv);
-                    else tile4_grad<RHS, DISC, K, false, 0, true, true>(dm, g, th[l], rg[l], acc[l], gvv);
-                } else {
-                    if (edge) tile4_grad<RHS, DISC, K, true, 0, false, true>(dm, g, th[l], rg[l], acc[l], gvv);
-                    else tile4_grad<RHS, DISC, K, false, 0, false, true>(dm, g, th[l], rg[l], acc[l], gvv);
-                }
+                if (edge) tile4_grad<RHS, DISC, K, true, DC, WS, true>(dm, g, th[l], rg[l], acc[l], gvv);
+                else tile4_grad<RHS, DISC, K, false, DC, WS, true>(dm, g, th[l], rg[l], acc[l], gvv);
                 for (int k = 0; k < K; ++k) {
                     if (th[l].r0 + k < dm.N) gt[(long)(th[l].r0 + k) * D + th[l].tx] = gvv[k];
                     else if (gvv[k] != 0.0) { fprintf(stderr, "emul: row %d col %d beyond N has gradient %g\n", th[l].r0 + k, th[l].tx, gvv[k]); abort(); }          // rows that do not exist must come out as exact zeros
@@ -308,6 +310,33 @@ void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_
         }
 }
 
+template <class RHS, int DISC, int K>
+void eval_seed4(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
+                double rf_scale, double *gt, double *ev)
+{
+    // the instantiation the device picks (va_kernels.hip: eval4_d; generated modules: va_user_rhs.hip)
+    const bool sw = !E.pp.rm_arr && !E.pp.rf0_arr, ws = sw && E.dm.nskip == 1;
+    const bool builtin = E.rhs < VA_RHS_USER_BASE;
+    if (E.dm.D == 20) {
+        if (ws) eval_seed4_v<RHS, DISC, K, 20, 1>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (sw && builtin) eval_seed4_v<RHS, DISC, K, 20, 2>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else eval_seed4_v<RHS, DISC, K, 20, 0>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+    } else if (ws) eval_seed4_v<RHS, DISC, K, 0, 1>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+    else eval_seed4_v<RHS, DISC, K, 0, 0>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+}
+
+#if defined(VA_USER_RHS_HEADER) && defined(VA_USER_COL)
+// a generated module compiles k_eval4 with ITS D as the constant, scalar weights or weight arrays (va_user_rhs.hip)
+template <int DISC, int K>
+void eval_seed4_user(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
+                     double rf_scale, double *gt, double *ev)
+{
+    const bool ws = !E.pp.rm_arr && !E.pp.rf0_arr && E.dm.nskip == 1;
+    if (ws) eval_seed4_v<RhsUserCol, DISC, K, RhsUserCol::D, 1>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+    else eval_seed4_v<RhsUserCol, DISC, K, RhsUserCol::D, 0>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+}
+#endif
+
 template <int DISC>
 void eval_seed_rhs(const Emul &E, int b, const double *x, const double *d, int use_d, double stp,
                    double rf_scale, double *gt, double *ev)
@@ -315,11 +344,11 @@ void eval_seed_rhs(const Emul &E, int b, const double *x, const double *d, int u
 #ifdef VA_USER_RHS_HEADER
 #ifdef VA_USER_COL
     if (E.rhs >= VA_RHS_USER_BASE && E.dm.emode == 4) {
-        if (E.dm.maxr == 4) eval_seed4<RhsUserCol, DISC, 4>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
-        else if (E.dm.maxr == 5) eval_seed4<RhsUserCol, DISC, 5>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
-        else if (E.dm.maxr == 6) eval_seed4<RhsUserCol, DISC, 6>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
-        else if (E.dm.maxr == 7) eval_seed4<RhsUserCol, DISC, 7>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
-        else eval_seed4<RhsUserCol, DISC, 8>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        if (E.dm.maxr == 4) eval_seed4_user<DISC, 4>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 5) eval_seed4_user<DISC, 5>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 6) eval_seed4_user<DISC, 6>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 7) eval_seed4_user<DISC, 7>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else eval_seed4_user<DISC, 8>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
         return;
     }
 #endif
@@ -340,6 +369,7 @@ void eval_seed_rhs(const Emul &E, int b, const double *x, const double *d, int u
         else if (E.dm.maxr == 5) eval_seed4<RhsL96s, DISC, 5>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
         else if (E.dm.maxr == 6) eval_seed4<RhsL96s, DISC, 6>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
         else if (E.dm.maxr == 7) eval_seed4<RhsL96s, DISC, 7>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
+        else if (E.dm.maxr == 12) eval_seed4<RhsL96s, DISC, 12>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
         else eval_seed4<RhsL96s, DISC, 8>(E, b, x, d, use_d, stp, rf_scale, gt, ev);
     } else if (E.dm.emode == 3) {
         if (E.dm.maxr == 4) eval_seed3<RhsL96g, DISC, 4>(E, b, x, d, use_d, stp, rf_scale, gt, ev);

@@ -40,7 +40,7 @@ def test_tile_phases_match_golden_for_every_tiling(golden_single, eval_kernel):
     tiles, every discretisation, scalar/vector RM/RF, nskip 1 and 2."""
     for name, c in golden_single.items():
         desc, keep = _desc(c, eval_kernel=eval_kernel)
-        for T in (2, 7, 50, 72, 84, 400):   # tiny tiles, ragged last tile, K = 5, 6, 7 runs, single tile
+        for T in (2, 7, 50, 72, 84, 144, 400):   # tiny tiles, ragged last tile, K = 5, 6, 7, 12 runs, single tile
             A, me, fe, g = emul.action_grad(desc, T, c["XP"][None, :], c["rf_scale"])
             assert abs(A[0] - c["A"]) <= 1e-12 * abs(c["A"]), (name, T)
             assert abs(me[0] - c["me"]) <= 1e-12 * max(abs(c["me"]), abs(c["A"])), (name, T)
