@@ -1,4 +1,4 @@
-"""usage: VARANNEAL_AMD_LIB=.../libvaranneal_amd_fbst.so python3 tools/nn_fb_probe.py [fused value]
+"""usage: python -m varanneal_amd._build --variant fbst -DVA_FB_STAMPS; VARANNEAL_AMD_LIB=.../libvaranneal_amd_fbst.so python3 tools/nn_fb_probe.py [fused value]
 Phase times of one workgroup of k_nnet_fb at c5x (measurement build -DVA_FB_STAMPS, csrc/va_measure.h)."""
 import os, sys
 import numpy as np
